@@ -1,0 +1,310 @@
+"""Generate tests/golden/*.npz from the LIVE reference and pin the oracle to it.
+
+TEST INFRASTRUCTURE ONLY (see oracle/nfi_oracle.py header).
+
+Runs only where /root/reference exists (the build container).  It
+  1. imports lib.nerf_utils / models.generator from /root/reference with
+     PYTORCH_JIT=0 (scripted functions become plain Python, so the two
+     torch.rand* draws can be intercepted),
+  2. obtains ``render`` by AST-slicing run.py (run.py is a script: argparse at
+     import time) and exec-ing it with stub ``args`` / ``dataset_config``,
+  3. wraps the nerf_utils stage functions and the sampler closure to record
+     every stage boundary,
+  4. runs a set of small seeded cases, asserts that oracle/nfi_oracle.py
+     reproduces every recorded tensor BIT FOR BIT on CPU, and
+  5. writes inputs + reference outputs to tests/golden/.
+
+Usage:  PYTORCH_JIT=0 python oracle/make_golden.py
+"""
+import os
+import sys
+
+os.environ['PYTORCH_JIT'] = '0'
+import ast
+import math
+import types
+import warnings
+
+import numpy as np
+import torch
+
+REF = '/root/reference'
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, REF)
+sys.path.insert(0, ROOT)
+warnings.filterwarnings('ignore')
+
+from lib import nerf_utils as ref_nu          # noqa: E402
+from models import generator as ref_gen       # noqa: E402
+from oracle import nfi_oracle as orc          # noqa: E402
+
+
+def load_reference_render(cfg_args, dataset_config):
+    src = open(os.path.join(REF, 'run.py')).read()
+    tree = ast.parse(src)
+    fn = [n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name == 'render'][0]
+    mod = ast.Module(body=[fn], type_ignores=[])
+    import torch.nn.functional as F
+    g = {'torch': torch, 'F': F, 'nerf_utils': ref_nu, 'args': cfg_args,
+         'dataset_config': dataset_config}
+    exec(compile(mod, 'run.py::render', 'exec'), g)
+    return g['render'], g
+
+
+class Recorder:
+    """Wraps module-level functions to record their outputs."""
+
+    def __init__(self):
+        self.log = {}
+        self._orig = {}
+
+    def wrap(self, module, name, keys):
+        orig = getattr(module, name)
+        self._orig[(module, name)] = orig
+
+        def wrapped(*a, **k):
+            out = orig(*a, **k)
+            outs = out if isinstance(out, tuple) else (out,)
+            for key, val in zip(keys, outs):
+                if key is not None and val is not None:
+                    self.log.setdefault(key, []).append(val.detach().clone())
+            return out
+        setattr(module, name, wrapped)
+
+    def restore(self):
+        for (module, name), orig in self._orig.items():
+            setattr(module, name, orig)
+
+
+class NoiseTap:
+    """Intercepts torch.rand / torch.rand_like in draw order (render draws
+    rand_like [B,H,W,S] first, then rand [N,S])."""
+
+    def __init__(self, gen):
+        self.gen = gen
+        self.draws = []
+
+    def __enter__(self):
+        self._rand, self._rand_like = torch.rand, torch.rand_like
+
+        def rand(*size, **kw):
+            size = size[0] if len(size) == 1 and isinstance(size[0], (list, tuple)) else size
+            out = self._rand(list(size), generator=self.gen, dtype=kw.get('dtype', torch.float32))
+            self.draws.append(out.clone())
+            return out
+
+        def rand_like(t, **kw):
+            out = self._rand(list(t.shape), generator=self.gen, dtype=t.dtype)
+            self.draws.append(out.clone())
+            return out
+        torch.rand, torch.rand_like = rand, rand_like
+        return self
+
+    def __exit__(self, *a):
+        torch.rand, torch.rand_like = self._rand, self._rand_like
+
+
+def look_at_cameras(n, radius, gen, ortho=False):
+    """Random cameras on a sphere looking at the origin (OpenGL convention:
+    camera looks down -z, as nerf_utils.get_ray_bundle expects)."""
+    v = torch.randn(n, 3, generator=gen)
+    eye = radius * v / v.norm(dim=-1, keepdim=True)
+    fwd = -eye / eye.norm(dim=-1, keepdim=True)
+    up = torch.tensor([0., 0., 1.]).expand(n, 3)
+    right = torch.cross(fwd, up, dim=-1)
+    right = right / right.norm(dim=-1, keepdim=True)
+    true_up = torch.cross(right, fwd, dim=-1)
+    cam = torch.eye(4).repeat(n, 1, 1)
+    cam[:, :3, 0] = right
+    cam[:, :3, 1] = true_up
+    cam[:, :3, 2] = -fwd
+    cam[:, :3, 3] = eye
+    return cam
+
+
+CASES = {
+    # name: dict(...)
+    'persp_white_fine_rand': dict(B=2, H=12, W=12, S=16, scene_range=0.55, radius=2.0, focal=1.0254,
+                                  white=True, fine=True, randomize=True, sdf=True, A=10, alpha=0.05,
+                                  beta=0.1, bbox=False, ortho=False),
+    'persp_bbox_black_fine_rand': dict(B=2, H=10, W=14, S=16, scene_range=1.4, radius=2.0, focal=1.0,
+                                       white=False, fine=True, randomize=True, sdf=True, A=10, alpha=0.02,
+                                       beta=0.07, bbox=True, ortho=False),
+    'ortho_fine_det': dict(B=2, H=12, W=12, S=16, scene_range=2.0, radius=3.0, focal=None,
+                           white=False, fine=True, randomize=False, sdf=True, A=10, alpha=0.03,
+                           beta=0.1, bbox=False, ortho=True),
+    'density_rgb_coarse_only': dict(B=2, H=12, W=12, S=32, scene_range=0.55, radius=2.0, focal=1.0254,
+                                    white=True, fine=False, randomize=True, sdf=False, A=0, alpha=1.0,
+                                    beta=0.1, bbox=False, ortho=False),
+    'persp_s64_fine_rand': dict(B=1, H=8, W=8, S=64, scene_range=0.55, radius=1.3, focal=1.0254,
+                                white=True, fine=True, randomize=True, sdf=True, A=10, alpha=0.02,
+                                beta=0.1, bbox=False, ortho=False),
+}
+
+PLANE_RES = 32
+PLANE_CH = 32
+
+
+def make_planes(n_scenes, seed):
+    g = torch.Generator().manual_seed(seed)
+    # smooth-ish random planes: low-res noise upsampled + a little high-res noise
+    low = torch.randn(n_scenes * 3, PLANE_CH, 8, 8, generator=g)
+    up = torch.nn.functional.interpolate(low, size=(PLANE_RES, PLANE_RES), mode='bilinear', align_corners=True)
+    hi = 0.25 * torch.randn(n_scenes * 3, PLANE_CH, PLANE_RES, PLANE_RES, generator=g)
+    return (up + hi).view(n_scenes, 3, PLANE_CH, PLANE_RES, PLANE_RES).contiguous()
+
+
+def run_case(name, c, planes_all):
+    g = torch.Generator().manual_seed(sum(ord(ch) * (i + 1) for i, ch in enumerate(name)))
+    B, H, W, S, A = c['B'], c['H'], c['W'], c['S'], c['A']
+    planes = planes_all[:B]
+    cfg_args = types.SimpleNamespace(use_viewdir=False, use_sdf=c['sdf'], attention_values=A,
+                                     fine_sampling=c['fine'])
+    dataset_config = {'scene_range': c['scene_range'], 'white_background': c['white']}
+    render, _ = load_reference_render(cfg_args, dataset_config)
+
+    torch.manual_seed(1234)
+    gen = ref_gen.Generator(512, c['scene_range'], attention_values=A, use_sdf=c['sdf'],
+                            disable_stylegan_noise=True)
+    gen.eval()
+    # plane producer stub: the StyleGAN2 synthesis network is outside the hot path
+    class PlaneStub(torch.nn.Module):
+        def forward(self, ws, **kw):
+            return planes.reshape(B, 3 * PLANE_CH, PLANE_RES, PLANE_RES)
+    gen.synthesis_network = PlaneStub()
+    with torch.no_grad():
+        gen.decoder.net[0].weight.copy_(torch.randn(64, 32, generator=g))
+        gen.decoder.net[0].bias.copy_(0.5 * torch.randn(64, generator=g))
+        gen.decoder.net[2].weight.copy_(torch.randn(1 + max(A, 3) if A == 0 else 1 + A, 64, generator=g))
+        gen.decoder.net[2].bias.copy_(0.5 * torch.randn(gen.decoder.net[2].bias.shape[0], generator=g))
+        if c['sdf']:
+            gen.beta.fill_(c['beta'])
+            gen.alpha.fill_(c['alpha'])
+    cam = look_at_cameras(B, c['radius'], g)
+    focal = None if c['ortho'] else torch.full((B,), c['focal']) * (1 + 0.05 * torch.randn(B, generator=g))
+    bbox = None
+    if c['bbox']:
+        start = -0.8 + 0.2 * torch.rand(B, 2, generator=g)
+        extent = 1.4 + 0.4 * torch.rand(B, 2, generator=g)
+        bbox = torch.stack((start, extent), dim=1)           # [B,2,2]
+    num_ws = 15 if A > 0 else 14
+    ws = torch.randn(B, num_ws, 512, generator=g)
+    att = None
+    extra_in = {}
+    if A > 0:
+        att = torch.sigmoid(torch.randn(B, A, 3, generator=g)) * 2.004 - 1.002
+        extra_in = {'attention_values': att}
+
+    rec = Recorder()
+    rec.wrap(ref_nu, 'get_ray_bundle', ['ro', 'rd_raw'])
+    rec.wrap(ref_nu, 'compute_near_far_planes', ['near', 'far'])
+    rec.wrap(ref_nu, 'compute_query_points_from_rays', ['x_coarse', 't_coarse'])
+    rec.wrap(ref_nu, 'render_volume_density_weights_only', ['weights_coarse'])
+    rec.wrap(ref_nu, 'sample_pdf', ['t_fine'])
+    sampler_log = []
+    orig_forward = gen.forward
+
+    def fwd(*a, **k):
+        out = orig_forward(*a, **k)
+        smp = out['sampler']
+
+        def tapped(x_in, req=['sigma', 'rgb']):
+            r = smp(x_in, req)
+            sampler_log.append({k2: v.detach().clone() for k2, v in r.items()})
+            return r
+        out['sampler'] = tapped
+        return out
+    gen.forward = fwd
+
+    noise_gen = torch.Generator().manual_seed(4321)
+    with torch.no_grad(), NoiseTap(noise_gen) as tap:
+        rgb, depth, mask, normals, sem, _ = render(
+            gen, H, W, cam, focal, None, bbox, ws, S, randomize=c['randomize'],
+            compute_semantics=(A > 0), extra_model_inputs=extra_in)
+    rec.restore()
+    noise_c = tap.draws[0] if c['randomize'] else None
+    noise_f = tap.draws[1] if (c['randomize'] and c['fine']) else None
+
+    dec = gen.decoder.net
+    w1, b1, w2, b2 = dec[0].weight.detach(), dec[0].bias.detach(), dec[2].weight.detach(), dec[2].bias.detach()
+    beta = gen.beta.detach() if c['sdf'] else None
+    alpha = gen.alpha.detach() if c['sdf'] else None
+
+    # ---- oracle must reproduce the reference bit for bit -------------------
+    with torch.no_grad():
+        o = orc.render(planes, w1, b1, w2, b2, cam, focal, H, W, S, c['scene_range'],
+                       white_background=c['white'], fine_sampling=c['fine'], bbox=bbox,
+                       noise_coarse=noise_c, noise_fine=noise_f, use_sdf=c['sdf'], beta=beta,
+                       alpha=alpha, attention_values=att, want_semantics=(A > 0))
+
+    def same(a, b, what):
+        assert a.shape == b.shape, (name, what, a.shape, b.shape)
+        assert torch.equal(a, b), (name, what, (a - b).abs().max().item())
+    same(o['rgb'], rgb, 'rgb')
+    same(o['depth'], depth, 'depth')
+    same(o['mask'], mask, 'mask')
+    if A > 0:
+        same(o['semantics'], sem, 'semantics')
+    same(o['ro'], rec.log['ro'][0].expand_as(o['ro']), 'ro')
+    same(o['near'], rec.log['near'][0], 'near')
+    same(o['far'], rec.log['far'][0], 'far')
+    same(o['t_coarse'], rec.log['t_coarse'][0], 't_coarse')
+    shp = o['t_coarse'].shape
+    same(o['sigma_coarse'], sampler_log[0]['sigma'].view(*shp), 'sigma_coarse')
+    same(o['rgb_coarse'], sampler_log[0]['rgb'].view(*shp, 3), 'rgb_coarse')
+    if c['fine']:
+        same(o['weights_coarse'], rec.log['weights_coarse'][0].flatten(0, 2), 'weights_coarse')
+        same(o['t_fine'].flatten(0, 2), rec.log['t_fine'][0], 't_fine')
+        same(o['sigma_fine'], sampler_log[1]['sigma'].view(*shp), 'sigma_fine')
+        same(o['rgb_fine'], sampler_log[1]['rgb'].view(*shp, 3), 'rgb_fine')
+
+    out = dict(cam2world=cam, w1=w1, b1=b1, w2=w2, b2=b2,
+               ref_rgb=rgb, ref_depth=depth, ref_mask=mask,
+               ref_ro=o['ro'], ref_rd=o['rd'], ref_near=o['near'], ref_far=o['far'], ref_hit=o['hit'],
+               ref_t_coarse=o['t_coarse'], ref_sigma_coarse=o['sigma_coarse'],
+               ref_rgb_coarse=o['rgb_coarse'], ref_outside_coarse=o['outside_coarse'],
+               ref_sdf_coarse=o['sdf_coarse'], ref_weights=o['weights'])
+    if focal is not None:
+        out['focal'] = focal
+    if bbox is not None:
+        out['bbox'] = bbox
+    if att is not None:
+        out['attention_values'] = att
+        out['ref_semantics'] = sem
+    if c['sdf']:
+        out['beta'] = beta
+        out['alpha'] = alpha
+    if noise_c is not None:
+        out['noise_coarse'] = noise_c
+    if noise_f is not None:
+        out['noise_fine'] = noise_f
+    if c['fine']:
+        out.update(ref_weights_coarse=o['weights_coarse'], ref_weights_smooth=o['weights_smooth'],
+                   ref_cdf=o['cdf'], ref_inds=o['inds'], ref_t_fine=o['t_fine'],
+                   ref_sigma_fine=o['sigma_fine'], ref_rgb_fine=o['rgb_fine'],
+                   ref_perm=o['perm'], ref_t_sorted=o['t_sorted'])
+    meta = {k: v for k, v in c.items()}
+    return out, meta
+
+
+def main():
+    import json
+    gold = os.path.join(ROOT, 'tests', 'golden')
+    os.makedirs(gold, exist_ok=True)
+    planes = make_planes(2, 777)
+    np.savez(os.path.join(gold, 'planes.npz'), planes=planes.numpy())
+    metas = {}
+    for name, c in CASES.items():
+        out, meta = run_case(name, c, planes)
+        np.savez(os.path.join(gold, name + '.npz'), **{k: v.numpy() for k, v in out.items()})
+        metas[name] = meta
+        print('%-28s ok  mask mean %.3f  rgb mean %.3f  hit %.2f' %
+              (name, out['ref_mask'].mean().item(), out['ref_rgb'].mean().item(),
+               out['ref_hit'].float().mean().item()))
+    json.dump(metas, open(os.path.join(gold, 'cases.json'), 'w'), indent=1, sort_keys=True)
+    print('torch', torch.__version__, '-> wrote', gold)
+
+
+if __name__ == '__main__':
+    main()

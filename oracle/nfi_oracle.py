@@ -1,0 +1,296 @@
+"""CPU oracle for the nerf-from-image volumetric-rendering hot path.
+
+TEST INFRASTRUCTURE ONLY.  Nothing under ``nerf_from_image_amd/`` may import
+this module; only ``tests/``, ``__graft_entry__.smoke()`` and the
+``cpu_baseline`` leg of ``bench.py`` do, and there only as the checker /
+reported baseline, never as the product path.
+
+What it is: a stage-by-stage restatement of the reference renderer in plain
+torch ops on whatever device the inputs live on (CPU in practice).  The
+reference's numerics live in ATen (``grid_sample``, ``softplus``, ``softmax``,
+``searchsorted``, ``sort``, ``cumprod`` ...), so the oracle calls the same ATen
+ops, but with the two random draws turned into explicit arguments and every
+stage boundary returned, so that the HIP kernels can be checked stage by stage
+on identical float inputs.
+
+Reference lines each function follows (paths relative to /root/reference):
+
+  ray_bundle            lib/nerf_utils.py:28-91   (get_ray_bundle)
+  unit_dirs             run.py:196                (F.normalize)
+  near_far              lib/nerf_utils.py:225-273 (compute_near_far_planes)
+  stratified_depths     lib/nerf_utils.py:94-120  (compute_query_points_from_rays)
+  points_on_rays        lib/nerf_utils.py:117-118 / run.py:286-288
+  decoder_params        models/stylegan.py:173-180 (EqualizedLinear gains)
+  field_query           models/generator.py:301-331, 587-681 (decoder + sampler)
+  ray_weights           lib/nerf_utils.py:164-180, 20-25
+  smooth_weights        run.py:264-272
+  inverse_cdf           lib/nerf_utils.py:183-222 (sample_pdf)
+  merge_sorted          run.py:283-335
+  composite             lib/nerf_utils.py:123-161
+  render                run.py:176-350
+
+Pinning: ``oracle/make_golden.py`` runs the *live* reference (imported from
+/root/reference, ``render`` AST-sliced out of run.py) on seeded inputs with the
+same noise and asserts this restatement reproduces every output bit for bit on
+CPU before it writes ``tests/golden/*.npz``.  ``tests/test_oracle_golden.py``
+re-checks the oracle against those committed vectors wherever it runs.
+"""
+import math
+from typing import Dict, Optional
+
+import torch
+import torch.nn.functional as F
+
+
+# --------------------------------------------------------------------------- #
+# camera rays
+# --------------------------------------------------------------------------- #
+def ray_bundle(height: int, width: int, focal: Optional[torch.Tensor],
+               cam2world: torch.Tensor, bbox: Optional[torch.Tensor] = None,
+               center: Optional[torch.Tensor] = None):
+    """Pixel (row j, col i) -> world ray.  focal=None selects the ortho model."""
+    dev = cam2world.device
+    col = torch.arange(width, device=dev) / width      # left pixel edge, i/W
+    row = torch.arange(height, device=dev) / height
+    u = col.view(1, 1, width).expand(1, height, width)
+    v = row.view(1, height, 1).expand(1, height, width)
+    rot = cam2world[:, None, None, :3, :3]
+    trans = cam2world[:, None, None, :3, -1]
+    if focal is not None:
+        if center is not None:
+            u = u - 0.5 * (2 * center[:, 0, None, None] - 1) - 0.5
+            v = v - 0.5 * (2 * center[:, 1, None, None] - 1) - 0.5
+        else:
+            u = u - 0.5
+            v = v - 0.5
+        if bbox is not None:
+            u = (bbox[:, 1:2, 0].unsqueeze(-1) * (u + 0.5) + bbox[:, 0:1, 0].unsqueeze(-1)) * 0.5
+            v = -(bbox[:, 1:2, 1].unsqueeze(-1) * (-v + 0.5) + bbox[:, 0:1, 1].unsqueeze(-1)) * 0.5
+        f = focal.view(-1, 1, 1)
+        u = u / f
+        v = v / f
+        cam_dir = torch.stack((u, -v, -torch.ones_like(u)), dim=-1)
+        rd = (cam_dir[..., None, :] * rot).sum(dim=-1)
+        ro = trans.expand(rd.shape)
+    else:
+        u = (u - 0.5) * 2
+        v = (v - 0.5) * 2
+        if bbox is not None:
+            u = bbox[:, 1:2, 0].unsqueeze(-1) * (u / 2 + 0.5) + bbox[:, 0:1, 0].unsqueeze(-1)
+            v = -(bbox[:, 1:2, 1].unsqueeze(-1) * (-v / 2 + 0.5) + bbox[:, 0:1, 1].unsqueeze(-1))
+        zero = torch.zeros_like(u)
+        cam_org = torch.stack((u, -v, zero), dim=-1)
+        cam_dir = torch.stack((zero, zero, -torch.ones_like(u)), dim=-1)
+        ro = (cam_org[..., None, :] * rot).sum(dim=-1) + trans
+        rd = (cam_dir[..., None, :] * rot).sum(dim=-1) / cam2world[:, None, None, 3, 3].unsqueeze(-1)
+    return ro, rd
+
+
+def unit_dirs(rd: torch.Tensor) -> torch.Tensor:
+    return F.normalize(rd, dim=-1)
+
+
+def near_far(ro: torch.Tensor, rd: torch.Tensor, scene_range: float):
+    """Slab test against the cube [-r, r]^3.  Returns near, far, hit (bool).
+
+    Rays that miss take the min(near)/max(far) of the rays that hit, over the
+    whole batch handed in (a replica-wide reduction in the reference)."""
+    shape = ro.shape[:-1]
+    o = ro.detach().reshape(-1, 3)
+    d = rd.detach().reshape(-1, 3)
+    r = torch.tensor(scene_range, dtype=o.dtype, device=o.device)
+    inv = 1 / d
+    neg = inv < 0
+    lo_b = torch.where(neg, r, -r)          # bound giving the entry distance
+    hi_b = torch.where(neg, -r, r)
+    lo = (lo_b - o) * inv
+    hi = (hi_b - o) * inv
+    hit = ~((lo[:, 0] > hi[:, 1]) | (lo[:, 1] > hi[:, 0]))
+    near = torch.max(lo[:, 0], lo[:, 1])
+    far = torch.min(hi[:, 0], hi[:, 1])
+    hit = hit & ~((near > hi[:, 2]) | (lo[:, 2] > far))
+    near = torch.max(near, lo[:, 2])
+    far = torch.min(far, hi[:, 2])
+    fill_near = near[hit].min()             # raises on "no ray hits", like the reference
+    fill_far = far[hit].max()
+    near = torch.where(hit, near, fill_near)
+    far = torch.where(hit, far, fill_far)
+    near = near.clamp(min=0.1)
+    far = far.clamp(min=0.1)
+    thin = (far - near) < 1e-3
+    far = torch.where(thin, near + 1e-3, far)
+    return near.reshape(shape), far.reshape(shape), hit.reshape(shape)
+
+
+def stratified_depths(near: torch.Tensor, far: torch.Tensor, num_samples: int,
+                      noise: Optional[torch.Tensor]) -> torch.Tensor:
+    """t_k = lerp(near, far, k/S) (+ noise_k * (far-near)/S).  noise: [..., S] in [0,1)."""
+    n = near.unsqueeze(-1)
+    f = far.unsqueeze(-1)
+    frac = torch.arange(num_samples, device=near.device) / num_samples
+    t = torch.lerp(n, f, frac)
+    if noise is not None:
+        t = t + noise * ((f - n) / num_samples)
+    return t
+
+
+def points_on_rays(ro: torch.Tensor, rd: torch.Tensor, t: torch.Tensor) -> torch.Tensor:
+    return ro[..., None, :] + rd[..., None, :] * t[..., :, None]
+
+
+# --------------------------------------------------------------------------- #
+# triplane field
+# --------------------------------------------------------------------------- #
+def decoder_params(w1, b1, w2, b2):
+    """Apply the equalized-learning-rate gains (lr_multiplier = 1)."""
+    return (w1 * (1.0 / math.sqrt(w1.shape[1])), b1 * 1.0,
+            w2 * (1.0 / math.sqrt(w2.shape[1])), b2 * 1.0)
+
+
+def field_query(planes: torch.Tensor, w1, b1, w2, b2, x_in: torch.Tensor,
+                scene_range: float, use_sdf: bool = True,
+                beta: Optional[torch.Tensor] = None, alpha: Optional[torch.Tensor] = None,
+                attention_values: Optional[torch.Tensor] = None) -> Dict[str, torch.Tensor]:
+    """planes [B,3,C,Hp,Wp]; x_in [B,...,3] world points; raw (un-gained) decoder
+    weights w1 [64,C], b1 [64], w2 [1+A,64], b2 [1+A]; attention_values [B,A,3] or None.
+
+    Returns flat per-scene tensors: sigma [B,P], rgb [B,P,3], sdf [B,P],
+    outside [B,P] (1.0 where the point is outside the scene cube) and, when
+    attention_values is given, semantics [B,P,A]."""
+    bs = x_in.shape[0]
+    x = x_in.reshape(bs, -1, 1, 3) / scene_range
+    outside = (x.abs() > 1).any(dim=-1).float().flatten(1)
+    feats = 0
+    pairs = ((0, 1), (0, 2), (1, 2))
+    sampled = [F.grid_sample(planes[:, p], x[..., list(ax)], mode='bilinear',
+                             padding_mode='border', align_corners=True)
+               for p, ax in enumerate(pairs)]
+    feats = (sampled[0] + sampled[1] + sampled[2]) / 3
+    feats = feats.view(bs, planes.shape[2], -1).transpose(-2, -1)
+    gw1, gb1, gw2, gb2 = decoder_params(w1, b1, w2, b2)
+    hidden = F.softplus(F.linear(feats, gw1, gb1))
+    out = F.linear(hidden, gw2, gb2)
+    dist = out[..., 0]
+    feat = out[..., 1:]
+    res = {'sdf': dist, 'outside': outside}
+    if use_sdf:
+        neg = -dist
+        cdf = 0.5 + 0.5 * torch.sign(neg) * (1 - torch.exp(-neg.abs() / beta))
+        res['sigma'] = (1 / alpha) * (cdf * (1 - outside))
+    else:
+        res['sigma'] = F.softplus(dist - 1) * (1 - outside)
+    if attention_values is None:
+        res['rgb'] = torch.sigmoid(feat) * 2.004 - 1.002
+    else:
+        probs = F.softmax(feat, dim=-1)
+        res['semantics'] = probs
+        res['rgb'] = torch.matmul(probs, attention_values)
+    return res
+
+
+# --------------------------------------------------------------------------- #
+# per-ray sampling / compositing
+# --------------------------------------------------------------------------- #
+def _alpha_weights(sigma, rd, t):
+    zero = torch.zeros_like(t[..., :1])
+    delta = torch.cat((t[..., 1:] - t[..., :-1], zero), dim=-1)
+    delta = delta * rd.norm(p=2, dim=-1, keepdim=True)
+    a = 1. - torch.exp(-sigma * delta)
+    trans = torch.cumprod((1. - a + 1e-10)[..., :-1], dim=-1)
+    trans = torch.cat((torch.ones_like(trans[..., :1]), trans), dim=-1)
+    return a * trans
+
+
+def ray_weights(sigma, rd, t):
+    return _alpha_weights(sigma, rd, t)
+
+
+def smooth_weights(w: torch.Tensor) -> torch.Tensor:
+    """w [N,S] -> dilate(2) -> box(2) -> +0.01, [N,S]."""
+    m = F.max_pool1d(w.unsqueeze(1).float(), 2, 1, padding=1)
+    return F.avg_pool1d(m, 2, 1).squeeze(1) + 0.01
+
+
+def inverse_cdf(bins: torch.Tensor, weights: torch.Tensor, u: torch.Tensor):
+    """bins [N,M], weights [N,M-1], u [N,K] -> samples [N,K], inds int64 [N,K], cdf [N,M]."""
+    w = weights + 1e-5
+    pdf = w / w.sum(dim=-1, keepdim=True)
+    cdf = torch.cumsum(pdf, dim=-1)
+    cdf = torch.cat((torch.zeros_like(cdf[..., :1]), cdf), dim=-1).contiguous()
+    u = u.contiguous()
+    inds = torch.searchsorted(cdf, u, right=True)
+    lo = (inds - 1).clamp(min=0)
+    hi = inds.clamp(max=cdf.shape[-1] - 1)
+    c_lo, c_hi = cdf.gather(-1, lo), cdf.gather(-1, hi)
+    b_lo, b_hi = bins.gather(-1, lo), bins.gather(-1, hi)
+    den = c_hi - c_lo
+    den = torch.where(den < 1e-5, torch.ones_like(den), den)
+    frac = (u - c_lo) / den
+    return b_lo + frac * (b_hi - b_lo), inds, cdf
+
+
+def deterministic_u(n_rows: int, num_samples: int, like: torch.Tensor) -> torch.Tensor:
+    u = torch.linspace(0.0, 1.0, steps=num_samples, dtype=like.dtype, device=like.device)
+    return u.expand(n_rows, num_samples)
+
+
+def composite(sigma, rgb, rd, t, semantics=None, white_background=True):
+    w = _alpha_weights(sigma, rd, t)
+    rgb_map = (w[..., None] * rgb).sum(dim=-2)
+    depth_map = (w * t).sum(dim=-1)
+    sem_map = (w[..., None] * semantics).sum(dim=-2) if semantics is not None else None
+    acc = w.sum(-1)
+    if white_background:
+        rgb_map = rgb_map + (1. - acc[..., None])
+    return rgb_map, depth_map, acc, sem_map, w
+
+
+# --------------------------------------------------------------------------- #
+# whole pipeline
+# --------------------------------------------------------------------------- #
+def render(planes, w1, b1, w2, b2, cam2world, focal, height, width, num_samples,
+           scene_range, white_background=True, fine_sampling=True, bbox=None, center=None,
+           noise_coarse=None, noise_fine=None, use_sdf=True, beta=None, alpha=None,
+           attention_values=None, want_semantics=False):
+    """Oracle restatement of run.py:176-350 given precomputed planes.
+
+    noise_coarse [B,H,W,S] / noise_fine [B*H*W,S] in [0,1) or None (deterministic:
+    no jitter, linspace u).  Returns a dict with every stage boundary."""
+    o = {}
+    ro, rd = ray_bundle(height, width, focal, cam2world, bbox, center)
+    rd = unit_dirs(rd)
+    near, far, hit = near_far(ro, rd, scene_range)
+    o.update(ro=ro, rd=rd, near=near, far=far, hit=hit)
+    t_c = stratified_depths(near, far, num_samples, noise_coarse)
+    x_c = points_on_rays(ro, rd, t_c)
+    shp = x_c.shape[:-1]
+    q = field_query(planes, w1, b1, w2, b2, x_c, scene_range, use_sdf, beta, alpha, attention_values)
+    sigma = q['sigma'].view(*shp)
+    rgb = q['rgb'].view(*shp, 3)
+    sem = q['semantics'].view(*shp, -1) if (want_semantics and 'semantics' in q) else None
+    o.update(t_coarse=t_c, sigma_coarse=sigma, rgb_coarse=rgb, outside_coarse=q['outside'].view(*shp),
+             sdf_coarse=q['sdf'].view(*shp))
+    t = t_c
+    if fine_sampling:
+        w = ray_weights(sigma, rd, t_c).flatten(0, 2)
+        ws = smooth_weights(w)
+        mid = (.5 * (t_c[..., 1:] + t_c[..., :-1])).flatten(0, 2)
+        u = noise_fine if noise_fine is not None else deterministic_u(ws.shape[0], num_samples, ws)
+        t_f, inds, cdf = inverse_cdf(mid, ws[..., 1:-1], u)
+        t_f = t_f.view(*t_c.shape[:3], -1)
+        o.update(weights_coarse=w, weights_smooth=ws, cdf=cdf, inds=inds, t_fine=t_f)
+        t, perm = torch.sort(torch.cat((t_c, t_f), dim=-1), dim=-1)
+        x_f = points_on_rays(ro, rd, t_f)
+        qf = field_query(planes, w1, b1, w2, b2, x_f, scene_range, use_sdf, beta, alpha, attention_values)
+        sigma_f = qf['sigma'].view(*shp[:3], -1)
+        rgb_f = qf['rgb'].view(*shp[:3], -1, 3)
+        o.update(sigma_fine=sigma_f, rgb_fine=rgb_f, perm=perm, t_sorted=t)
+        sigma = torch.cat((sigma, sigma_f), dim=-1).gather(-1, perm)
+        rgb = torch.cat((rgb, rgb_f), dim=-2).gather(-2, perm.unsqueeze(-1).expand(-1, -1, -1, -1, 3))
+        if sem is not None:
+            sem_f = qf['semantics'].view(*shp[:3], -1, sem.shape[-1])
+            sem = torch.cat((sem, sem_f), dim=-2).gather(
+                -2, perm.unsqueeze(-1).expand(-1, -1, -1, -1, sem.shape[-1]))
+    rgb_map, depth_map, acc, sem_map, wts = composite(sigma, rgb, rd, t, sem, white_background)
+    o.update(rgb=rgb_map, depth=depth_map, mask=acc, semantics=sem_map, weights=wts)
+    return o

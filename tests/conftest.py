@@ -1,0 +1,37 @@
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+GOLDEN = os.path.join(ROOT, 'tests', 'golden')
+
+
+def pytest_configure(config):
+    config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
+
+
+def golden_case_names():
+    return sorted(json.load(open(os.path.join(GOLDEN, 'cases.json'))).keys())
+
+
+def load_golden(name, device='cpu'):
+    """Returns (meta dict, tensors dict) for a committed golden case."""
+    meta = json.load(open(os.path.join(GOLDEN, 'cases.json')))[name]
+    z = np.load(os.path.join(GOLDEN, name + '.npz'))
+    t = {k: torch.from_numpy(z[k]).to(device) for k in z.files}
+    planes = torch.from_numpy(np.load(os.path.join(GOLDEN, 'planes.npz'))['planes'])
+    t['planes'] = planes[:meta['B']].contiguous().to(device)
+    return meta, t
+
+
+@pytest.fixture(scope='session')
+def gpu_device():
+    if not torch.cuda.is_available():
+        pytest.skip('no GPU visible')
+    return torch.device('cuda:0')
