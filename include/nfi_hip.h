@@ -1,0 +1,279 @@
+/*
+ * nfi_hip.h — C ABI of libnfi_hip.so, the MI355X (gfx950) implementation of the
+ * nerf-from-image volumetric-rendering hot path.
+ *
+ * The reference (google-research/nerf-from-image) has no FFI: the boundary of this
+ * path is a set of Python callables.  Each entry point below names the reference
+ * callable it replaces (file:line relative to the reference checkout); the Python
+ * binding in nerf_from_image_amd/ calls these through ctypes and re-creates the
+ * reference's call surface on top (lib/nerf_utils.py functions, the Generator
+ * `sampler` closure, run.py::render).  INTEGRATION.md shows the binding.
+ *
+ * Conventions
+ *   - every pointer is a CALLER-OWNED DEVICE pointer (HIP, same device as the
+ *     stream) unless the field says "host"; nothing is allocated, nothing is
+ *     synchronised, every launch goes to the caller's stream;
+ *   - all entry points are re-entrant (no global mutable state): the reference
+ *     calls this path concurrently from one thread per GPU (nn.DataParallel,
+ *     run.py:636-640);
+ *   - return value: 0 on success, a negative nfi_status otherwise;
+ *     nfi_last_error() returns a thread-local message for the last failure;
+ *   - tensors are dense row-major fp32 unless stated; "N" is the number of rays
+ *     B*H*W, "S" the samples per ray and pass.
+ */
+#ifndef NFI_HIP_H
+#define NFI_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* nfi_stream_t; /* hipStream_t */
+
+typedef enum nfi_status {
+  NFI_OK = 0,
+  NFI_ERR_INVALID_ARGUMENT = -1,
+  NFI_ERR_UNSUPPORTED = -2,
+  NFI_ERR_WORKSPACE_TOO_SMALL = -3,
+  NFI_ERR_LAUNCH = -4
+} nfi_status;
+
+enum { NFI_PLANE_CHANNELS = 32, NFI_HIDDEN = 64, NFI_MAX_ATTENTION = 14, NFI_MAX_SAMPLES = 128 };
+
+/* texel storage type of the channel-last plane image */
+enum { NFI_TEXEL_F32 = 0, NFI_TEXEL_BF16 = 1 };
+
+const char* nfi_last_error(void);
+int nfi_version(void);
+
+/* ------------------------------------------------------------------------------------------
+ * Triplane hand-off: NCHW planes from the synthesis network -> channel-last texels.
+ * Replaces the implicit layout the reference gathers from (models/generator.py:475-477,
+ * 501-503: planes.view(B,3,32,R,R); F.grid_sample reads NCHW).  A texel (32 channels) becomes
+ * one 128-byte line (fp32) / 64-byte line (bf16).
+ *   planes  [B,3,32,R,R] fp32      texels  [B,3,R,R,32] fp32|bf16
+ * ------------------------------------------------------------------------------------------ */
+int nfi_planes_to_texels(const float* planes, void* texels, int n_scenes, int plane_res,
+                         int texel_dtype, nfi_stream_t stream);
+/* adjoint of the above (fp32 only): texel-layout gradient -> NCHW gradient */
+int nfi_texels_to_planes(const float* texels, float* planes, int n_scenes, int plane_res,
+                         nfi_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Decoder operand image.  Replaces the per-call weight scaling of EqualizedLinear
+ * (models/stylegan.py:173-180: W * 1/sqrt(in), b * 1) for TriplanarDecoder.net
+ * (models/generator.py:295-299): folds the gains, the /3 of the plane mean
+ * (generator.py:328) and the exp2/log2 change of base into a lane-ordered MFMA operand image.
+ *   w1 [64,32]  b1 [64]  w2 [n_out,64]  b2 [n_out]   (raw parameters, n_out = 1+A, or 4 if A==0)
+ *   image: nfi_decoder_image_floats() floats
+ * ------------------------------------------------------------------------------------------ */
+size_t nfi_decoder_image_floats(void);
+int nfi_decoder_pack(const float* w1, const float* b1, const float* w2, const float* b2,
+                     int n_attention, int texel_dtype, float* image, nfi_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Camera rays + scene-box intersection.
+ * Replaces nerf_utils.get_ray_bundle (lib/nerf_utils.py:28-91), F.normalize (run.py:196)
+ * and nerf_utils.compute_near_far_planes (lib/nerf_utils.py:225-273).
+ * ------------------------------------------------------------------------------------------ */
+typedef struct nfi_raygen_args {
+  int n_scenes, height, width;
+  const float* cam2world;   /* [B,4,4] */
+  const float* focal;       /* [B] or NULL -> orthographic model (nerf_utils.py:66-89) */
+  const float* bbox;        /* [B,2,2] or NULL */
+  const float* center;      /* [B,2] or NULL (perspective only) */
+  int normalize;            /* 1: ray directions L2-normalised (run.py:196) */
+  float* ray_origins;       /* [N,3] out */
+  float* ray_directions;    /* [N,3] out */
+} nfi_raygen_args;
+int nfi_raygen(const nfi_raygen_args* a, nfi_stream_t stream);
+
+typedef struct nfi_near_far_args {
+  int64_t n_rays;
+  const float* ray_origins;    /* [N,3] */
+  const float* ray_directions; /* [N,3] */
+  float scene_range;
+  float* near_raw;  /* [N] out: slab entry distance before the miss-fill / clamps */
+  float* far_raw;   /* [N] out */
+  uint8_t* hit;     /* [N] out: 1 if the ray's line meets the cube */
+  uint32_t* reduce; /* [4] out: order-preserving keys of min(near|hit), max(far|hit), hit count, 0 */
+  /* optional: finished planes (miss-fill with the batch-wide min/max, clamp >= 0.1,
+   * far-near >= 1e-3; nerf_utils.py:258-268).  NULL to skip. */
+  float* near_plane; /* [N] out or NULL */
+  float* far_plane;  /* [N] out or NULL */
+} nfi_near_far_args;
+int nfi_near_far(const nfi_near_far_args* a, nfi_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Stratified depths + query points.  Replaces nerf_utils.compute_query_points_from_rays
+ * (lib/nerf_utils.py:94-120).  noise: the reference's torch.rand_like draw, or NULL.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct nfi_stratified_args {
+  int64_t n_rays;
+  int n_samples;
+  const float* ray_origins;    /* [N,3] */
+  const float* ray_directions; /* [N,3] */
+  const float* near_plane;     /* [N] */
+  const float* far_plane;      /* [N] */
+  const float* noise;          /* [N,S] in [0,1) or NULL */
+  float* depth;                /* [N,S] out */
+  float* points;               /* [N,S,3] out */
+} nfi_stratified_args;
+int nfi_stratified_points(const nfi_stratified_args* a, nfi_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Field query: the `sampler` closure of Generator.forward (models/generator.py:587-681) with
+ * TriplanarDecoder.forward (301-331), laplace_cdf (30-33) and the colour head (661-679).
+ *   points [B,P,3] world coordinates -> sigma [B,P], rgb [B,P,3], optional sdf [B,P]
+ *   (raw decoder output 0), semantics [B,P,A] (softmax probabilities), outside [B,P] (u8).
+ * ------------------------------------------------------------------------------------------ */
+typedef struct nfi_field_args {
+  int n_scenes;
+  int64_t points_per_scene;
+  const float* points;           /* [B,P,3] */
+  const void* texels;            /* [B,3,R,R,32] */
+  int plane_res;
+  int texel_dtype;
+  const float* decoder_image;    /* from nfi_decoder_pack (same texel_dtype, same n_attention) */
+  int n_attention;               /* A; 0 -> rgb = wide sigmoid of 3 features */
+  const float* attention_values; /* [B,A,3] (A>0) */
+  int use_sdf;                   /* 1: sigma = laplace_cdf(-d,beta)/alpha; 0: softplus(d-1) */
+  const float* beta;             /* device scalar (use_sdf) */
+  const float* alpha;            /* device scalar (use_sdf) */
+  float scene_range;
+  float* sigma;                  /* [B,P] out */
+  float* rgb;                    /* [B,P,3] out */
+  float* sdf;                    /* [B,P] out or NULL */
+  float* semantics;              /* [B,P,A] out or NULL */
+  uint8_t* outside;              /* [B,P] out or NULL */
+} nfi_field_args;
+int nfi_field_query_fwd(const nfi_field_args* a, nfi_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Per-ray weights.  Replaces nerf_utils.render_volume_density_weights_only
+ * (lib/nerf_utils.py:164-180, cumprod_exclusive 20-25).
+ * ------------------------------------------------------------------------------------------ */
+typedef struct nfi_weights_args {
+  int64_t n_rays;
+  int n_samples;               /* <= NFI_MAX_SAMPLES */
+  const float* sigma;          /* [N,S] */
+  const float* ray_directions; /* [N,3] */
+  const float* depth;          /* [N,S] */
+  float* weights;              /* [N,S] out */
+} nfi_weights_args;
+int nfi_ray_weights(const nfi_weights_args* a, nfi_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Inverse-CDF sampling.  Replaces nerf_utils.sample_pdf (lib/nerf_utils.py:183-222).
+ *   bins [N,M], weights [N,M-1], u [N,K] (row stride u_row_stride floats; 0 broadcasts one
+ *   row, which is how the deterministic linspace(0,1,K) of the reference is passed)
+ *   -> samples [N,K]; optional inds int64 [N,K] (searchsorted(cdf,u,right=True)), cdf [N,M].
+ *   M <= 128, K <= 128.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct nfi_sample_pdf_args {
+  int64_t n_rays;
+  int n_bins;      /* M */
+  int n_samples;   /* K */
+  const float* bins;
+  const float* weights;
+  const float* u;
+  int64_t u_row_stride;
+  float* samples;
+  int64_t* inds;   /* or NULL */
+  float* cdf;      /* or NULL */
+} nfi_sample_pdf_args;
+int nfi_sample_pdf(const nfi_sample_pdf_args* a, nfi_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Hierarchical resampling as run.py does it between the two field queries: coarse weights
+ * (run.py:262) -> EG3D smoothing (264-272) -> sample_pdf on the bin mid-points (274-281).
+ *   sigma,depth [N,S]; u as above with K = S  ->  fine depths [N,S] (unsorted, like the reference)
+ * ------------------------------------------------------------------------------------------ */
+typedef struct nfi_resample_args {
+  int64_t n_rays;
+  int n_samples;               /* S <= 64 */
+  const float* sigma;
+  const float* ray_directions;
+  const float* depth;
+  const float* u;
+  int64_t u_row_stride;
+  float* fine_depth;           /* [N,S] out */
+  float* weights;              /* [N,S] out or NULL (coarse weights) */
+  float* smooth;               /* [N,S] out or NULL */
+  float* cdf;                  /* [N,S-1] out or NULL */
+  int64_t* inds;               /* [N,S] out or NULL */
+} nfi_resample_args;
+int nfi_resample(const nfi_resample_args* a, nfi_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Alpha compositing.  Replaces nerf_utils.render_volume_density (lib/nerf_utils.py:123-161)
+ * and, when depth_b != NULL, the sort/merge of run.py:283-335 in front of it: the two depth
+ * lists are merged ascending (stable: list a first on ties) and attributes follow.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct nfi_composite_args {
+  int64_t n_rays;
+  int n_a;                      /* samples in list a (<= 128 total with n_b) */
+  int n_b;                      /* 0: plain compositing of list a, assumed in ray order */
+  const float* ray_directions;  /* [N,3] */
+  const float* depth_a; const float* sigma_a; const float* rgb_a;  /* [N,n_a], [N,n_a], [N,n_a,3] */
+  const float* depth_b; const float* sigma_b; const float* rgb_b;  /* [N,n_b] ... or NULL */
+  int n_extra;                  /* channels of an extra attribute (semantics / normals / coords), 0 = none */
+  const float* extra_a;         /* [N,n_a,n_extra] */
+  const float* extra_b;         /* [N,n_b,n_extra] */
+  int white_background;
+  float* rgb_map;    /* [N,3] out */
+  float* depth_map;  /* [N] out */
+  float* mask;       /* [N] out */
+  float* extra_map;  /* [N,n_extra] out or NULL */
+  float* weights;    /* [N,n_a+n_b] out or NULL (in merged order) */
+  float* depth_sorted; /* [N,n_a+n_b] out or NULL */
+  int64_t* perm;     /* [N,n_a+n_b] out or NULL: merged position -> index into cat(a,b) */
+} nfi_composite_args;
+int nfi_composite_fwd(const nfi_composite_args* a, nfi_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Fused forward render: run.py::render (176-350) from cameras + texels to pixels in one
+ * persistent launch (plus the ray set-up launch), no per-sample HBM round trips.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct nfi_render_args {
+  int n_scenes, height, width;
+  int n_samples;                 /* S per pass, <= 64 */
+  int fine_sampling;             /* args.fine_sampling (run.py:259) */
+  int white_background;          /* dataset_config['white_background'] (run.py:348) */
+  float scene_range;             /* dataset_config['scene_range'] (run.py:200) */
+  /* camera (as nfi_raygen_args) */
+  const float* cam2world; const float* focal; const float* bbox; const float* center;
+  /* field (as nfi_field_args) */
+  const void* texels; int plane_res; int texel_dtype;
+  const float* decoder_image; int n_attention; const float* attention_values;
+  int use_sdf; const float* beta; const float* alpha;
+  /* the reference's two random draws (nerf_utils.py:115, 202); NULL = deterministic */
+  const float* noise_coarse;     /* [N,S] or NULL */
+  const float* noise_fine;       /* u: [N,S] with row stride below, never NULL when fine_sampling */
+  int64_t noise_fine_row_stride;
+  /* outputs */
+  float* rgb;        /* [N,3] */
+  float* depth;      /* [N] */
+  float* mask;       /* [N] */
+  float* semantics;  /* [N,A] or NULL */
+  /* optional stage taps (any may be NULL) */
+  float* ray_origins; float* ray_directions; float* near_plane; float* far_plane; uint8_t* hit;
+  float* t_coarse; float* sigma_coarse; float* rgb_coarse;   /* [N,S], [N,S], [N,S,3] */
+  float* t_fine; float* sigma_fine; float* rgb_fine;
+  float* t_sorted; float* weights; int32_t* perm;            /* [N,2S] */
+  /* workspace: nfi_render_workspace_bytes(n_scenes*height*width) bytes */
+  void* workspace; size_t workspace_bytes;
+  /* 1: rays whose line misses the scene cube inflated by 1e-4 skip both passes (exact:
+   * every sample of such a ray is outside the cube, sigma==0).  0: evaluate every ray. */
+  int skip_missed_rays;
+} nfi_render_args;
+size_t nfi_render_workspace_bytes(int64_t n_rays);
+int nfi_render_fwd(const nfi_render_args* a, nfi_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NFI_HIP_H */

@@ -1,0 +1,526 @@
+// nfi_device.hpp — device-side building blocks shared by every kernel of libnfi_hip.so.
+//
+// Target: gfx950 (MI355X, CDNA4) only.  One wavefront (64 lanes) owns one ray; a ray's samples
+// live one (or two) per lane, so scans, neighbour differences, the inverse-CDF search and the
+// 2S-key merge are intra-wavefront operations (DPP/ds_bpermute shuffles + a per-wave LDS slab),
+// never HBM round trips.  The triplane gather + decoder MLP runs on 16-point tiles shaped for
+// v_mfma_f32_16x16x4_f32 (exact fp32, so the 1e-4 parity budget is spent on nothing).
+//
+// The translation unit is compiled with -ffp-contract=off: the reference evaluates every
+// elementwise step as a separate ATen kernel (un-fused mul/add, true division), and sample
+// indices/masks are discontinuous in those values.  FMAs appear only where written (fmaf),
+// i.e. where ATen itself fuses (torch.lerp, the L2 norm) or where only a tolerance applies.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace nfi {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kWave = 64;
+constexpr int kC = 32;        // plane channels
+constexpr int kHidden = 64;   // decoder hidden width
+constexpr float kLog2e = 1.4426950408889634f;
+constexpr float kLn2 = 0.6931471805599453f;
+constexpr float kSoftplusThr2 = 28.853900817779268f;  // 20 * log2(e): softplus threshold in the log2 domain
+
+// ---- decoder operand image (floats), built by nfi_decoder_pack -------------------------------
+// W1F [8 k-steps][64 lanes][4 n-tiles]   A operand of layer 1 (rows = hidden units)
+// W2F [4 n-tiles][64 lanes][4 regs]      A operand of layer 2 (rows = outputs), k-step = (nt, r)
+// B1F [4 groups][4 n-tiles][4 regs]      layer-1 bias in accumulator layout, * log2(e)
+// B2F [4 groups][4 regs]                 layer-2 bias in accumulator layout
+constexpr int kW1F = 0;
+constexpr int kW2F = kW1F + 8 * 64 * 4;
+constexpr int kB1F = kW2F + 4 * 64 * 4;
+constexpr int kB2F = kB1F + 64;
+constexpr int kImageFloats = kB2F + 16;                 // 3152
+constexpr int kVF = kImageFloats;                       // per-scene attention values [4 groups][4 regs][4] appended in LDS
+constexpr int kFieldLdsFloats = kVF + 64;               // 3216
+
+// ---- small wave helpers ---------------------------------------------------------------------
+__device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
+__device__ __forceinline__ void wave_lds_fence() {
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
+__device__ __forceinline__ float bits2f(uint32_t u) { return __builtin_bit_cast(float, u); }
+__device__ __forceinline__ uint32_t f2bits(float f) { return __builtin_bit_cast(uint32_t, f); }
+// order-preserving float -> uint key (total order; -0 < +0; NaNs at the ends)
+__device__ __forceinline__ uint32_t ordered_key(float f) {
+  uint32_t b = f2bits(f);
+  return b ^ ((b >> 31) ? 0xFFFFFFFFu : 0x80000000u);
+}
+__device__ __forceinline__ float ordered_key_inv(uint32_t k) {
+  uint32_t b = (k >> 31) ? (k ^ 0x80000000u) : ~k;
+  return bits2f(b);
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) v = fmaxf(v, __shfl_xor(v, d, 64));
+  return v;
+}
+__device__ __forceinline__ float wave_min(float v) {
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) v = fminf(v, __shfl_xor(v, d, 64));
+  return v;
+}
+__device__ __forceinline__ double wave_incl_scan_add(double v, int lane) {
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    double o = __shfl_up(v, d, 64);
+    if (lane >= d) v += o;
+  }
+  return v;
+}
+__device__ __forceinline__ double wave_incl_scan_mul(double v, int lane) {
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    double o = __shfl_up(v, d, 64);
+    if (lane >= d) v *= o;
+  }
+  return v;
+}
+
+// Element layout for per-ray arrays of up to SPL*64 entries: element e lives in slot e/64 of
+// lane e%64.
+template <int SPL>
+__device__ __forceinline__ void next_elem(const float (&x)[SPL], float (&y)[SPL], int lane) {
+#pragma unroll
+  for (int j = 0; j < SPL; ++j) {
+    float v = __shfl_down(x[j], 1, 64);
+    if (j + 1 < SPL) {
+      float w = __shfl(x[j + 1 < SPL ? j + 1 : j], 0, 64);
+      if (lane == 63) v = w;
+    }
+    y[j] = v;
+  }
+}
+template <int SPL>
+__device__ __forceinline__ void prev_elem(const float (&x)[SPL], float (&y)[SPL], int lane, float first) {
+#pragma unroll
+  for (int j = 0; j < SPL; ++j) {
+    float v = __shfl_up(x[j], 1, 64);
+    if (j > 0) {
+      float w = __shfl(x[j > 0 ? j - 1 : 0], 63, 64);
+      if (lane == 0) v = w;
+    } else if (lane == 0) {
+      v = first;
+    }
+    y[j] = v;
+  }
+}
+
+// Exclusive running product over the SPL*64 elements.  ATen's CPU cumprod accumulates a float
+// row in double (acc_type<float,false>), so a double scan reproduces it to the last bit except
+// on exact rounding ties; elements past the ray's length must hold 1.
+template <int SPL>
+__device__ __forceinline__ void excl_cumprod(const float (&x)[SPL], float (&out)[SPL], int lane) {
+  double carry = 1.0;
+#pragma unroll
+  for (int j = 0; j < SPL; ++j) {
+    double inc = wave_incl_scan_mul((double)x[j], lane);
+    double exc = __shfl_up(inc, 1, 64);
+    if (lane == 0) exc = 1.0;
+    // the reference rounds every inclusive product to float before the next multiply would
+    // see it only through the double accumulator, i.e. it does not: keep double throughout.
+    out[j] = (float)(carry * exc);
+    carry = carry * __shfl(inc, 63, 64);
+  }
+}
+template <int SPL>
+__device__ __forceinline__ void incl_cumsum(const float (&x)[SPL], float (&out)[SPL], int lane) {
+  double carry = 0.0;
+#pragma unroll
+  for (int j = 0; j < SPL; ++j) {
+    double inc = wave_incl_scan_add((double)x[j], lane);
+    out[j] = (float)(carry + inc);
+    carry = carry + __shfl(inc, 63, 64);
+  }
+}
+
+// ||d||_2 as ATen's CPU norm kernel evaluates it for a 3-vector: an fma chain, then sqrt.
+__device__ __forceinline__ float norm3(float x, float y, float z) {
+  return __fsqrt_rn(fmaf(z, z, fmaf(y, y, x * x)));
+}
+
+// torch.lerp(a, b, w) bit for bit (ATen: w < 0.5 ? a + w*(b-a) : b - (b-a)*(1-w), both fused)
+__device__ __forceinline__ float aten_lerp(float a, float b, float w) {
+  float d = b - a;
+  return (w < 0.5f) ? fmaf(w, d, a) : fmaf(-d, 1.0f - w, b);
+}
+
+// ---- camera rays (lib/nerf_utils.py:28-91, run.py:196) ----------------------------------------
+struct CameraParams {
+  const float* cam2world;  // [B,4,4]
+  const float* focal;      // [B] or null (ortho)
+  const float* bbox;       // [B,2,2] or null
+  const float* center;     // [B,2] or null
+  int height, width;
+  int normalize;
+};
+
+__device__ __forceinline__ void make_ray(const CameraParams& c, int b, int row, int col, float (&o)[3],
+                                         float (&d)[3]) {
+  const float* M = c.cam2world + (size_t)b * 16;
+  float u = (float)col / (float)c.width;
+  float v = (float)row / (float)c.height;
+  float cd[3], co[3];
+  if (c.focal) {
+    if (c.center) {
+      u = (u - 0.5f * (2.0f * c.center[b * 2 + 0] - 1.0f)) - 0.5f;
+      v = (v - 0.5f * (2.0f * c.center[b * 2 + 1] - 1.0f)) - 0.5f;
+    } else {
+      u = u - 0.5f;
+      v = v - 0.5f;
+    }
+    if (c.bbox) {
+      const float* bb = c.bbox + b * 4;  // [[x0,y0],[w,h]]
+      u = (bb[2] * (u + 0.5f) + bb[0]) * 0.5f;
+      v = -(bb[3] * (-v + 0.5f) + bb[1]) * 0.5f;
+    }
+    float f = c.focal[b];
+    u = u / f;
+    v = v / f;
+    cd[0] = u; cd[1] = -v; cd[2] = -1.0f;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      d[k] = (cd[0] * M[k * 4 + 0] + cd[1] * M[k * 4 + 1]) + cd[2] * M[k * 4 + 2];
+      o[k] = M[k * 4 + 3];
+    }
+  } else {
+    u = (u - 0.5f) * 2.0f;
+    v = (v - 0.5f) * 2.0f;
+    if (c.bbox) {
+      const float* bb = c.bbox + b * 4;
+      u = bb[2] * (u / 2.0f + 0.5f) + bb[0];
+      v = -(bb[3] * (-v / 2.0f + 0.5f) + bb[1]);
+    }
+    co[0] = u; co[1] = -v; co[2] = 0.0f;
+    cd[0] = 0.0f; cd[1] = 0.0f; cd[2] = -1.0f;
+    float w = M[15];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      o[k] = ((co[0] * M[k * 4 + 0] + co[1] * M[k * 4 + 1]) + co[2] * M[k * 4 + 2]) + M[k * 4 + 3];
+      d[k] = ((cd[0] * M[k * 4 + 0] + cd[1] * M[k * 4 + 1]) + cd[2] * M[k * 4 + 2]) / w;
+    }
+  }
+  if (c.normalize) {
+    float n = fmaxf(norm3(d[0], d[1], d[2]), 1e-12f);
+    d[0] = d[0] / n; d[1] = d[1] / n; d[2] = d[2] / n;
+  }
+}
+
+// ---- scene-cube slab test (lib/nerf_utils.py:237-256) -----------------------------------------
+__device__ __forceinline__ bool slab_test(const float (&o)[3], const float (&d)[3], float r, float& near,
+                                          float& far) {
+  float lo[3], hi[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    float inv = 1.0f / d[k];
+    bool neg = inv < 0.0f;
+    lo[k] = ((neg ? r : -r) - o[k]) * inv;
+    hi[k] = ((neg ? -r : r) - o[k]) * inv;
+  }
+  bool hit = !((lo[0] > hi[1]) || (lo[1] > hi[0]));
+  // torch.max / torch.min propagate NaN; fmaxf would not, so spell the selects out
+  near = (lo[0] > lo[1] || lo[0] != lo[0]) ? lo[0] : lo[1];
+  far = (hi[0] < hi[1] || hi[0] != hi[0]) ? hi[0] : hi[1];
+  hit = hit && !((near > hi[2]) || (lo[2] > far));
+  near = (near > lo[2] || near != near) ? near : lo[2];
+  far = (far < hi[2] || far != far) ? far : hi[2];
+  return hit;
+}
+
+// miss-fill + clamps (lib/nerf_utils.py:258-268)
+__device__ __forceinline__ void finish_planes(bool hit, float fill_near, float fill_far, float& near, float& far) {
+  near = hit ? near : fill_near;
+  far = hit ? far : fill_far;
+  near = (near < 0.1f) ? 0.1f : near;  // clamp_(min): NaN stays NaN
+  far = (far < 0.1f) ? 0.1f : far;
+  if ((far - near) < 1e-3f) far = near + 1e-3f;
+}
+
+// ---- triplane field on 16-point tiles ---------------------------------------------------------
+struct FieldParams {
+  __amdgpu_buffer_rsrc_t rsrc;   // texels of ONE scene: [3][R][R][32]
+  uint32_t plane_bytes;          // R*R*texel_bytes
+  uint32_t row_bytes;            // R*texel_bytes
+  int res;                       // R
+  float res_m1;                  // R-1
+  int n_attention;               // A (0: direct rgb)
+  int use_sdf;
+  float inv_alpha;               // 1/alpha
+  float beta;
+  const float* lds;              // LDS: decoder image + VF
+};
+
+// per-point gather set-up in sample layout: unnormalised, border-clamped plane coordinates.
+// grid_sample(align_corners=True): u = ((p+1)/2)*(R-1); border: clamp to [0,R-1].  The left
+// texel index is clamped to R-2 so that its right/lower neighbour always exists; at u == R-1 the
+// fraction becomes 1 and the value is the same texel the reference reads with weight 1.
+__device__ __forceinline__ void plane_coord(float p, float res_m1, int res, int& i0, float& fr) {
+  float u = ((p + 1.0f) / 2.0f) * res_m1;
+  u = fminf(fmaxf(u, 0.0f), res_m1);
+  float fl = floorf(u);
+  fl = fminf(fl, (float)(res - 2));
+  i0 = (int)fl;
+  fr = u - fl;
+}
+
+template <int TEX>
+__device__ __forceinline__ void load_texel8(const FieldParams& P, uint32_t voff, uint32_t soff, int imm, float (&t)[8]);
+
+template <>
+__device__ __forceinline__ void load_texel8<0>(const FieldParams& P, uint32_t voff, uint32_t soff, int imm,
+                                               float (&t)[8]) {
+  // fp32 texel = 128 B; this lane (group g) owns channels [4g,4g+4) and [16+4g,16+4g+4)
+  u32x4 a = __builtin_amdgcn_raw_buffer_load_b128(P.rsrc, voff + imm, soff, 0);
+  u32x4 b = __builtin_amdgcn_raw_buffer_load_b128(P.rsrc, voff + imm + 64, soff, 0);
+  t[0] = bits2f(a.x); t[1] = bits2f(a.y); t[2] = bits2f(a.z); t[3] = bits2f(a.w);
+  t[4] = bits2f(b.x); t[5] = bits2f(b.y); t[6] = bits2f(b.z); t[7] = bits2f(b.w);
+}
+template <>
+__device__ __forceinline__ void load_texel8<1>(const FieldParams& P, uint32_t voff, uint32_t soff, int imm,
+                                               float (&t)[8]) {
+  // bf16 texel = 64 B; this lane owns channels [8g,8g+8)
+  u32x4 a = __builtin_amdgcn_raw_buffer_load_b128(P.rsrc, voff + imm, soff, 0);
+  t[0] = bits2f(a.x << 16); t[1] = bits2f(a.x & 0xFFFF0000u);
+  t[2] = bits2f(a.y << 16); t[3] = bits2f(a.y & 0xFFFF0000u);
+  t[4] = bits2f(a.z << 16); t[5] = bits2f(a.z & 0xFFFF0000u);
+  t[6] = bits2f(a.w << 16); t[7] = bits2f(a.w & 0xFFFF0000u);
+}
+
+struct TileOut {
+  float sdf, sigma, r, g, b;
+};
+
+// One tile = 16 points.  Lane l works for point j = l&15 as channel group g = l>>4.
+//   xi: packed integer texel coordinates of point j (x | y<<10 | z<<20), fx,fy,fz fractions,
+//   outside: 1.0f if the point is outside the scene cube.
+// Returns (in every lane of the four groups) the decoder outputs for point j.
+// sem: if non-null, softmax probabilities are written to sem[point j][A] (global).
+template <int TEX, bool ATT>
+__device__ __forceinline__ TileOut field_tile(const FieldParams& P, int lane, uint32_t xi, float fx, float fy,
+                                              float fz, float outside, float* sem) {
+  const int g = lane >> 4;
+  constexpr int TB = (TEX == 0) ? 128 : 64;                 // texel bytes
+  constexpr int GB = (TEX == 0) ? 16 : 16;                  // byte offset per group inside a texel
+  const int x0 = xi & 1023, y0 = (xi >> 10) & 1023, z0 = (xi >> 20) & 1023;
+
+  float feat[8];
+#pragma unroll
+  for (int s = 0; s < 8; ++s) feat[s] = 0.0f;
+
+#pragma unroll
+  for (int pl = 0; pl < 3; ++pl) {
+    const int a0 = (pl == 2) ? y0 : x0;      // W index: x, x, y
+    const int b0 = (pl == 0) ? y0 : z0;      // H index: y, z, z
+    const float fa = (pl == 2) ? fy : fx;
+    const float fb = (pl == 0) ? fy : fz;
+    const uint32_t voff = (uint32_t)pl * P.plane_bytes + ((uint32_t)b0 * (uint32_t)P.res + (uint32_t)a0) * TB +
+                          (uint32_t)g * GB;
+    float t00[8], t10[8], t01[8], t11[8];
+    load_texel8<TEX>(P, voff, 0, 0, t00);
+    load_texel8<TEX>(P, voff, 0, TB, t10);
+    load_texel8<TEX>(P, voff, P.row_bytes, 0, t01);
+    load_texel8<TEX>(P, voff, P.row_bytes, TB, t11);
+    const float ga = 1.0f - fa, gb = 1.0f - fb;
+    const float w00 = ga * gb, w10 = fa * gb, w01 = ga * fb, w11 = fa * fb;
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+      float acc = feat[s];
+      acc = fmaf(w00, t00[s], acc);
+      acc = fmaf(w10, t10[s], acc);
+      acc = fmaf(w01, t01[s], acc);
+      acc = fmaf(w11, t11[s], acc);
+      feat[s] = acc;
+    }
+  }
+
+  // ---- layer 1: H^T[64 x 16] = W1'[64 x 32] * F^T[32 x 16], bias pre-loaded, log2 domain ----
+  const f32x4* ldsv = reinterpret_cast<const f32x4*>(P.lds);
+  f32x4 acc1[4];
+#pragma unroll
+  for (int nt = 0; nt < 4; ++nt) acc1[nt] = ldsv[(kB1F >> 2) + g * 4 + nt];
+#pragma unroll
+  for (int s = 0; s < 8; ++s) {
+    f32x4 w = ldsv[(kW1F >> 2) + s * 64 + lane];
+    acc1[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(w.x, feat[s], acc1[0], 0, 0, 0);
+    acc1[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(w.y, feat[s], acc1[1], 0, 0, 0);
+    acc1[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(w.z, feat[s], acc1[2], 0, 0, 0);
+    acc1[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(w.w, feat[s], acc1[3], 0, 0, 0);
+  }
+  // softplus in base 2: sp2 = log2(1 + 2^h2)  (= softplus(h)/ln2; ln2 is folded into W2')
+#pragma unroll
+  for (int nt = 0; nt < 4; ++nt) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float h = acc1[nt][r];
+      float e = __builtin_amdgcn_exp2f(h);
+      float s = __builtin_amdgcn_logf(1.0f + e);
+      acc1[nt][r] = (h > kSoftplusThr2) ? h : s;
+    }
+  }
+  // ---- layer 2: O^T[16 x 16] = W2'[16 x 64] * SP^T[64 x 16]; two accumulators hide latency ----
+  f32x4 o0 = ldsv[(kB2F >> 2) + g];
+  f32x4 o1 = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+  for (int nt = 0; nt < 4; ++nt) {
+    f32x4 w = ldsv[(kW2F >> 2) + nt * 64 + lane];
+    o0 = __builtin_amdgcn_mfma_f32_16x16x4f32(w.x, acc1[nt][0], o0, 0, 0, 0);
+    o1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w.y, acc1[nt][1], o1, 0, 0, 0);
+    o0 = __builtin_amdgcn_mfma_f32_16x16x4f32(w.z, acc1[nt][2], o0, 0, 0, 0);
+    o1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w.w, acc1[nt][3], o1, 0, 0, 0);
+  }
+  f32x4 o = o0 + o1;  // lane (j,g): outputs 4g..4g+3 of point j; output 0 = sdf/density, 1.. = features*log2e
+
+  TileOut res;
+  const int j = lane & 15;
+  float sdf = __shfl(o.x, j, 64);  // broadcast group 0's row 0 to all groups
+  res.sdf = sdf;
+  if (P.use_sdf) {
+    float x = -sdf;
+    float sgn = (x > 0.0f) ? 1.0f : ((x < 0.0f) ? -1.0f : 0.0f);
+    float cdf = 0.5f + (0.5f * sgn) * (1.0f - __expf(-fabsf(x) / P.beta));
+    res.sigma = P.inv_alpha * (cdf * (1.0f - outside));
+  } else {
+    float d = sdf - 1.0f;
+    float sp = (d > 20.0f) ? d : log1pf(__expf(d));
+    res.sigma = sp * (1.0f - outside);
+  }
+  if constexpr (ATT) {
+    // softmax over features 1..A spread over (group, reg); rows are pre-scaled by log2e
+    const int A = P.n_attention;
+    float m = -INFINITY;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      int row = 4 * g + r;
+      bool valid = (row >= 1) && (row <= A);
+      m = valid ? fmaxf(m, o[r]) : m;
+    }
+    m = fmaxf(m, __shfl_xor(m, 16, 64));
+    m = fmaxf(m, __shfl_xor(m, 32, 64));
+    const f32x4* vf = ldsv + (kVF >> 2) + g * 4;
+    float se = 0.0f, sr = 0.0f, sg = 0.0f, sb = 0.0f;
+    float e4[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      int row = 4 * g + r;
+      bool valid = (row >= 1) && (row <= A);
+      float e = valid ? __builtin_amdgcn_exp2f(o[r] - m) : 0.0f;
+      e4[r] = e;
+      f32x4 v = vf[r];
+      se += e;
+      sr = fmaf(e, v.x, sr);
+      sg = fmaf(e, v.y, sg);
+      sb = fmaf(e, v.z, sb);
+    }
+    se += __shfl_xor(se, 16, 64); sr += __shfl_xor(sr, 16, 64); sg += __shfl_xor(sg, 16, 64); sb += __shfl_xor(sb, 16, 64);
+    se += __shfl_xor(se, 32, 64); sr += __shfl_xor(sr, 32, 64); sg += __shfl_xor(sg, 32, 64); sb += __shfl_xor(sb, 32, 64);
+    float inv = 1.0f / se;
+    res.r = sr * inv; res.g = sg * inv; res.b = sb * inv;
+    if (sem) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        int row = 4 * g + r;
+        if (row >= 1 && row <= A) sem[row - 1] = e4[r] * inv;
+      }
+    }
+  } else {
+    // rgb = sigmoid(f)*2.004 - 1.002, features (rows 1..3 of group 0) pre-scaled by log2e
+    float r1 = __shfl(o.y, j, 64), r2 = __shfl(o.z, j, 64), r3 = __shfl(o.w, j, 64);
+    res.r = (1.0f / (1.0f + __builtin_amdgcn_exp2f(-r1))) * 2.004f - 1.002f;
+    res.g = (1.0f / (1.0f + __builtin_amdgcn_exp2f(-r2))) * 2.004f - 1.002f;
+    res.b = (1.0f / (1.0f + __builtin_amdgcn_exp2f(-r3))) * 2.004f - 1.002f;
+  }
+  return res;
+}
+
+struct SampleOut {
+  float sdf, sigma, r, g, b;
+};
+
+// Field query for the (up to) 64 points a wave holds one per lane.  px,py,pz: WORLD coordinates;
+// valid: lane holds a point.  Tiles whose 16 points are all outside the cube (or invalid) are
+// skipped: sigma is exactly 0 there (the reference multiplies by (1-mask), generator.py:633),
+// rgb is reported as 0 (its weight is exactly 0).
+// sem_base: null or global pointer to this wave's [64][A] semantics rows.
+template <int TEX, bool ATT>
+__device__ __forceinline__ SampleOut field_wave(const FieldParams& P, float scene_range, int lane, float px, float py,
+                                                float pz, bool valid, float* sem_base, bool* outside_flag) {
+  // sem_base rows are written only for valid points (rows past the end of the array do not exist)
+  // reference: x / scene_range, mask = any(|x| > 1)   (true division, generator.py:604-607)
+  float qx = px / scene_range, qy = py / scene_range, qz = pz / scene_range;
+  bool out = (fabsf(qx) > 1.0f) || (fabsf(qy) > 1.0f) || (fabsf(qz) > 1.0f);
+  if (outside_flag) *outside_flag = out;
+  int x0, y0, z0;
+  float fx, fy, fz;
+  plane_coord(qx, P.res_m1, P.res, x0, fx);
+  plane_coord(qy, P.res_m1, P.res, y0, fy);
+  plane_coord(qz, P.res_m1, P.res, z0, fz);
+  if (!valid) { x0 = y0 = z0 = 0; fx = fy = fz = 0.0f; }  // keep NaN/garbage out of the address math
+  uint32_t xi = (uint32_t)x0 | ((uint32_t)y0 << 10) | ((uint32_t)z0 << 20);
+  float outf = out ? 1.0f : 0.0f;
+  uint64_t live = __ballot(valid && !out);
+
+  SampleOut so;
+  so.sdf = 0.0f; so.sigma = 0.0f; so.r = 0.0f; so.g = 0.0f; so.b = 0.0f;
+  const int j = lane & 15, g = lane >> 4;
+#pragma unroll 1
+  for (int t = 0; t < 4; ++t) {
+    if (((live >> (16 * t)) & 0xFFFFull) == 0) continue;  // wave-uniform
+    int src = 16 * t + j;
+    uint32_t txi = (uint32_t)__shfl((int)xi, src, 64);
+    float tfx = __shfl(fx, src, 64), tfy = __shfl(fy, src, 64), tfz = __shfl(fz, src, 64);
+    float tout = __shfl(outf, src, 64);
+    int tvalid = __shfl(valid ? 1 : 0, src, 64);
+    float* sem = (sem_base && tvalid) ? sem_base + (size_t)src * P.n_attention : nullptr;
+    TileOut to = field_tile<TEX, ATT>(P, lane, txi, tfx, tfy, tfz, tout, sem);
+    if (g == t) { so.sdf = to.sdf; so.sigma = to.sigma; so.r = to.r; so.g = to.g; so.b = to.b; }
+  }
+  return so;
+}
+
+// ---- per-ray weights (lib/nerf_utils.py:164-180) ------------------------------------------------
+// sigma/t hold n elements (invalid slots: sigma = 0).  dnorm = ||ray direction||.
+template <int SPL>
+__device__ __forceinline__ void ray_weights(const float (&sigma)[SPL], const float (&t)[SPL], int n, float dnorm,
+                                            int lane, float (&w)[SPL]) {
+  float tn[SPL], om[SPL], alpha[SPL];
+  next_elem<SPL>(t, tn, lane);
+#pragma unroll
+  for (int j = 0; j < SPL; ++j) {
+    int e = j * 64 + lane;
+    float delta = (e < n - 1) ? (tn[j] - t[j]) : 0.0f;
+    delta = delta * dnorm;
+    float a = 1.0f - expf(-sigma[j] * delta);
+    if (e >= n) a = 0.0f;
+    alpha[j] = a;
+    om[j] = (1.0f - a) + 1e-10f;
+  }
+  float T[SPL];
+  excl_cumprod<SPL>(om, T, lane);
+#pragma unroll
+  for (int j = 0; j < SPL; ++j) w[j] = alpha[j] * T[j];
+}
+
+// count of cdf entries <= u (searchsorted right=True) over the M sorted floats at cdf[] (LDS)
+__device__ __forceinline__ int upper_bound_lds(const float* cdf, int M, float u) {
+  int pos = 0;
+#pragma unroll
+  for (int step = 128; step >= 1; step >>= 1) {
+    int idx = pos + step;
+    if (idx <= M && cdf[idx - 1] <= u) pos = idx;
+  }
+  return pos;
+}
+
+}  // namespace nfi

@@ -1,0 +1,995 @@
+// nfi_kernels.hip — kernels and C ABI of libnfi_hip.so (gfx950 / MI355X only).
+// See include/nfi_hip.h for the contract and nfi_device.hpp for the building blocks.
+#include "nfi_device.hpp"
+#include "../../include/nfi_hip.h"
+
+#include <cstdio>
+#include <cstring>
+
+using namespace nfi;
+
+// ------------------------------------------------------------------------------------------------
+// error plumbing
+// ------------------------------------------------------------------------------------------------
+static thread_local char g_err[256] = "";
+static int fail(int code, const char* msg) {
+  snprintf(g_err, sizeof(g_err), "%s", msg);
+  return code;
+}
+static int check_launch(const char* what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    snprintf(g_err, sizeof(g_err), "%s: %s", what, hipGetErrorString(e));
+    return NFI_ERR_LAUNCH;
+  }
+  return NFI_OK;
+}
+extern "C" const char* nfi_last_error(void) { return g_err; }
+extern "C" int nfi_version(void) { return 100; }
+
+#define REQUIRE(cond, msg) \
+  do {                     \
+    if (!(cond)) return fail(NFI_ERR_INVALID_ARGUMENT, msg); \
+  } while (0)
+
+static inline int texel_bytes(int dtype) { return dtype == NFI_TEXEL_F32 ? 128 : 64; }
+
+// ------------------------------------------------------------------------------------------------
+// planes [B,3,32,R,R] <-> texels [B,3,R,R,32]
+// ------------------------------------------------------------------------------------------------
+template <int TEX>
+__global__ __launch_bounds__(256) void planes_to_texels_kernel(const float* __restrict__ planes, void* __restrict__ texels,
+                                                               int hw) {
+  __shared__ float tile[kC][65];
+  const int img = blockIdx.y;                 // b*3 + plane
+  const int px0 = blockIdx.x * 64;
+  const float* src = planes + (size_t)img * kC * hw;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+#pragma unroll
+  for (int c = ty; c < kC; c += 4) {
+    int px = px0 + tx;
+    tile[c][tx] = (px < hw) ? src[(size_t)c * hw + px] : 0.0f;
+  }
+  __syncthreads();
+  const int p = threadIdx.x >> 2, q = threadIdx.x & 3;  // pixel, channel octet
+  if (px0 + p < hw) {
+    float v[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] = tile[q * 8 + k][p];
+    if (TEX == 0) {
+      float4* dst = reinterpret_cast<float4*>(reinterpret_cast<float*>(texels) + ((size_t)img * hw + px0 + p) * kC + q * 8);
+      dst[0] = make_float4(v[0], v[1], v[2], v[3]);
+      dst[1] = make_float4(v[4], v[5], v[6], v[7]);
+    } else {
+      uint32_t w[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        // round-to-nearest-even fp32 -> bf16
+        uint32_t a = f2bits(v[2 * k]), b = f2bits(v[2 * k + 1]);
+        a = (a + 0x7FFFu + ((a >> 16) & 1u)) >> 16;
+        b = (b + 0x7FFFu + ((b >> 16) & 1u)) >> 16;
+        w[k] = a | (b << 16);
+      }
+      uint4* dst = reinterpret_cast<uint4*>(reinterpret_cast<uint16_t*>(texels) + ((size_t)img * hw + px0 + p) * kC + q * 8);
+      dst[0] = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void texels_to_planes_kernel(const float* __restrict__ texels, float* __restrict__ planes,
+                                                               int hw) {
+  __shared__ float tile[kC][65];
+  const int img = blockIdx.y;
+  const int px0 = blockIdx.x * 64;
+  const int p = threadIdx.x >> 2, q = threadIdx.x & 3;
+  if (px0 + p < hw) {
+    const float4* src = reinterpret_cast<const float4*>(texels + ((size_t)img * hw + px0 + p) * kC + q * 8);
+    float4 a = src[0], b = src[1];
+    tile[q * 8 + 0][p] = a.x; tile[q * 8 + 1][p] = a.y; tile[q * 8 + 2][p] = a.z; tile[q * 8 + 3][p] = a.w;
+    tile[q * 8 + 4][p] = b.x; tile[q * 8 + 5][p] = b.y; tile[q * 8 + 6][p] = b.z; tile[q * 8 + 7][p] = b.w;
+  }
+  __syncthreads();
+  float* dst = planes + (size_t)img * kC * hw;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+#pragma unroll
+  for (int c = ty; c < kC; c += 4) {
+    int px = px0 + tx;
+    if (px < hw) dst[(size_t)c * hw + px] = tile[c][tx];
+  }
+}
+
+extern "C" int nfi_planes_to_texels(const float* planes, void* texels, int n_scenes, int plane_res, int texel_dtype,
+                                    nfi_stream_t stream) {
+  REQUIRE(planes && texels, "planes_to_texels: null pointer");
+  REQUIRE(n_scenes > 0 && plane_res >= 2 && plane_res <= 1024, "planes_to_texels: plane_res must be in [2,1024]");
+  REQUIRE(texel_dtype == NFI_TEXEL_F32 || texel_dtype == NFI_TEXEL_BF16, "planes_to_texels: bad texel dtype");
+  int hw = plane_res * plane_res;
+  dim3 grid((hw + 63) / 64, n_scenes * 3);
+  if (texel_dtype == NFI_TEXEL_F32)
+    hipLaunchKernelGGL(planes_to_texels_kernel<0>, grid, dim3(256), 0, (hipStream_t)stream, planes, texels, hw);
+  else
+    hipLaunchKernelGGL(planes_to_texels_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, planes, texels, hw);
+  return check_launch("planes_to_texels");
+}
+
+extern "C" int nfi_texels_to_planes(const float* texels, float* planes, int n_scenes, int plane_res, nfi_stream_t stream) {
+  REQUIRE(planes && texels, "texels_to_planes: null pointer");
+  REQUIRE(n_scenes > 0 && plane_res >= 2 && plane_res <= 1024, "texels_to_planes: plane_res must be in [2,1024]");
+  int hw = plane_res * plane_res;
+  dim3 grid((hw + 63) / 64, n_scenes * 3);
+  hipLaunchKernelGGL(texels_to_planes_kernel, grid, dim3(256), 0, (hipStream_t)stream, texels, planes, hw);
+  return check_launch("texels_to_planes");
+}
+
+// ------------------------------------------------------------------------------------------------
+// decoder operand image
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int feat_channel(int tex, int s, int g) {
+  // which plane channel sits in feature register s of channel group g (see load_texel8)
+  return tex == 0 ? ((s < 4) ? 4 * g + s : 16 + 4 * g + (s - 4)) : 8 * g + s;
+}
+
+__global__ __launch_bounds__(256) void decoder_pack_kernel(const float* __restrict__ w1, const float* __restrict__ b1,
+                                                           const float* __restrict__ w2, const float* __restrict__ b2,
+                                                           int n_out, int tex, float* __restrict__ image) {
+  const float gain1 = 0.17677669529663687f;  // 1/sqrt(32)  (models/stylegan.py:171)
+  const float gain2 = 0.125f;                // 1/sqrt(64)
+  for (int i = threadIdx.x; i < kImageFloats; i += blockDim.x) {
+    float v = 0.0f;
+    if (i < kW2F) {
+      int k = i - kW1F;
+      int nt = k & 3, lane = (k >> 2) & 63, s = k >> 8;
+      int row = 16 * nt + (lane & 15);
+      int ch = feat_channel(tex, s, lane >> 4);
+      // gain, the /3 of the three-plane mean (generator.py:328) and log2(e) for the base-2 softplus
+      v = (w1[row * kC + ch] * gain1) * (kLog2e / 3.0f);
+    } else if (i < kB1F) {
+      int k = i - kW2F;
+      int r = k & 3, lane = (k >> 2) & 63, nt = k >> 8;
+      int row = lane & 15;
+      int hid = 16 * nt + 4 * (lane >> 4) + r;
+      if (row < n_out) {
+        float w = w2[row * kHidden + hid] * gain2;
+        // softplus was computed in base 2 (missing factor ln2).  Row 0 (distance / density) stays in
+        // natural units; feature rows are wanted times log2(e) for the base-2 softmax/sigmoid, and
+        // ln2*log2e == 1.
+        v = (row == 0) ? w * kLn2 : w;
+      }
+    } else if (i < kB2F) {
+      int k = i - kB1F;
+      int r = k & 3, nt = (k >> 2) & 3, g = k >> 4;
+      v = b1[16 * nt + 4 * g + r] * kLog2e;
+    } else {
+      int k = i - kB2F;
+      int row = k;  // 4g + r
+      if (row < n_out) v = (row == 0) ? b2[0] : b2[row] * kLog2e;
+    }
+    image[i] = v;
+  }
+}
+
+extern "C" size_t nfi_decoder_image_floats(void) { return (size_t)kImageFloats; }
+
+extern "C" int nfi_decoder_pack(const float* w1, const float* b1, const float* w2, const float* b2, int n_attention,
+                                int texel_dtype, float* image, nfi_stream_t stream) {
+  REQUIRE(w1 && b1 && w2 && b2 && image, "decoder_pack: null pointer");
+  REQUIRE(n_attention >= 0 && n_attention <= NFI_MAX_ATTENTION, "decoder_pack: attention_values must be in [0,14]");
+  REQUIRE(texel_dtype == NFI_TEXEL_F32 || texel_dtype == NFI_TEXEL_BF16, "decoder_pack: bad texel dtype");
+  int n_out = n_attention > 0 ? 1 + n_attention : 4;
+  hipLaunchKernelGGL(decoder_pack_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, w1, b1, w2, b2, n_out, texel_dtype,
+                     image);
+  return check_launch("decoder_pack");
+}
+
+// ------------------------------------------------------------------------------------------------
+// rays + scene-cube planes
+// ------------------------------------------------------------------------------------------------
+// reduce[0] = ~key(min near | hit) (so that zero-initialised memory + atomicMax works),
+// reduce[1] = key(max far | hit), reduce[2] = hit count.
+__device__ __forceinline__ void block_reduce_planes(bool hit, float near, float far, uint32_t* reduce) {
+  __shared__ uint32_t s_min[4], s_max[4], s_cnt[4];
+  uint32_t kmin = hit ? ~ordered_key(near) : 0u;  // maximise the complement
+  uint32_t kmax = hit ? ordered_key(far) : 0u;
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) {
+    uint32_t a = (uint32_t)__shfl_xor((int)kmin, d, 64), b = (uint32_t)__shfl_xor((int)kmax, d, 64);
+    kmin = a > kmin ? a : kmin;
+    kmax = b > kmax ? b : kmax;
+  }
+  uint32_t cnt = (uint32_t)__popcll(__ballot(hit));
+  int wave = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) { s_min[wave] = kmin; s_max[wave] = kmax; s_cnt[wave] = cnt; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int nw = blockDim.x >> 6;
+    for (int w = 1; w < nw; ++w) {
+      kmin = s_min[w] > kmin ? s_min[w] : kmin;
+      kmax = s_max[w] > kmax ? s_max[w] : kmax;
+      cnt += s_cnt[w];
+    }
+    if (cnt) {
+      atomicMax(&reduce[0], kmin);
+      atomicMax(&reduce[1], kmax);
+      atomicAdd(&reduce[2], cnt);
+    }
+  }
+}
+
+struct RaygenOut {
+  float* ro; float* rd;          // [N,3] or null
+  float* near_raw; float* far_raw; uint8_t* hit;  // [N] or null (null near_raw -> no slab test)
+  uint32_t* reduce;
+  float scene_range;
+};
+
+__global__ __launch_bounds__(256) void raygen_kernel(CameraParams cam, int n_scenes, RaygenOut out) {
+  const int hw = cam.height * cam.width;
+  const int64_t n = (int64_t)n_scenes * hw;
+  const int64_t ray = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  bool hit = false;
+  float near = 0.0f, far = 0.0f;
+  if (ray < n) {
+    int b = (int)(ray / hw);
+    int pix = (int)(ray - (int64_t)b * hw);
+    int row = pix / cam.width, col = pix - row * cam.width;
+    float o[3], d[3];
+    make_ray(cam, b, row, col, o, d);
+    if (out.ro) { out.ro[ray * 3 + 0] = o[0]; out.ro[ray * 3 + 1] = o[1]; out.ro[ray * 3 + 2] = o[2]; }
+    if (out.rd) { out.rd[ray * 3 + 0] = d[0]; out.rd[ray * 3 + 1] = d[1]; out.rd[ray * 3 + 2] = d[2]; }
+    if (out.near_raw) {
+      hit = slab_test(o, d, out.scene_range, near, far);
+      // second, inflated test: lets the fused renderer skip rays that provably never enter the cube
+      float n2, f2;
+      bool hit_wide = slab_test(o, d, out.scene_range * 1.0001f, n2, f2);
+      out.near_raw[ray] = near;
+      out.far_raw[ray] = far;
+      out.hit[ray] = (uint8_t)((hit ? 1 : 0) | (hit_wide ? 2 : 0));
+    }
+  }
+  if (out.near_raw) block_reduce_planes(hit, near, far, out.reduce);
+}
+
+__global__ __launch_bounds__(256) void slab_kernel(const float* __restrict__ ro, const float* __restrict__ rd, int64_t n,
+                                                   float scene_range, float* __restrict__ near_raw,
+                                                   float* __restrict__ far_raw, uint8_t* __restrict__ hit_out,
+                                                   uint32_t* reduce) {
+  const int64_t ray = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  bool hit = false;
+  float near = 0.0f, far = 0.0f;
+  if (ray < n) {
+    float o[3] = {ro[ray * 3], ro[ray * 3 + 1], ro[ray * 3 + 2]};
+    float d[3] = {rd[ray * 3], rd[ray * 3 + 1], rd[ray * 3 + 2]};
+    hit = slab_test(o, d, scene_range, near, far);
+    float n2, f2;
+    bool hit_wide = slab_test(o, d, scene_range * 1.0001f, n2, f2);
+    near_raw[ray] = near;
+    far_raw[ray] = far;
+    hit_out[ray] = (uint8_t)((hit ? 1 : 0) | (hit_wide ? 2 : 0));
+  }
+  block_reduce_planes(hit, near, far, reduce);
+}
+
+__global__ __launch_bounds__(256) void finish_planes_kernel(const float* __restrict__ near_raw,
+                                                            const float* __restrict__ far_raw,
+                                                            const uint8_t* __restrict__ hit, const uint32_t* __restrict__ reduce,
+                                                            int64_t n, float* __restrict__ near_plane,
+                                                            float* __restrict__ far_plane) {
+  const int64_t ray = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (ray >= n) return;
+  float fill_near = ordered_key_inv(~reduce[0]), fill_far = ordered_key_inv(reduce[1]);
+  float a = near_raw[ray], b = far_raw[ray];
+  finish_planes((hit[ray] & 1) != 0, fill_near, fill_far, a, b);
+  near_plane[ray] = a;
+  far_plane[ray] = b;
+}
+
+extern "C" int nfi_raygen(const nfi_raygen_args* a, nfi_stream_t stream) {
+  REQUIRE(a && a->cam2world && a->ray_origins && a->ray_directions, "raygen: null pointer");
+  REQUIRE(a->n_scenes > 0 && a->height > 0 && a->width > 0, "raygen: bad shape");
+  CameraParams cam{a->cam2world, a->focal, a->bbox, a->focal ? a->center : nullptr, a->height, a->width, a->normalize};
+  RaygenOut out{a->ray_origins, a->ray_directions, nullptr, nullptr, nullptr, nullptr, 0.0f};
+  int64_t n = (int64_t)a->n_scenes * a->height * a->width;
+  hipLaunchKernelGGL(raygen_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, cam,
+                     a->n_scenes, out);
+  return check_launch("raygen");
+}
+
+extern "C" int nfi_near_far(const nfi_near_far_args* a, nfi_stream_t stream) {
+  REQUIRE(a && a->ray_origins && a->ray_directions && a->near_raw && a->far_raw && a->hit && a->reduce,
+          "near_far: null pointer");
+  REQUIRE(a->n_rays > 0, "near_far: no rays");
+  hipStream_t s = (hipStream_t)stream;
+  if (hipMemsetAsync(a->reduce, 0, 16, s) != hipSuccess) return fail(NFI_ERR_LAUNCH, "near_far: memset failed");
+  unsigned blocks = (unsigned)((a->n_rays + 255) / 256);
+  hipLaunchKernelGGL(slab_kernel, dim3(blocks), dim3(256), 0, s, a->ray_origins, a->ray_directions, a->n_rays,
+                     a->scene_range, a->near_raw, a->far_raw, a->hit, a->reduce);
+  if (a->near_plane && a->far_plane)
+    hipLaunchKernelGGL(finish_planes_kernel, dim3(blocks), dim3(256), 0, s, a->near_raw, a->far_raw, a->hit, a->reduce,
+                       a->n_rays, a->near_plane, a->far_plane);
+  return check_launch("near_far");
+}
+
+// ------------------------------------------------------------------------------------------------
+// stratified depths + query points (lib/nerf_utils.py:94-120)
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float stratified_depth(float near, float far, int k, int S, float noise, bool jitter) {
+  float t = aten_lerp(near, far, (float)k / (float)S);
+  if (jitter) t = t + noise * ((far - near) / (float)S);
+  return t;
+}
+
+__global__ __launch_bounds__(256) void stratified_kernel(nfi_stratified_args a) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t total = a.n_rays * a.n_samples;
+  if (idx >= total) return;
+  const int64_t ray = idx / a.n_samples;
+  const int k = (int)(idx - ray * a.n_samples);
+  float near = a.near_plane[ray], far = a.far_plane[ray];
+  float t = stratified_depth(near, far, k, a.n_samples, a.noise ? a.noise[idx] : 0.0f, a.noise != nullptr);
+  a.depth[idx] = t;
+  if (a.points) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) a.points[idx * 3 + c] = a.ray_origins[ray * 3 + c] + a.ray_directions[ray * 3 + c] * t;
+  }
+}
+
+extern "C" int nfi_stratified_points(const nfi_stratified_args* a, nfi_stream_t stream) {
+  REQUIRE(a && a->ray_origins && a->ray_directions && a->near_plane && a->far_plane && a->depth, "stratified: null pointer");
+  REQUIRE(a->n_rays > 0 && a->n_samples > 0, "stratified: bad shape");
+  int64_t total = a->n_rays * a->n_samples;
+  hipLaunchKernelGGL(stratified_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, *a);
+  return check_launch("stratified_points");
+}
+
+// ------------------------------------------------------------------------------------------------
+// field query (sampler closure)
+// ------------------------------------------------------------------------------------------------
+struct FieldKernelParams {
+  const float* points; int64_t P;
+  const void* texels; int res; int tex;
+  const float* image; int A; const float* att;
+  int use_sdf; const float* beta; const float* alpha; float scene_range;
+  float* sigma; float* rgb; float* sdf; float* sem; uint8_t* outside;
+};
+
+// stage the decoder image (+ this scene's attention values in accumulator layout) into LDS
+__device__ __forceinline__ void stage_field_lds(float* lds, const float* image, const float* att_scene, int A) {
+  for (int i = threadIdx.x; i < kImageFloats; i += blockDim.x) lds[i] = image[i];
+  for (int i = threadIdx.x; i < 64; i += blockDim.x) {
+    int c = i & 3, row = i >> 2;  // row = 4g + r; value for feature row-1
+    float v = 0.0f;
+    if (att_scene && c < 3 && row >= 1 && row <= A) v = att_scene[(row - 1) * 3 + c];
+    lds[kVF + i] = v;
+  }
+}
+
+__device__ __forceinline__ FieldParams make_field_params(const void* texels_scene, int res, int tex, int A, int use_sdf,
+                                                         const float* beta, const float* alpha, const float* lds) {
+  FieldParams P;
+  uint32_t tb = tex == 0 ? 128u : 64u;
+  P.plane_bytes = (uint32_t)res * (uint32_t)res * tb;
+  P.row_bytes = (uint32_t)res * tb;
+  P.rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(texels_scene), 0, (int)(3u * P.plane_bytes), 0x00020000);
+  P.res = res;
+  P.res_m1 = (float)(res - 1);
+  P.n_attention = A;
+  P.use_sdf = use_sdf;
+  P.inv_alpha = use_sdf ? 1.0f / alpha[0] : 1.0f;
+  P.beta = use_sdf ? beta[0] : 1.0f;
+  P.lds = lds;
+  return P;
+}
+
+template <int TEX, bool ATT>
+__global__ __launch_bounds__(256) void field_query_kernel(FieldKernelParams k) {
+  __shared__ __attribute__((aligned(16))) float lds[kFieldLdsFloats];
+  const int scene = blockIdx.y;
+  stage_field_lds(lds, k.image, k.att ? k.att + (size_t)scene * k.A * 3 : nullptr, k.A);
+  __syncthreads();
+  const size_t tb = TEX == 0 ? 128 : 64;
+  const char* tex_scene = reinterpret_cast<const char*>(k.texels) + (size_t)scene * 3 * k.res * k.res * tb;
+  FieldParams P = make_field_params(tex_scene, k.res, TEX, k.A, k.use_sdf, k.beta, k.alpha, lds);
+  const int lane = lane_id();
+  const int wave = threadIdx.x >> 6;
+  const int64_t n_chunks = (k.P + 63) / 64;
+  for (int64_t chunk = (int64_t)blockIdx.x * 4 + wave; chunk < n_chunks; chunk += (int64_t)gridDim.x * 4) {
+    int64_t p = chunk * 64 + lane;
+    bool valid = p < k.P;
+    size_t gi = (size_t)scene * k.P + (valid ? p : 0);
+    float px = 0.0f, py = 0.0f, pz = 0.0f;
+    if (valid) { px = k.points[gi * 3]; py = k.points[gi * 3 + 1]; pz = k.points[gi * 3 + 2]; }
+    bool out;
+    float* sem = k.sem ? k.sem + ((size_t)scene * k.P + chunk * 64) * k.A : nullptr;
+    SampleOut so = field_wave<TEX, ATT>(P, k.scene_range, lane, px, py, pz, valid, sem, &out);
+    if (valid) {
+      k.sigma[gi] = so.sigma;
+      k.rgb[gi * 3] = so.r; k.rgb[gi * 3 + 1] = so.g; k.rgb[gi * 3 + 2] = so.b;
+      if (k.sdf) k.sdf[gi] = so.sdf;
+      if (k.outside) k.outside[gi] = out ? 1 : 0;
+    }
+  }
+}
+
+static int check_field_common(const void* texels, int plane_res, int texel_dtype, const float* image, int A,
+                              const float* att, int use_sdf, const float* beta, const float* alpha) {
+  REQUIRE(texels && image, "field: null texels / decoder image");
+  REQUIRE(plane_res >= 2 && plane_res <= 1024, "field: plane_res must be in [2,1024]");
+  REQUIRE(texel_dtype == NFI_TEXEL_F32 || texel_dtype == NFI_TEXEL_BF16, "field: bad texel dtype");
+  REQUIRE(A >= 0 && A <= NFI_MAX_ATTENTION, "field: attention_values must be in [0,14]");
+  REQUIRE(A == 0 || att, "field: attention_values tensor missing");
+  REQUIRE(!use_sdf || (beta && alpha), "field: use_sdf needs beta and alpha");
+  return NFI_OK;
+}
+
+extern "C" int nfi_field_query_fwd(const nfi_field_args* a, nfi_stream_t stream) {
+  REQUIRE(a && a->points && a->sigma && a->rgb, "field_query: null pointer");
+  REQUIRE(a->n_scenes > 0 && a->points_per_scene > 0, "field_query: bad shape");
+  int rc = check_field_common(a->texels, a->plane_res, a->texel_dtype, a->decoder_image, a->n_attention,
+                               a->attention_values, a->use_sdf, a->beta, a->alpha);
+  if (rc) return rc;
+  REQUIRE(!a->semantics || a->n_attention > 0, "field_query: semantics need attention_values > 0");
+  // unskipped tiles of invalid lanes may write semantics rows past P in the last chunk: forbid unless P%64==0
+  FieldKernelParams k{a->points, a->points_per_scene, a->texels, a->plane_res, a->texel_dtype, a->decoder_image,
+                      a->n_attention, a->attention_values, a->use_sdf, a->beta, a->alpha, a->scene_range,
+                      a->sigma, a->rgb, a->sdf, a->semantics, a->outside};
+  int64_t chunks = (a->points_per_scene + 63) / 64;
+  int64_t blocks = (chunks + 3) / 4;
+  if (blocks > 2048) blocks = 2048;
+  dim3 grid((unsigned)blocks, (unsigned)a->n_scenes);
+  hipStream_t s = (hipStream_t)stream;
+  bool att = a->n_attention > 0;
+  if (a->texel_dtype == NFI_TEXEL_F32) {
+    if (att) hipLaunchKernelGGL((field_query_kernel<0, true>), grid, dim3(256), 0, s, k);
+    else hipLaunchKernelGGL((field_query_kernel<0, false>), grid, dim3(256), 0, s, k);
+  } else {
+    if (att) hipLaunchKernelGGL((field_query_kernel<1, true>), grid, dim3(256), 0, s, k);
+    else hipLaunchKernelGGL((field_query_kernel<1, false>), grid, dim3(256), 0, s, k);
+  }
+  return check_launch("field_query_fwd");
+}
+
+// ------------------------------------------------------------------------------------------------
+// per-wave LDS slab used by the sampling / compositing stages
+// ------------------------------------------------------------------------------------------------
+struct __attribute__((aligned(16))) WaveSlab {
+  float cdf[128];
+  float bins[128];
+  uint32_t key[128];
+  float srt[5][128];   // depth, sigma, r, g, b in merged order
+};
+
+// ---- inverse CDF on a ray held one element per (slot, lane) -----------------------------------
+// bins[e] e<M, weights[e] e<M-1 (already padded with 0 past M-1).  Writes cdf/bins to the slab and
+// returns, for each of this lane's u values, the sample and the searchsorted index.
+template <int SPL>
+__device__ __forceinline__ void build_cdf(WaveSlab& slab, const float (&bins)[SPL], const float (&wts)[SPL], int M,
+                                          int lane) {
+  float q[SPL];
+  float tot = 0.0f;
+#pragma unroll
+  for (int j = 0; j < SPL; ++j) {
+    int e = j * 64 + lane;
+    q[j] = (e < M - 1) ? (wts[j] + 1e-5f) : 0.0f;
+    tot += q[j];
+  }
+  tot = wave_sum(tot);
+  float pdf[SPL], inc[SPL];
+#pragma unroll
+  for (int j = 0; j < SPL; ++j) pdf[j] = (j * 64 + lane < M - 1) ? q[j] / tot : 0.0f;
+  incl_cumsum<SPL>(pdf, inc, lane);
+  // cdf[0] = 0, cdf[e+1] = inclusive sum through e
+#pragma unroll
+  for (int j = 0; j < SPL; ++j) {
+    int e = j * 64 + lane;
+    if (e < M - 1) slab.cdf[e + 1] = inc[j];
+    if (e < M) slab.bins[e] = bins[j];
+  }
+  if (lane == 0) slab.cdf[0] = 0.0f;
+  wave_lds_fence();
+}
+
+__device__ __forceinline__ float invert_cdf(const WaveSlab& slab, int M, float u, int& ind) {
+  ind = upper_bound_lds(slab.cdf, M, u);
+  int lo = ind - 1 < 0 ? 0 : ind - 1;
+  int hi = ind > M - 1 ? M - 1 : ind;
+  float c_lo = slab.cdf[lo], c_hi = slab.cdf[hi];
+  float b_lo = slab.bins[lo], b_hi = slab.bins[hi];
+  float den = c_hi - c_lo;
+  den = (den < 1e-5f) ? 1.0f : den;
+  float fr = (u - c_lo) / den;
+  return b_lo + fr * (b_hi - b_lo);
+}
+
+// EG3D smoothing of S weights held one per lane (run.py:264-272); lanes >= S return garbage
+__device__ __forceinline__ float smooth_weights(float w, int S, int lane) {
+  float wp = __shfl_up(w, 1, 64);
+  float wn = __shfl_down(w, 1, 64);
+  if (lane == 0) wp = -INFINITY;
+  if (lane >= S - 1) wn = -INFINITY;
+  float m0 = fmaxf(wp, w);   // max(w[k-1], w[k])
+  float m1 = fmaxf(w, wn);   // max(w[k], w[k+1])
+  return (m0 + m1) / 2.0f + 0.01f;
+}
+
+// hierarchical resampling for S <= 64: coarse weights -> smooth -> pdf over smooth[1..S-2] on the
+// S-1 bin mid-points -> S fine depths.  Returns the fine depth for this lane's u.
+struct ResampleTaps { float w, smooth; int ind; };
+__device__ __forceinline__ float resample_ray(WaveSlab& slab, float sigma, float t, int S, float dnorm, float u, int lane,
+                                              ResampleTaps* taps) {
+  float sg[1] = {lane < S ? sigma : 0.0f}, tt[1] = {t}, w[1];
+  ray_weights<1>(sg, tt, S, dnorm, lane, w);
+  float sm = smooth_weights(w[0], S, lane);
+  float tn = __shfl_down(t, 1, 64);
+  float mid[1] = {0.5f * (tn + t)};                       // bins e = 0..S-2
+  float wts[1] = {__shfl_down(sm, 1, 64)};                 // weights e = 0..S-3  <- smooth[e+1]
+  build_cdf<1>(slab, mid, wts, S - 1, lane);
+  int ind;
+  float z = invert_cdf(slab, S - 1, u, ind);
+  if (taps) { taps->w = w[0]; taps->smooth = sm; taps->ind = ind; }
+  return z;
+}
+
+// ---- merge + composite ---------------------------------------------------------------------------
+// Every lane owns up to 2 input samples (element e = slot*64+lane of cat(a,b)); computes the
+// stable ascending rank of each key among the n keys, scatters (depth, sigma, rgb) to the slab in
+// merged order.  rank_out: merged position of each of this lane's elements.
+__device__ __forceinline__ void merge_scatter(WaveSlab& slab, const float (&dep)[2], const float (&sig)[2],
+                                              const float (&cr)[2], const float (&cg)[2], const float (&cb)[2], int n,
+                                              int lane, int (&rank_out)[2]) {
+  uint32_t key[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    int e = j * 64 + lane;
+    key[j] = ordered_key(dep[j]);
+    if (e < n) slab.key[e] = key[j];
+  }
+  wave_lds_fence();
+  int rank[2] = {0, 0};
+  const uint4* kv = reinterpret_cast<const uint4*>(slab.key);
+  const int n4 = (n + 3) >> 2;
+  for (int i = 0; i < n4; ++i) {
+    uint4 q = kv[i];
+    uint32_t qq[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      int idx = 4 * i + c;
+      bool in = idx < n;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        int e = j * 64 + lane;
+        bool before = (qq[c] < key[j]) || (qq[c] == key[j] && idx < e);
+        rank[j] += (in && before) ? 1 : 0;
+      }
+    }
+  }
+  wave_lds_fence();
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    int e = j * 64 + lane;
+    rank_out[j] = rank[j];
+    if (e < n) {
+      int r = rank[j];
+      slab.srt[0][r] = dep[j]; slab.srt[1][r] = sig[j];
+      slab.srt[2][r] = cr[j]; slab.srt[3][r] = cg[j]; slab.srt[4][r] = cb[j];
+    }
+  }
+  wave_lds_fence();
+}
+
+struct CompositeOut { float r, g, b, depth, mask; };
+
+// composite the n samples sitting in merged order in the slab (lib/nerf_utils.py:123-161)
+__device__ __forceinline__ CompositeOut composite_slab(const WaveSlab& slab, int n, float dnorm, int white, int lane,
+                                                       float (&w_out)[2]) {
+  float dep[2], sig[2], w[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    int e = j * 64 + lane;
+    dep[j] = (e < n) ? slab.srt[0][e] : 0.0f;
+    sig[j] = (e < n) ? slab.srt[1][e] : 0.0f;
+  }
+  ray_weights<2>(sig, dep, n, dnorm, lane, w);
+  float r = 0.0f, g = 0.0f, b = 0.0f, d = 0.0f, m = 0.0f;
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    int e = j * 64 + lane;
+    if (e < n) {
+      r += w[j] * slab.srt[2][e]; g += w[j] * slab.srt[3][e]; b += w[j] * slab.srt[4][e];
+      d += w[j] * dep[j]; m += w[j];
+    }
+    w_out[j] = w[j];
+  }
+  CompositeOut o;
+  o.r = wave_sum(r); o.g = wave_sum(g); o.b = wave_sum(b); o.depth = wave_sum(d); o.mask = wave_sum(m);
+  if (white) { float bg = 1.0f - o.mask; o.r += bg; o.g += bg; o.b += bg; }
+  return o;
+}
+
+// ------------------------------------------------------------------------------------------------
+// stand-alone stage kernels (one wave per ray)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void ray_weights_kernel(nfi_weights_args a) {
+  const int lane = lane_id();
+  const int64_t ray = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (ray >= a.n_rays) return;
+  const int S = a.n_samples;
+  float sig[2], t[2], w[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    int e = j * 64 + lane;
+    sig[j] = e < S ? a.sigma[ray * S + e] : 0.0f;
+    t[j] = e < S ? a.depth[ray * S + e] : 0.0f;
+  }
+  float dn = norm3(a.ray_directions[ray * 3], a.ray_directions[ray * 3 + 1], a.ray_directions[ray * 3 + 2]);
+  ray_weights<2>(sig, t, S, dn, lane, w);
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    int e = j * 64 + lane;
+    if (e < S) a.weights[ray * S + e] = w[j];
+  }
+}
+
+extern "C" int nfi_ray_weights(const nfi_weights_args* a, nfi_stream_t stream) {
+  REQUIRE(a && a->sigma && a->ray_directions && a->depth && a->weights, "ray_weights: null pointer");
+  REQUIRE(a->n_rays > 0 && a->n_samples > 0 && a->n_samples <= NFI_MAX_SAMPLES, "ray_weights: n_samples must be in [1,128]");
+  hipLaunchKernelGGL(ray_weights_kernel, dim3((unsigned)((a->n_rays + 3) / 4)), dim3(256), 0, (hipStream_t)stream, *a);
+  return check_launch("ray_weights");
+}
+
+__global__ __launch_bounds__(256) void sample_pdf_kernel(nfi_sample_pdf_args a) {
+  __shared__ WaveSlab slabs[4];
+  const int lane = lane_id();
+  const int wave = threadIdx.x >> 6;
+  const int64_t ray = (int64_t)blockIdx.x * 4 + wave;
+  if (ray >= a.n_rays) return;
+  WaveSlab& slab = slabs[wave];
+  const int M = a.n_bins, K = a.n_samples;
+  float bins[2], wts[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    int e = j * 64 + lane;
+    bins[j] = e < M ? a.bins[ray * M + e] : 0.0f;
+    wts[j] = e < M - 1 ? a.weights[ray * (M - 1) + e] : 0.0f;
+  }
+  build_cdf<2>(slab, bins, wts, M, lane);
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    int e = j * 64 + lane;
+    if (e < K) {
+      float u = a.u[ray * a.u_row_stride + e];
+      int ind;
+      float z = invert_cdf(slab, M, u, ind);
+      a.samples[ray * K + e] = z;
+      if (a.inds) a.inds[ray * K + e] = ind;
+    }
+    if (a.cdf && e < M) a.cdf[ray * M + e] = slab.cdf[e];
+  }
+}
+
+extern "C" int nfi_sample_pdf(const nfi_sample_pdf_args* a, nfi_stream_t stream) {
+  REQUIRE(a && a->bins && a->weights && a->u && a->samples, "sample_pdf: null pointer");
+  REQUIRE(a->n_rays > 0 && a->n_bins >= 2 && a->n_bins <= 128 && a->n_samples >= 1 && a->n_samples <= 128,
+          "sample_pdf: need 2 <= bins <= 128 and 1 <= samples <= 128");
+  hipLaunchKernelGGL(sample_pdf_kernel, dim3((unsigned)((a->n_rays + 3) / 4)), dim3(256), 0, (hipStream_t)stream, *a);
+  return check_launch("sample_pdf");
+}
+
+__global__ __launch_bounds__(256) void resample_kernel(nfi_resample_args a) {
+  __shared__ WaveSlab slabs[4];
+  const int lane = lane_id();
+  const int wave = threadIdx.x >> 6;
+  const int64_t ray = (int64_t)blockIdx.x * 4 + wave;
+  if (ray >= a.n_rays) return;
+  WaveSlab& slab = slabs[wave];
+  const int S = a.n_samples;
+  float sigma = lane < S ? a.sigma[ray * S + lane] : 0.0f;
+  float t = lane < S ? a.depth[ray * S + lane] : 0.0f;
+  float u = lane < S ? a.u[ray * a.u_row_stride + lane] : 0.0f;
+  float dn = norm3(a.ray_directions[ray * 3], a.ray_directions[ray * 3 + 1], a.ray_directions[ray * 3 + 2]);
+  ResampleTaps taps;
+  float z = resample_ray(slab, sigma, t, S, dn, u, lane, &taps);
+  if (lane < S) {
+    a.fine_depth[ray * S + lane] = z;
+    if (a.weights) a.weights[ray * S + lane] = taps.w;
+    if (a.smooth) a.smooth[ray * S + lane] = taps.smooth;
+    if (a.inds) a.inds[ray * S + lane] = taps.ind;
+  }
+  if (a.cdf && lane < S - 1) a.cdf[ray * (S - 1) + lane] = slab.cdf[lane];
+}
+
+extern "C" int nfi_resample(const nfi_resample_args* a, nfi_stream_t stream) {
+  REQUIRE(a && a->sigma && a->ray_directions && a->depth && a->u && a->fine_depth, "resample: null pointer");
+  REQUIRE(a->n_rays > 0 && a->n_samples >= 4 && a->n_samples <= 64, "resample: n_samples must be in [4,64]");
+  hipLaunchKernelGGL(resample_kernel, dim3((unsigned)((a->n_rays + 3) / 4)), dim3(256), 0, (hipStream_t)stream, *a);
+  return check_launch("resample");
+}
+
+__global__ __launch_bounds__(256) void composite_kernel(nfi_composite_args a) {
+  __shared__ WaveSlab slabs[4];
+  const int lane = lane_id();
+  const int wave = threadIdx.x >> 6;
+  const int64_t ray = (int64_t)blockIdx.x * 4 + wave;
+  if (ray >= a.n_rays) return;
+  WaveSlab& slab = slabs[wave];
+  const int na = a.n_a, nb = a.n_b, n = na + nb;
+  float dep[2], sig[2], cr[2], cg[2], cb[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    int e = j * 64 + lane;
+    dep[j] = sig[j] = cr[j] = cg[j] = cb[j] = 0.0f;
+    if (e < na) {
+      size_t i = (size_t)ray * na + e;
+      dep[j] = a.depth_a[i]; sig[j] = a.sigma_a[i];
+      cr[j] = a.rgb_a[i * 3]; cg[j] = a.rgb_a[i * 3 + 1]; cb[j] = a.rgb_a[i * 3 + 2];
+    } else if (e < n) {
+      size_t i = (size_t)ray * nb + (e - na);
+      dep[j] = a.depth_b[i]; sig[j] = a.sigma_b[i];
+      cr[j] = a.rgb_b[i * 3]; cg[j] = a.rgb_b[i * 3 + 1]; cb[j] = a.rgb_b[i * 3 + 2];
+    }
+  }
+  int rank[2];
+  if (nb > 0) {
+    merge_scatter(slab, dep, sig, cr, cg, cb, n, lane, rank);
+  } else {
+    // list a is composited in the order given (render_volume_density does not sort)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      int e = j * 64 + lane;
+      rank[j] = e;
+      if (e < n) { slab.srt[0][e] = dep[j]; slab.srt[1][e] = sig[j]; slab.srt[2][e] = cr[j]; slab.srt[3][e] = cg[j]; slab.srt[4][e] = cb[j]; }
+    }
+    wave_lds_fence();
+  }
+  float dn = norm3(a.ray_directions[ray * 3], a.ray_directions[ray * 3 + 1], a.ray_directions[ray * 3 + 2]);
+  float w[2];
+  CompositeOut o = composite_slab(slab, n, dn, a.white_background, lane, w);
+  if (lane == 0) {
+    a.rgb_map[ray * 3] = o.r; a.rgb_map[ray * 3 + 1] = o.g; a.rgb_map[ray * 3 + 2] = o.b;
+    a.depth_map[ray] = o.depth;
+    a.mask[ray] = o.mask;
+  }
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    int e = j * 64 + lane;
+    if (e < n) {
+      if (a.weights) a.weights[(size_t)ray * n + e] = w[j];
+      if (a.depth_sorted) a.depth_sorted[(size_t)ray * n + e] = slab.srt[0][e];
+      if (a.perm) a.perm[(size_t)ray * n + rank[j]] = e;
+    }
+  }
+  // extra attribute (semantics / normals / coords): weights are in merged order, attributes in input order
+  if (a.n_extra > 0 && a.extra_map) {
+    wave_lds_fence();
+    // park the merged-order weights in the slab, then every lane accumulates its own elements
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      int e = j * 64 + lane;
+      if (e < n) slab.cdf[e] = w[j];
+    }
+    wave_lds_fence();
+    float we[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) { int e = j * 64 + lane; we[j] = e < n ? slab.cdf[rank[j]] : 0.0f; }
+    for (int c = 0; c < a.n_extra; ++c) {
+      float acc = 0.0f;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        int e = j * 64 + lane;
+        if (e < na) acc += we[j] * a.extra_a[((size_t)ray * na + e) * a.n_extra + c];
+        else if (e < n) acc += we[j] * a.extra_b[((size_t)ray * nb + (e - na)) * a.n_extra + c];
+      }
+      acc = wave_sum(acc);
+      if (lane == 0) a.extra_map[ray * a.n_extra + c] = acc;
+    }
+  }
+}
+
+extern "C" int nfi_composite_fwd(const nfi_composite_args* a, nfi_stream_t stream) {
+  REQUIRE(a && a->ray_directions && a->depth_a && a->sigma_a && a->rgb_a && a->rgb_map && a->depth_map && a->mask,
+          "composite: null pointer");
+  REQUIRE(a->n_rays > 0 && a->n_a > 0 && a->n_b >= 0 && a->n_a + a->n_b <= NFI_MAX_SAMPLES,
+          "composite: need 1 <= n_a + n_b <= 128");
+  REQUIRE(a->n_b == 0 || (a->depth_b && a->sigma_b && a->rgb_b), "composite: list b missing");
+  REQUIRE(a->n_extra == 0 || (a->extra_a && (a->n_b == 0 || a->extra_b)), "composite: extra attribute missing");
+  hipLaunchKernelGGL(composite_kernel, dim3((unsigned)((a->n_rays + 3) / 4)), dim3(256), 0, (hipStream_t)stream, *a);
+  return check_launch("composite_fwd");
+}
+
+// ------------------------------------------------------------------------------------------------
+// fused forward render
+// ------------------------------------------------------------------------------------------------
+struct RenderKernelParams {
+  int n_scenes, hw, S;
+  int fine, white;
+  float scene_range;
+  // ray set-up results
+  const float* ro; const float* rd; const float* near_raw; const float* far_raw; const uint8_t* hit;
+  const uint32_t* reduce;
+  // field
+  const void* texels; int res;
+  const float* image; int A; const float* att;
+  int use_sdf; const float* beta; const float* alpha;
+  // noise
+  const float* noise_c; const float* noise_f; int64_t noise_f_stride;
+  // outputs
+  float* rgb; float* depth; float* mask;
+  // taps
+  float* near_plane; float* far_plane;
+  float* t_coarse; float* sigma_coarse; float* rgb_coarse;
+  float* t_fine; float* sigma_fine; float* rgb_fine;
+  float* t_sorted; float* weights; int32_t* perm;
+  int skip_missed;
+};
+
+template <int TEX, bool ATT>
+__global__ __launch_bounds__(256) void render_fwd_kernel(RenderKernelParams k) {
+  __shared__ __attribute__((aligned(16))) float lds[kFieldLdsFloats];
+  __shared__ WaveSlab slabs[4];
+  const int scene = blockIdx.y;
+  stage_field_lds(lds, k.image, k.att ? k.att + (size_t)scene * k.A * 3 : nullptr, k.A);
+  __syncthreads();
+  const size_t tb = TEX == 0 ? 128 : 64;
+  const char* tex_scene = reinterpret_cast<const char*>(k.texels) + (size_t)scene * 3 * k.res * k.res * tb;
+  FieldParams P = make_field_params(tex_scene, k.res, TEX, k.A, k.use_sdf, k.beta, k.alpha, lds);
+  const int lane = lane_id();
+  const int wave = threadIdx.x >> 6;
+  WaveSlab& slab = slabs[wave];
+  const int S = k.S;
+  const float fill_near = ordered_key_inv(~k.reduce[0]), fill_far = ordered_key_inv(k.reduce[1]);
+  const float bg = k.white ? 1.0f : 0.0f;
+
+  for (int pix = blockIdx.x * 4 + wave; pix < k.hw; pix += gridDim.x * 4) {
+    const int64_t ray = (int64_t)scene * k.hw + pix;
+    const uint8_t hitb = k.hit[ray];
+    if (k.skip_missed && !(hitb & 2)) {
+      // the ray's line stays outside the (inflated) scene cube: every sample has sigma == 0
+      if (lane == 0) {
+        k.rgb[ray * 3] = bg; k.rgb[ray * 3 + 1] = bg; k.rgb[ray * 3 + 2] = bg;
+        k.depth[ray] = 0.0f; k.mask[ray] = 0.0f;
+      }
+      continue;
+    }
+    const float ox = k.ro[ray * 3], oy = k.ro[ray * 3 + 1], oz = k.ro[ray * 3 + 2];
+    const float dx = k.rd[ray * 3], dy = k.rd[ray * 3 + 1], dz = k.rd[ray * 3 + 2];
+    float near = k.near_raw[ray], far = k.far_raw[ray];
+    finish_planes((hitb & 1) != 0, fill_near, fill_far, near, far);
+    if (lane == 0) {
+      if (k.near_plane) k.near_plane[ray] = near;
+      if (k.far_plane) k.far_plane[ray] = far;
+    }
+    const bool valid = lane < S;
+    const float dnorm = norm3(dx, dy, dz);
+
+    // ---- coarse pass ----
+    float tc = 0.0f;
+    if (valid) tc = stratified_depth(near, far, lane, S, k.noise_c ? k.noise_c[ray * S + lane] : 0.0f, k.noise_c != nullptr);
+    float px = ox + dx * tc, py = oy + dy * tc, pz = oz + dz * tc;
+    SampleOut c = field_wave<TEX, ATT>(P, k.scene_range, lane, px, py, pz, valid, nullptr, nullptr);
+    if (valid) {
+      if (k.t_coarse) k.t_coarse[ray * S + lane] = tc;
+      if (k.sigma_coarse) k.sigma_coarse[ray * S + lane] = c.sigma;
+      if (k.rgb_coarse) { float* q = k.rgb_coarse + (ray * S + lane) * 3; q[0] = c.r; q[1] = c.g; q[2] = c.b; }
+    }
+
+    int n = S;
+    float dep[2] = {tc, 0.0f}, sig[2] = {c.sigma, 0.0f}, cr[2] = {c.r, 0.0f}, cg[2] = {c.g, 0.0f}, cb[2] = {c.b, 0.0f};
+    int rank[2] = {lane, 64 + lane};
+    if (k.fine) {
+      // ---- hierarchical resampling + fine pass ----
+      float u = valid ? k.noise_f[ray * k.noise_f_stride + lane] : 0.0f;
+      float tf = resample_ray(slab, c.sigma, tc, S, dnorm, u, lane, nullptr);
+      float fx = ox + dx * tf, fy = oy + dy * tf, fz = oz + dz * tf;
+      SampleOut f = field_wave<TEX, ATT>(P, k.scene_range, lane, fx, fy, fz, valid, nullptr, nullptr);
+      if (valid) {
+        if (k.t_fine) k.t_fine[ray * S + lane] = tf;
+        if (k.sigma_fine) k.sigma_fine[ray * S + lane] = f.sigma;
+        if (k.rgb_fine) { float* q = k.rgb_fine + (ray * S + lane) * 3; q[0] = f.r; q[1] = f.g; q[2] = f.b; }
+      }
+      n = 2 * S;
+      // element e of cat(coarse, fine): e < S coarse, else fine.  With S < 64 both halves sit in
+      // slot 0/1 differently, so build the (slot, lane) view explicitly.
+      if (S == 64) {
+        dep[1] = tf; sig[1] = f.sigma; cr[1] = f.r; cg[1] = f.g; cb[1] = f.b;
+      } else {
+        // lanes [S, 2S) of slot 0 take the fine sample of lane-S; slot 1 takes the rest
+        int src = lane - S;
+        float tf0 = __shfl(tf, src & 63, 64), sf0 = __shfl(f.sigma, src & 63, 64);
+        float rf0 = __shfl(f.r, src & 63, 64), gf0 = __shfl(f.g, src & 63, 64), bf0 = __shfl(f.b, src & 63, 64);
+        int src1 = 64 + lane - S;   // element 64+lane -> fine index 64+lane-S
+        float tf1 = __shfl(tf, src1 & 63, 64), sf1 = __shfl(f.sigma, src1 & 63, 64);
+        float rf1 = __shfl(f.r, src1 & 63, 64), gf1 = __shfl(f.g, src1 & 63, 64), bf1 = __shfl(f.b, src1 & 63, 64);
+        if (lane >= S) { dep[0] = tf0; sig[0] = sf0; cr[0] = rf0; cg[0] = gf0; cb[0] = bf0; }
+        dep[1] = tf1; sig[1] = sf1; cr[1] = rf1; cg[1] = gf1; cb[1] = bf1;
+      }
+      merge_scatter(slab, dep, sig, cr, cg, cb, n, lane, rank);
+    } else {
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        int e = j * 64 + lane;
+        if (e < n) { slab.srt[0][e] = dep[j]; slab.srt[1][e] = sig[j]; slab.srt[2][e] = cr[j]; slab.srt[3][e] = cg[j]; slab.srt[4][e] = cb[j]; }
+      }
+      wave_lds_fence();
+    }
+    float w[2];
+    CompositeOut o = composite_slab(slab, n, dnorm, k.white, lane, w);
+    if (lane == 0) {
+      k.rgb[ray * 3] = o.r; k.rgb[ray * 3 + 1] = o.g; k.rgb[ray * 3 + 2] = o.b;
+      k.depth[ray] = o.depth; k.mask[ray] = o.mask;
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      int e = j * 64 + lane;
+      if (e < n) {
+        if (k.weights) k.weights[ray * n + e] = w[j];
+        if (k.t_sorted) k.t_sorted[ray * n + e] = slab.srt[0][e];
+        if (k.perm) k.perm[ray * n + rank[j]] = e;
+      }
+    }
+    wave_lds_fence();  // slab is reused by the next ray
+  }
+}
+
+extern "C" size_t nfi_render_workspace_bytes(int64_t n_rays) {
+  // ro, rd, near_raw, far_raw (fp32) + hit (u8, padded) + reduce[4]
+  size_t n = (size_t)n_rays;
+  return n * 8 * sizeof(float) + ((n + 15) & ~(size_t)15) + 64;
+}
+
+extern "C" int nfi_render_fwd(const nfi_render_args* a, nfi_stream_t stream) {
+  REQUIRE(a && a->cam2world && a->rgb && a->depth && a->mask && a->workspace, "render: null pointer");
+  REQUIRE(a->n_scenes > 0 && a->height > 0 && a->width > 0, "render: bad image shape");
+  REQUIRE(a->n_samples >= 4 && a->n_samples <= 64, "render: n_samples must be in [4,64] per pass");
+  REQUIRE(!a->fine_sampling || a->noise_fine, "render: fine sampling needs u (noise_fine)");
+  REQUIRE(!a->semantics, "render: composited semantics are produced by nfi_composite_fwd, not the fused kernel");
+  int rc = check_field_common(a->texels, a->plane_res, a->texel_dtype, a->decoder_image, a->n_attention,
+                               a->attention_values, a->use_sdf, a->beta, a->alpha);
+  if (rc) return rc;
+  const int64_t n = (int64_t)a->n_scenes * a->height * a->width;
+  if (a->workspace_bytes < nfi_render_workspace_bytes(n)) return fail(NFI_ERR_WORKSPACE_TOO_SMALL, "render: workspace too small");
+  hipStream_t s = (hipStream_t)stream;
+  // carve the workspace
+  float* ws = reinterpret_cast<float*>(a->workspace);
+  uint32_t* reduce = reinterpret_cast<uint32_t*>(ws);           // 16 floats reserved
+  float* ro = a->ray_origins ? a->ray_origins : ws + 16;
+  float* rd = a->ray_directions ? a->ray_directions : ws + 16 + 3 * n;
+  float* near_raw = ws + 16 + 6 * n;
+  float* far_raw = ws + 16 + 7 * n;
+  uint8_t* hit = a->hit ? a->hit : reinterpret_cast<uint8_t*>(ws + 16 + 8 * n);
+  // note: 16 floats + 8n floats + n bytes <= workspace_bytes by construction (64 + 32n + pad(n))
+  if (hipMemsetAsync(reduce, 0, 16, s) != hipSuccess) return fail(NFI_ERR_LAUNCH, "render: memset failed");
+  CameraParams cam{a->cam2world, a->focal, a->bbox, a->focal ? a->center : nullptr, a->height, a->width, 1};
+  RaygenOut rout{ro, rd, near_raw, far_raw, hit, reduce, a->scene_range};
+  hipLaunchKernelGGL(raygen_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, cam, a->n_scenes, rout);
+
+  const bool any_tap = a->t_coarse || a->sigma_coarse || a->rgb_coarse || a->t_fine || a->sigma_fine || a->rgb_fine ||
+                       a->t_sorted || a->weights || a->perm || a->near_plane || a->far_plane;
+  RenderKernelParams k;
+  memset(&k, 0, sizeof(k));
+  k.n_scenes = a->n_scenes; k.hw = a->height * a->width; k.S = a->n_samples;
+  k.fine = a->fine_sampling; k.white = a->white_background; k.scene_range = a->scene_range;
+  k.ro = ro; k.rd = rd; k.near_raw = near_raw; k.far_raw = far_raw; k.hit = hit; k.reduce = reduce;
+  k.texels = a->texels; k.res = a->plane_res; k.image = a->decoder_image; k.A = a->n_attention; k.att = a->attention_values;
+  k.use_sdf = a->use_sdf; k.beta = a->beta; k.alpha = a->alpha;
+  k.noise_c = a->noise_coarse; k.noise_f = a->noise_fine; k.noise_f_stride = a->noise_fine_row_stride;
+  k.rgb = a->rgb; k.depth = a->depth; k.mask = a->mask;
+  k.near_plane = a->near_plane; k.far_plane = a->far_plane;
+  k.t_coarse = a->t_coarse; k.sigma_coarse = a->sigma_coarse; k.rgb_coarse = a->rgb_coarse;
+  k.t_fine = a->t_fine; k.sigma_fine = a->sigma_fine; k.rgb_fine = a->rgb_fine;
+  k.t_sorted = a->t_sorted; k.weights = a->weights; k.perm = a->perm;
+  k.skip_missed = (a->skip_missed_rays && !any_tap) ? 1 : 0;
+
+  int blocks_x = (k.hw + 3) / 4;
+  int cap = 4096 / a->n_scenes;            // persistent grid: a few blocks per CU in total
+  if (cap < 64) cap = 64;
+  if (blocks_x > cap) blocks_x = cap;
+  dim3 grid((unsigned)blocks_x, (unsigned)a->n_scenes);
+  bool att = a->n_attention > 0;
+  if (a->texel_dtype == NFI_TEXEL_F32) {
+    if (att) hipLaunchKernelGGL((render_fwd_kernel<0, true>), grid, dim3(256), 0, s, k);
+    else hipLaunchKernelGGL((render_fwd_kernel<0, false>), grid, dim3(256), 0, s, k);
+  } else {
+    if (att) hipLaunchKernelGGL((render_fwd_kernel<1, true>), grid, dim3(256), 0, s, k);
+    else hipLaunchKernelGGL((render_fwd_kernel<1, false>), grid, dim3(256), 0, s, k);
+  }
+  return check_launch("render_fwd");
+}

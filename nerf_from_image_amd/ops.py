@@ -1,0 +1,303 @@
+"""Tensor-level wrappers over the C ABI (one function per entry point of include/nfi_hip.h).
+
+PyTorch is used here for device memory and streams only: every function checks
+its inputs, allocates the outputs as torch tensors, and passes raw device
+pointers plus ``torch.cuda.current_stream()`` to libnfi_hip.so.  Nothing here
+computes on the CPU and nothing falls back to ATen ops.
+"""
+import torch
+
+from . import _lib
+
+TEXEL_F32 = 0
+TEXEL_BF16 = 1
+
+
+def _stream(t):
+    return torch.cuda.current_stream(t.device).cuda_stream
+
+
+def _f32c(t, name):
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise RuntimeError('%s must live on the GPU (no CPU path in nerf_from_image_amd)' % name)
+    if t.dtype != torch.float32:
+        raise TypeError('%s must be float32, got %s' % (name, t.dtype))
+    return t.contiguous()
+
+
+# --------------------------------------------------------------------------- #
+def planes_to_texels(planes, texel_dtype=TEXEL_F32):
+    """planes [B,3,32,R,R] fp32 -> texels [B,3,R,R,32] (fp32 or bf16)."""
+    planes = _f32c(planes, 'planes')
+    B, three, C, R, R2 = planes.shape
+    if three != 3 or C != 32 or R != R2:
+        raise ValueError('planes must be [B,3,32,R,R], got %s' % (tuple(planes.shape),))
+    dt = torch.float32 if texel_dtype == TEXEL_F32 else torch.bfloat16
+    texels = torch.empty((B, 3, R, R, 32), dtype=dt, device=planes.device)
+    lib = _lib.load()
+    with torch.cuda.device(planes.device):
+        _lib.check(lib.nfi_planes_to_texels(_lib.ptr(planes), _lib.ptr(texels), B, R, texel_dtype, _stream(planes)),
+                   'nfi_planes_to_texels')
+    return texels
+
+
+def texels_to_planes(texels):
+    """fp32 texels [B,3,R,R,32] -> planes [B,3,32,R,R] (adjoint layout change for gradients)."""
+    texels = _f32c(texels, 'texels')
+    B, three, R, R2, C = texels.shape
+    planes = torch.empty((B, 3, C, R, R), dtype=torch.float32, device=texels.device)
+    lib = _lib.load()
+    with torch.cuda.device(texels.device):
+        _lib.check(lib.nfi_texels_to_planes(_lib.ptr(texels), _lib.ptr(planes), B, R, _stream(texels)),
+                   'nfi_texels_to_planes')
+    return planes
+
+
+def decoder_pack(w1, b1, w2, b2, n_attention, texel_dtype=TEXEL_F32):
+    """Raw TriplanarDecoder parameters -> lane-ordered MFMA operand image (fp32 [3152])."""
+    w1, b1, w2, b2 = (_f32c(t, n) for t, n in ((w1, 'w1'), (b1, 'b1'), (w2, 'w2'), (b2, 'b2')))
+    n_out = 1 + n_attention if n_attention > 0 else 4
+    if tuple(w1.shape) != (64, 32) or tuple(b1.shape) != (64,) or tuple(w2.shape) != (n_out, 64) \
+            or tuple(b2.shape) != (n_out,):
+        raise ValueError('decoder shapes must be [64,32],[64],[%d,64],[%d]; got %s %s %s %s' % (
+            n_out, n_out, tuple(w1.shape), tuple(b1.shape), tuple(w2.shape), tuple(b2.shape)))
+    lib = _lib.load()
+    image = torch.empty((lib.nfi_decoder_image_floats(),), dtype=torch.float32, device=w1.device)
+    with torch.cuda.device(w1.device):
+        _lib.check(lib.nfi_decoder_pack(_lib.ptr(w1), _lib.ptr(b1), _lib.ptr(w2), _lib.ptr(b2), n_attention,
+                                        texel_dtype, _lib.ptr(image), _stream(w1)), 'nfi_decoder_pack')
+    return image
+
+
+# --------------------------------------------------------------------------- #
+def raygen(height, width, focal, cam2world, bbox=None, center=None, normalize=False):
+    cam2world = _f32c(cam2world, 'tform_cam2world')
+    B = cam2world.shape[0]
+    dev = cam2world.device
+    focal, bbox, center = _f32c(focal, 'focal_length'), _f32c(bbox, 'bbox'), _f32c(center, 'center')
+    ro = torch.empty((B, height, width, 3), dtype=torch.float32, device=dev)
+    rd = torch.empty_like(ro)
+    with torch.cuda.device(dev):
+        _lib.call_struct('nfi_raygen', 'nfi_raygen_args', _stream(cam2world), n_scenes=B, height=height, width=width,
+                         cam2world=cam2world, focal=focal, bbox=bbox, center=center, normalize=int(normalize),
+                         ray_origins=ro, ray_directions=rd)
+    return ro, rd
+
+
+def near_far(ray_origins, ray_directions, scene_range, strict=True):
+    """Returns near, far (finished planes), hit (bool).  strict: raise when no ray hits, as the
+    reference does (costs a device->host read of one counter)."""
+    ro, rd = _f32c(ray_origins, 'ray_origins'), _f32c(ray_directions, 'ray_directions')
+    shape = ro.shape[:-1]
+    n = ro.numel() // 3
+    dev = ro.device
+    near_raw = torch.empty((n,), dtype=torch.float32, device=dev)
+    far_raw = torch.empty_like(near_raw)
+    near, far = torch.empty_like(near_raw), torch.empty_like(near_raw)
+    hit = torch.empty((n,), dtype=torch.uint8, device=dev)
+    red = torch.empty((4,), dtype=torch.int32, device=dev)
+    with torch.cuda.device(dev):
+        _lib.call_struct('nfi_near_far', 'nfi_near_far_args', _stream(ro), n_rays=n, ray_origins=ro,
+                         ray_directions=rd, scene_range=float(scene_range), near_raw=near_raw, far_raw=far_raw,
+                         hit=hit, reduce=red, near_plane=near, far_plane=far)
+    if strict and int(red[2].item()) == 0:
+        raise RuntimeError('compute_near_far_planes: no ray intersects the scene cube '
+                           '(the reference fails on min() of an empty selection here)')
+    return near.view(shape), far.view(shape), (hit & 1).bool().view(shape)
+
+
+def stratified_points(ray_origins, ray_directions, near, far, num_samples, noise=None, want_points=True):
+    ro, rd = _f32c(ray_origins, 'ray_origins'), _f32c(ray_directions, 'ray_directions')
+    near, far, noise = _f32c(near, 'near'), _f32c(far, 'far'), _f32c(noise, 'noise')
+    shape = ro.shape[:-1]
+    n = ro.numel() // 3
+    depth = torch.empty((*shape, num_samples), dtype=torch.float32, device=ro.device)
+    points = torch.empty((*shape, num_samples, 3), dtype=torch.float32, device=ro.device) if want_points else None
+    with torch.cuda.device(ro.device):
+        _lib.call_struct('nfi_stratified_points', 'nfi_stratified_args', _stream(ro), n_rays=n,
+                         n_samples=num_samples, ray_origins=ro, ray_directions=rd, near_plane=near, far_plane=far,
+                         noise=noise, depth=depth, points=points)
+    return points, depth
+
+
+# --------------------------------------------------------------------------- #
+def field_query(points, texels, decoder_image, scene_range, n_attention, attention_values=None, use_sdf=True,
+                beta=None, alpha=None, want_sdf=False, want_semantics=False, want_outside=False):
+    """points [B,P,3] -> dict(sigma [B,P], rgb [B,P,3], sdf?, semantics?, outside?)."""
+    points = _f32c(points, 'points')
+    B, P = points.shape[0], points.shape[1]
+    dev = points.device
+    tdt = TEXEL_F32 if texels.dtype == torch.float32 else TEXEL_BF16
+    att = _f32c(attention_values, 'attention_values') if n_attention > 0 else None
+    out = {'sigma': torch.empty((B, P), dtype=torch.float32, device=dev),
+           'rgb': torch.empty((B, P, 3), dtype=torch.float32, device=dev)}
+    if want_sdf:
+        out['sdf'] = torch.empty((B, P), dtype=torch.float32, device=dev)
+    if want_semantics:
+        out['semantics'] = torch.empty((B, P, n_attention), dtype=torch.float32, device=dev)
+    if want_outside:
+        out['outside'] = torch.empty((B, P), dtype=torch.uint8, device=dev)
+    with torch.cuda.device(dev):
+        _lib.call_struct('nfi_field_query_fwd', 'nfi_field_args', _stream(points), n_scenes=B, points_per_scene=P,
+                         points=points, texels=texels, plane_res=texels.shape[2], texel_dtype=tdt,
+                         decoder_image=decoder_image, n_attention=n_attention, attention_values=att,
+                         use_sdf=int(use_sdf), beta=_f32c(beta, 'beta') if use_sdf else None,
+                         alpha=_f32c(alpha, 'alpha') if use_sdf else None, scene_range=float(scene_range),
+                         sigma=out['sigma'], rgb=out['rgb'], sdf=out.get('sdf'), semantics=out.get('semantics'),
+                         outside=out.get('outside'))
+    return out
+
+
+# --------------------------------------------------------------------------- #
+def ray_weights(sigma, ray_directions, depth):
+    sigma, rd, depth = _f32c(sigma, 'sigma'), _f32c(ray_directions, 'ray_directions'), _f32c(depth, 'depth')
+    S = depth.shape[-1]
+    n = depth.numel() // S
+    w = torch.empty_like(depth)
+    with torch.cuda.device(depth.device):
+        _lib.call_struct('nfi_ray_weights', 'nfi_weights_args', _stream(depth), n_rays=n, n_samples=S, sigma=sigma,
+                         ray_directions=rd, depth=depth, weights=w)
+    return w
+
+
+def _u_and_stride(u, n, k):
+    """u: [n,k] dense, or a stride-0 broadcast of one row."""
+    if u.dim() == 2 and u.stride(0) == 0 and u.stride(1) == 1:
+        return u, 0
+    u = u.contiguous()
+    return u, k
+
+
+def sample_pdf(bins, weights, u, want_inds=False, want_cdf=False):
+    bins, weights = _f32c(bins, 'bins'), _f32c(weights, 'weights')
+    n, M = bins.shape
+    K = u.shape[-1]
+    u, stride = _u_and_stride(u, n, K)
+    dev = bins.device
+    samples = torch.empty((n, K), dtype=torch.float32, device=dev)
+    inds = torch.empty((n, K), dtype=torch.int64, device=dev) if want_inds else None
+    cdf = torch.empty((n, M), dtype=torch.float32, device=dev) if want_cdf else None
+    with torch.cuda.device(dev):
+        _lib.call_struct('nfi_sample_pdf', 'nfi_sample_pdf_args', _stream(bins), n_rays=n, n_bins=M, n_samples=K,
+                         bins=bins, weights=weights, u=u, u_row_stride=stride, samples=samples, inds=inds, cdf=cdf)
+    return samples, inds, cdf
+
+
+def resample(sigma, ray_directions, depth, u, want_taps=False):
+    sigma, rd, depth = _f32c(sigma, 'sigma'), _f32c(ray_directions, 'ray_directions'), _f32c(depth, 'depth')
+    S = depth.shape[-1]
+    n = depth.numel() // S
+    u, stride = _u_and_stride(u.reshape(-1, S) if u.stride(0) != 0 else u, n, S)
+    dev = depth.device
+    fine = torch.empty((n, S), dtype=torch.float32, device=dev)
+    taps = {}
+    if want_taps:
+        taps = dict(weights=torch.empty((n, S), dtype=torch.float32, device=dev),
+                    smooth=torch.empty((n, S), dtype=torch.float32, device=dev),
+                    cdf=torch.empty((n, S - 1), dtype=torch.float32, device=dev),
+                    inds=torch.empty((n, S), dtype=torch.int64, device=dev))
+    with torch.cuda.device(dev):
+        _lib.call_struct('nfi_resample', 'nfi_resample_args', _stream(depth), n_rays=n, n_samples=S, sigma=sigma,
+                         ray_directions=rd, depth=depth, u=u, u_row_stride=stride, fine_depth=fine, **taps)
+    return fine, taps
+
+
+def composite(ray_directions, depth_a, sigma_a, rgb_a, depth_b=None, sigma_b=None, rgb_b=None, extra_a=None,
+              extra_b=None, white_background=True, want_taps=False):
+    rd = _f32c(ray_directions, 'ray_directions')
+    depth_a, sigma_a, rgb_a = _f32c(depth_a, 'depth'), _f32c(sigma_a, 'sigma'), _f32c(rgb_a, 'rgb')
+    na = depth_a.shape[-1]
+    n = depth_a.numel() // na
+    nb = 0
+    if depth_b is not None:
+        depth_b, sigma_b, rgb_b = _f32c(depth_b, 'depth_b'), _f32c(sigma_b, 'sigma_b'), _f32c(rgb_b, 'rgb_b')
+        nb = depth_b.shape[-1]
+    n_extra = 0
+    if extra_a is not None:
+        extra_a = _f32c(extra_a, 'extra_a')
+        n_extra = extra_a.shape[-1]
+        extra_b = _f32c(extra_b, 'extra_b')
+    dev = depth_a.device
+    shape = depth_a.shape[:-1]
+    rgb_map = torch.empty((*shape, 3), dtype=torch.float32, device=dev)
+    depth_map = torch.empty(shape, dtype=torch.float32, device=dev)
+    mask = torch.empty(shape, dtype=torch.float32, device=dev)
+    extra_map = torch.empty((*shape, n_extra), dtype=torch.float32, device=dev) if n_extra else None
+    taps = {}
+    if want_taps:
+        taps = dict(weights=torch.empty((*shape, na + nb), dtype=torch.float32, device=dev),
+                    depth_sorted=torch.empty((*shape, na + nb), dtype=torch.float32, device=dev),
+                    perm=torch.empty((*shape, na + nb), dtype=torch.int64, device=dev))
+    with torch.cuda.device(dev):
+        _lib.call_struct('nfi_composite_fwd', 'nfi_composite_args', _stream(depth_a), n_rays=n, n_a=na, n_b=nb,
+                         ray_directions=rd, depth_a=depth_a, sigma_a=sigma_a, rgb_a=rgb_a, depth_b=depth_b,
+                         sigma_b=sigma_b, rgb_b=rgb_b, n_extra=n_extra, extra_a=extra_a, extra_b=extra_b,
+                         white_background=int(white_background), rgb_map=rgb_map, depth_map=depth_map, mask=mask,
+                         extra_map=extra_map, **taps)
+    return rgb_map, depth_map, mask, extra_map, taps
+
+
+# --------------------------------------------------------------------------- #
+TAP_NAMES = ('ray_origins', 'ray_directions', 'near_plane', 'far_plane', 'hit', 't_coarse', 'sigma_coarse',
+             'rgb_coarse', 't_fine', 'sigma_fine', 'rgb_fine', 't_sorted', 'weights', 'perm')
+
+
+def render_fwd(cam2world, focal, height, width, num_samples, texels, decoder_image, scene_range, n_attention,
+               attention_values=None, use_sdf=True, beta=None, alpha=None, bbox=None, center=None,
+               noise_coarse=None, noise_fine=None, fine_sampling=True, white_background=True, taps=(),
+               skip_missed_rays=True, workspace=None):
+    """Fused forward render.  Returns dict(rgb [B,H,W,3], depth, mask [B,H,W], + requested taps)."""
+    cam2world = _f32c(cam2world, 'tform_cam2world')
+    B = cam2world.shape[0]
+    dev = cam2world.device
+    n = B * height * width
+    S = num_samples
+    lib = _lib.load()
+    tdt = TEXEL_F32 if texels.dtype == torch.float32 else TEXEL_BF16
+    out = {'rgb': torch.empty((B, height, width, 3), dtype=torch.float32, device=dev),
+           'depth': torch.empty((B, height, width), dtype=torch.float32, device=dev),
+           'mask': torch.empty((B, height, width), dtype=torch.float32, device=dev)}
+    n2 = 2 * S if fine_sampling else S
+    shapes = {'ray_origins': ((B, height, width, 3), torch.float32), 'ray_directions': ((B, height, width, 3), torch.float32),
+              'near_plane': ((B, height, width), torch.float32), 'far_plane': ((B, height, width), torch.float32),
+              'hit': ((B, height, width), torch.uint8),
+              't_coarse': ((B, height, width, S), torch.float32), 'sigma_coarse': ((B, height, width, S), torch.float32),
+              'rgb_coarse': ((B, height, width, S, 3), torch.float32),
+              't_fine': ((B, height, width, S), torch.float32), 'sigma_fine': ((B, height, width, S), torch.float32),
+              'rgb_fine': ((B, height, width, S, 3), torch.float32),
+              't_sorted': ((B, height, width, n2), torch.float32), 'weights': ((B, height, width, n2), torch.float32),
+              'perm': ((B, height, width, n2), torch.int32)}
+    tap_t = {}
+    for name in taps:
+        if name not in shapes:
+            raise KeyError('unknown tap %s' % name)
+        if not fine_sampling and name in ('t_fine', 'sigma_fine', 'rgb_fine', 'perm'):
+            continue
+        shp, dt = shapes[name]
+        tap_t[name] = torch.zeros(shp, dtype=dt, device=dev)
+    ws_bytes = lib.nfi_render_workspace_bytes(n)
+    if workspace is None or workspace.numel() < ws_bytes:
+        workspace = torch.empty((ws_bytes,), dtype=torch.uint8, device=dev)
+    if fine_sampling:
+        if noise_fine is None:
+            noise_fine = torch.linspace(0.0, 1.0, steps=S, dtype=torch.float32, device=dev).expand(n, S)
+        u, ustride = _u_and_stride(noise_fine if noise_fine.dim() == 2 else noise_fine.reshape(-1, S), n, S)
+    else:
+        u, ustride = None, 0
+    with torch.cuda.device(dev):
+        _lib.call_struct(
+            'nfi_render_fwd', 'nfi_render_args', _stream(cam2world), n_scenes=B, height=height, width=width,
+            n_samples=S, fine_sampling=int(fine_sampling), white_background=int(white_background),
+            scene_range=float(scene_range), cam2world=cam2world, focal=_f32c(focal, 'focal_length'),
+            bbox=_f32c(bbox, 'bbox'), center=_f32c(center, 'center'), texels=texels, plane_res=texels.shape[2],
+            texel_dtype=tdt, decoder_image=decoder_image, n_attention=n_attention,
+            attention_values=_f32c(attention_values, 'attention_values') if n_attention > 0 else None,
+            use_sdf=int(use_sdf), beta=_f32c(beta, 'beta') if use_sdf else None,
+            alpha=_f32c(alpha, 'alpha') if use_sdf else None, noise_coarse=_f32c(noise_coarse, 'noise_coarse'),
+            noise_fine=u, noise_fine_row_stride=ustride, rgb=out['rgb'], depth=out['depth'], mask=out['mask'],
+            workspace=workspace, workspace_bytes=workspace.numel(), skip_missed_rays=int(skip_missed_rays), **tap_t)
+    out.update(tap_t)
+    out['_workspace'] = workspace
+    return out

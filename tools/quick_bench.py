@@ -1,0 +1,62 @@
+"""Quick timing of the fused render on synthetic shapenet_chairs-like inputs (GPU box)."""
+import os, sys, math, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+from nerf_from_image_amd import ops
+
+
+def cameras(n, radius, gen):
+    v = torch.randn(n, 3, generator=gen)
+    eye = radius * v / v.norm(dim=-1, keepdim=True)
+    fwd = -eye / eye.norm(dim=-1, keepdim=True)
+    up = torch.tensor([0., 0., 1.]).expand(n, 3)
+    right = torch.cross(fwd, up, dim=-1); right = right / right.norm(dim=-1, keepdim=True)
+    tup = torch.cross(right, fwd, dim=-1)
+    cam = torch.eye(4).repeat(n, 1, 1)
+    cam[:, :3, 0] = right; cam[:, :3, 1] = tup; cam[:, :3, 2] = -fwd; cam[:, :3, 3] = eye
+    return cam
+
+
+def main():
+    dev = torch.device('cuda:0')
+    g = torch.Generator().manual_seed(1234)
+    R, S, A = 128, 64, 10
+    for B, radius in ((1, 2.0), (8, 2.0), (8, 1.3)):
+        planes = torch.randn(B, 3, 32, 256, 256, generator=g).to(dev)
+        w1 = torch.randn(64, 32, generator=g).to(dev); b1 = torch.zeros(64, device=dev)
+        w2 = torch.randn(1 + A, 64, generator=g).to(dev); b2 = torch.zeros(1 + A, device=dev)
+        att = (torch.rand(B, A, 3, generator=g) * 2 - 1).to(dev)
+        beta = torch.tensor([0.1], device=dev); alpha = torch.tensor([0.05], device=dev)
+        cam = cameras(B, radius, g).to(dev); focal = torch.full((B,), 1.0254, device=dev)
+        n = B * R * R
+        noise_c = torch.rand(B, R, R, S, device=dev); noise_f = torch.rand(n, S, device=dev)
+        image = ops.decoder_pack(w1, b1, w2, b2, A)
+        texels = ops.planes_to_texels(planes)
+        ws = None
+        for skip in (True, False):
+            def step():
+                return ops.render_fwd(cam, focal, R, R, S, texels, image, 0.55, A, att, True, beta, alpha,
+                                      noise_coarse=noise_c, noise_fine=noise_f, skip_missed_rays=skip, workspace=ws)
+            for _ in range(3):
+                out = step(); ws = out['_workspace']
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            K = 20
+            e0.record()
+            for _ in range(K):
+                out = step()
+            e1.record(); torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1) / K
+            print('B=%d radius=%.1f skip=%d: %.3f ms/step  %.2f Mrays/s  mask mean %.3f rgb mean %.3f' % (
+                B, radius, skip, ms, n / ms / 1e3, out['mask'].mean().item(), out['rgb'].mean().item()))
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(10):
+            texels = ops.planes_to_texels(planes)
+        e1.record(); torch.cuda.synchronize()
+        print('   planes_to_texels: %.3f ms' % (e0.elapsed_time(e1) / 10))
+
+
+if __name__ == '__main__':
+    main()
