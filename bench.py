@@ -1,0 +1,226 @@
+"""Headline benchmark: rendered rays/s of the volumetric-rendering hot path (BASELINE.json cfg2).
+
+  python bench.py --gpus N --steps K --warmup W
+  (N>1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+One step = one pass of the hot path over one batch per GPU: triplane hand-off (NCHW -> channel-last
+texels), decoder operand packing, the reference's two torch.rand draws, ray set-up and the fused
+render of IMAGES_PER_GPU images at 128x128 with 64 coarse + 64 fine samples (fp32 planes, fp32
+arithmetic - the reference's precision).  Planes, decoder weights and cameras are synthetic and
+already resident in HBM.  Images are sharded across ranks (weak scaling, no collective on the render
+path: SURVEY.md section 8(e)).
+
+Printed JSON (rank 0, one line) carries, besides the contract fields:
+  roofline     - the fused render kernel: algorithmic gather bytes per launch (196 608 B per ray that
+                 is actually marched) / its live HIP-event duration, against HBM peak;
+                 traffic = measured HBM bytes per launch from profiles/ (rocprofv3 PMC) or null;
+  cpu_baseline - the oracle (CPU restatement of the reference, reference ATen numerics) timed on this
+                 box's host cores on ONE image of the same workload.
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+R, S, A, PLANE_RES = 128, 64, 10, 256
+IMAGES_PER_GPU = 8
+SCENE_RANGE, RADIUS, FOCAL = 0.55, 2.0, 1.0254      # shapenet_chairs-like
+GATHER_BYTES_PER_RAY = 196608                        # 128 points x 12 texels x 128 B
+HBM_PEAK_GBS = 8000.0
+MFMA_F32_PEAK_TFLOPS = 157.3
+MLP_FLOP_PER_RAY = 704512
+
+
+def cameras(n, radius, gen):
+    v = torch.randn(n, 3, generator=gen)
+    eye = radius * v / v.norm(dim=-1, keepdim=True)
+    fwd = -eye / eye.norm(dim=-1, keepdim=True)
+    up = torch.tensor([0., 0., 1.]).expand(n, 3)
+    right = torch.cross(fwd, up, dim=-1)
+    right = right / right.norm(dim=-1, keepdim=True)
+    tup = torch.cross(right, fwd, dim=-1)
+    cam = torch.eye(4).repeat(n, 1, 1)
+    cam[:, :3, 0] = right
+    cam[:, :3, 1] = tup
+    cam[:, :3, 2] = -fwd
+    cam[:, :3, 3] = eye
+    return cam
+
+
+def synthetic_inputs(n_images, seed, dev):
+    g = torch.Generator().manual_seed(seed)
+    low = torch.randn(n_images * 3, 32, 16, 16, generator=g)
+    planes = torch.nn.functional.interpolate(low, size=(PLANE_RES, PLANE_RES), mode='bilinear', align_corners=True)
+    planes = (planes + 0.2 * torch.randn(n_images * 3, 32, PLANE_RES, PLANE_RES, generator=g))
+    d = dict(planes=planes.view(n_images, 3, 32, PLANE_RES, PLANE_RES).contiguous(),
+             w1=torch.randn(64, 32, generator=g), b1=0.3 * torch.randn(64, generator=g),
+             w2=torch.randn(1 + A, 64, generator=g), b2=0.3 * torch.randn(1 + A, generator=g),
+             att=torch.rand(n_images, A, 3, generator=g) * 2 - 1, beta=torch.tensor([0.1]), alpha=torch.tensor([0.05]),
+             cam=cameras(n_images, RADIUS, g), focal=torch.full((n_images,), FOCAL))
+    # centre the decoder's distance output (sign change inside the cube => surfaces to render); done
+    # with a closed-form shift of b2[0] from a CPU probe of the first-layer statistics
+    feat = planes.view(n_images, 3, 32, -1).mean(dim=(1, 3))                 # mean plane feature per scene
+    hid = torch.nn.functional.softplus(feat.mean(0) @ (d['w1'] / 32 ** 0.5).t() + d['b1'])
+    d['b2'][0] -= float((hid @ (d['w2'][0] / 8.0)) + d['b2'][0])
+    return {k: v.to(dev) for k, v in d.items()}
+
+
+class HipEvents:
+    """Raw hipEvent pair (the render kernel is bracketed inside the C ABI call, on its stream)."""
+
+    def __init__(self):
+        self.hip = ctypes.CDLL('libamdhip64.so')
+        self.a, self.b = ctypes.c_void_p(), ctypes.c_void_p()
+        assert self.hip.hipEventCreate(ctypes.byref(self.a)) == 0
+        assert self.hip.hipEventCreate(ctypes.byref(self.b)) == 0
+
+    def pair(self):
+        return (self.a.value, self.b.value)
+
+    def elapsed_ms(self):
+        ms = ctypes.c_float()
+        self.hip.hipEventSynchronize(self.b)
+        assert self.hip.hipEventElapsedTime(ctypes.byref(ms), self.a, self.b) == 0
+        return ms.value
+
+
+def cpu_baseline(seed):
+    """Oracle (kind 'port': the CPU restatement pinned bit-exactly to the reference) on one image."""
+    from oracle import nfi_oracle as orc
+    d = synthetic_inputs(1, seed, 'cpu')
+    g = torch.Generator().manual_seed(seed + 1)
+    nc = torch.rand(1, R, R, S, generator=g)
+    nf = torch.rand(R * R, S, generator=g)
+    times = []
+    with torch.no_grad():
+        for i in range(4):
+            t0 = time.perf_counter()
+            orc.render(d['planes'], d['w1'], d['b1'], d['w2'], d['b2'], d['cam'], d['focal'], R, R, S, SCENE_RANGE,
+                       white_background=True, noise_coarse=nc, noise_fine=nf, use_sdf=True, beta=d['beta'],
+                       alpha=d['alpha'], attention_values=d['att'])
+            if i > 0:
+                times.append(time.perf_counter() - t0)
+    med = sorted(times)[len(times) // 2]
+    return {'value': R * R / med, 'unit': 'rays/s', 'cores': torch.get_num_threads(), 'kind': 'port',
+            'sample': '1 image 128x128, 64+64 samples, planes precomputed (render only), fp32, 1 warm-up + 3 timed runs, median'}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=50)
+    ap.add_argument('--warmup', type=int, default=10)
+    ap.add_argument('--images-per-gpu', type=int, default=IMAGES_PER_GPU)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-skip', action='store_true', help='march rays that miss the scene cube too')
+    args = ap.parse_args()
+
+    rank = int(os.environ.get('RANK', 0))
+    local_rank = int(os.environ.get('LOCAL_RANK', 0))
+    world = int(os.environ.get('WORLD_SIZE', 1))
+    if world != args.gpus:
+        raise SystemExit('--gpus %d but WORLD_SIZE=%d: launch N>1 with torch.distributed.run' % (args.gpus, world))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group('nccl', device_id=dev)
+
+    import __graft_entry__ as entry
+    entry.build()
+    from nerf_from_image_amd import ops
+
+    B = args.images_per_gpu
+    d = synthetic_inputs(B, 1234 + rank, dev)
+    n_rays = B * R * R
+    ev = HipEvents()
+    state = {'ws': None, 'kernel_ms': 0.0, 'kernel_n': 0}
+
+    def step(timed_kernel=False):
+        texels = ops.planes_to_texels(d['planes'])
+        image = ops.decoder_pack(d['w1'], d['b1'], d['w2'], d['b2'], A)
+        noise_c = torch.rand((B, R, R, S), dtype=torch.float32, device=dev)
+        noise_f = torch.rand([n_rays, S], dtype=torch.float32, device=dev)
+        out = ops.render_fwd(d['cam'], d['focal'], R, R, S, texels, image, SCENE_RANGE, A, d['att'], True, d['beta'],
+                             d['alpha'], noise_coarse=noise_c, noise_fine=noise_f, fine_sampling=True,
+                             white_background=True, skip_missed_rays=not args.no_skip, workspace=state['ws'],
+                             events=ev.pair() if timed_kernel else None, taps=('hit',) if timed_kernel == 'hit' else ())
+        state['ws'] = out['_workspace']
+        return out
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        out = step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # ---- dominant kernel, timed live with HIP events on its own stream (untimed extra launches) ----
+    k_ms = []
+    for _ in range(min(20, max(5, args.steps))):
+        step(timed_kernel=True)
+        k_ms.append(ev.elapsed_ms())
+    kernel_ms = sum(k_ms) / len(k_ms)
+    hit = step(timed_kernel='hit')['hit']
+    torch.cuda.synchronize()
+    marched = int(((hit & 2) != 0).sum().item()) if not args.no_skip else n_rays
+
+    if rank == 0:
+        value = world * n_rays * args.steps / elapsed
+        ach_gbs = marched * GATHER_BYTES_PER_RAY / (kernel_ms * 1e-3) / 1e9
+        traffic = None
+        pmc = os.path.join(ROOT, 'profiles', 'pmc_render_fwd.json')
+        if os.path.exists(pmc):
+            try:
+                traffic = json.load(open(pmc)).get('hbm_bytes_per_launch')
+            except Exception:
+                traffic = None
+        res = {
+            'metric': 'rendered rays/sec (128x128, 64+64 samples)', 'value': value, 'unit': 'rays/s',
+            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': elapsed / args.steps * 1e3,
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': 'cfg2: shapenet_chairs-like forward render, %d images/GPU, 128x128 rays/image, '
+                                   '64 coarse + 64 fine samples, 3x256x256x32 fp32 triplanes, SDF decoder, A=10; '
+                                   'step = texel hand-off + decoder pack + 2 rand draws + ray set-up + fused render'
+                                   % B,
+                       'images_per_gpu': B, 'resolution': R, 'samples': '64+64', 'plane_res': PLANE_RES,
+                       'camera_radius': RADIUS, 'scene_range': SCENE_RANGE, 'rays_marched_fraction': marched / n_rays,
+                       'skip_missed_rays': not args.no_skip, 'sharding': 'images across ranks, no collective'},
+            'roofline': {'bound': 'hbm', 'kernel': 'render_fwd_kernel', 'achieved': ach_gbs, 'peak': HBM_PEAK_GBS,
+                         'unit': 'GB/s', 'frac': ach_gbs / HBM_PEAK_GBS, 'traffic': traffic,
+                         'kernel_ms': kernel_ms, 'rays_marched_per_launch': marched,
+                         'note': 'algorithmic gather stream (196608 B per marched ray); it is served mostly by '
+                                 'L2/Infinity Cache, so frac > 1 is possible - see DESIGN.md'},
+            'roofline_mfma': {'bound': 'mfma', 'achieved': marched * MLP_FLOP_PER_RAY / (kernel_ms * 1e-3) / 1e12,
+                              'peak': MFMA_F32_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                              'frac': marched * MLP_FLOP_PER_RAY / (kernel_ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            res['cpu_baseline'] = cpu_baseline(1234)
+        else:
+            res['cpu_baseline'] = None
+        print(json.dumps(res))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -123,6 +123,10 @@ typedef struct nfi_stratified_args {
   float* points;               /* [N,S,3] out */
 } nfi_stratified_args;
 int nfi_stratified_points(const nfi_stratified_args* a, nfi_stream_t stream);
+/* x = o + d*t for given depths (the fine query points, run.py:286-288).
+ * ray_origins/ray_directions [N,3], depth [N,S] -> points [N,S,3] */
+int nfi_points_on_rays(const float* ray_origins, const float* ray_directions, const float* depth,
+                       int64_t n_rays, int n_samples, float* points, nfi_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Field query: the `sampler` closure of Generator.forward (models/generator.py:587-681) with
@@ -269,6 +273,12 @@ typedef struct nfi_render_args {
   /* 1: rays whose line misses the scene cube inflated by 1e-4 skip both passes (exact:
    * every sample of such a ray is outside the cube, sigma==0).  0: evaluate every ray. */
   int skip_missed_rays;
+  /* optional hipEvent_t pair recorded on the stream immediately before / after the render kernel
+   * (excludes the ray set-up launch): live per-launch kernel timing for bench.py.  NULL = off. */
+  void* event_start; void* event_stop;
+  /* tuning knob, 0 = default: bits 0-1 select the register/occupancy variant of the render kernel
+   * (1: 2, 2 or 0: 3, 3: 4 waves per SIMD).  Results do not depend on it. */
+  int tuning;
 } nfi_render_args;
 size_t nfi_render_workspace_bytes(int64_t n_rays);
 int nfi_render_fwd(const nfi_render_args* a, nfi_stream_t stream);

@@ -148,7 +148,7 @@ __device__ __forceinline__ void incl_cumsum(const float (&x)[SPL], float (&out)[
 
 // ||d||_2 as ATen's CPU norm kernel evaluates it for a 3-vector: an fma chain, then sqrt.
 __device__ __forceinline__ float norm3(float x, float y, float z) {
-  return __fsqrt_rn(fmaf(z, z, fmaf(y, y, x * x)));
+  return sqrtf(fmaf(z, z, fmaf(y, y, x * x)));  // sqrtf is correctly rounded; __fsqrt_rn lowers to a bare v_sqrt_f32 (1 ulp)
 }
 
 // torch.lerp(a, b, w) bit for bit (ATen: w < 0.5 ? a + w*(b-a) : b - (b-a)*(1-w), both fused)
@@ -259,7 +259,9 @@ struct FieldParams {
   int use_sdf;
   float inv_alpha;               // 1/alpha
   float beta;
-  const float* lds;              // LDS: decoder image + VF
+  const float* lds;              // LDS: decoder operand image (shared by the block)
+  const float* vf;               // LDS: this scene's attention values in accumulator layout [16 rows][4]
+  int ablate;                    // profiling only (tuning bits 4-5): 1 = no texel loads, 2 = no MFMA
 };
 
 // per-point gather set-up in sample layout: unnormalised, border-clamped plane coordinates.
@@ -328,10 +330,15 @@ __device__ __forceinline__ TileOut field_tile(const FieldParams& P, int lane, ui
     const uint32_t voff = (uint32_t)pl * P.plane_bytes + ((uint32_t)b0 * (uint32_t)P.res + (uint32_t)a0) * TB +
                           (uint32_t)g * GB;
     float t00[8], t10[8], t01[8], t11[8];
+    if (P.ablate & 1) {
+#pragma unroll
+      for (int s = 0; s < 8; ++s) { t00[s] = bits2f(0x3f000000u | (voff & 0xffff)); t10[s] = t00[s] * 0.5f; t01[s] = t00[s] * 0.25f; t11[s] = t00[s] * 0.125f; }
+    } else {
     load_texel8<TEX>(P, voff, 0, 0, t00);
     load_texel8<TEX>(P, voff, 0, TB, t10);
     load_texel8<TEX>(P, voff, P.row_bytes, 0, t01);
     load_texel8<TEX>(P, voff, P.row_bytes, TB, t11);
+    }
     const float ga = 1.0f - fa, gb = 1.0f - fb;
     const float w00 = ga * gb, w10 = fa * gb, w01 = ga * fb, w11 = fa * fb;
 #pragma unroll
@@ -347,6 +354,10 @@ __device__ __forceinline__ TileOut field_tile(const FieldParams& P, int lane, ui
 
   // ---- layer 1: H^T[64 x 16] = W1'[64 x 32] * F^T[32 x 16], bias pre-loaded, log2 domain ----
   const f32x4* ldsv = reinterpret_cast<const f32x4*>(P.lds);
+  f32x4 o;
+  if (P.ablate & 2) {
+    o.x = feat[0] + feat[4]; o.y = feat[1] + feat[5]; o.z = feat[2] + feat[6]; o.w = feat[3] + feat[7];
+  } else {
   f32x4 acc1[4];
 #pragma unroll
   for (int nt = 0; nt < 4; ++nt) acc1[nt] = ldsv[(kB1F >> 2) + g * 4 + nt];
@@ -380,7 +391,8 @@ __device__ __forceinline__ TileOut field_tile(const FieldParams& P, int lane, ui
     o0 = __builtin_amdgcn_mfma_f32_16x16x4f32(w.z, acc1[nt][2], o0, 0, 0, 0);
     o1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w.w, acc1[nt][3], o1, 0, 0, 0);
   }
-  f32x4 o = o0 + o1;  // lane (j,g): outputs 4g..4g+3 of point j; output 0 = sdf/density, 1.. = features*log2e
+  o = o0 + o1;  // lane (j,g): outputs 4g..4g+3 of point j; output 0 = sdf/density, 1.. = features*log2e
+  }
 
   TileOut res;
   const int j = lane & 15;
@@ -408,7 +420,7 @@ __device__ __forceinline__ TileOut field_tile(const FieldParams& P, int lane, ui
     }
     m = fmaxf(m, __shfl_xor(m, 16, 64));
     m = fmaxf(m, __shfl_xor(m, 32, 64));
-    const f32x4* vf = ldsv + (kVF >> 2) + g * 4;
+    const f32x4* vf = reinterpret_cast<const f32x4*>(P.vf) + g * 4;
     float se = 0.0f, sr = 0.0f, sg = 0.0f, sb = 0.0f;
     float e4[4];
 #pragma unroll
@@ -449,11 +461,12 @@ struct SampleOut {
 };
 
 // Field query for the (up to) 64 points a wave holds one per lane.  px,py,pz: WORLD coordinates;
-// valid: lane holds a point.  Tiles whose 16 points are all outside the cube (or invalid) are
-// skipped: sigma is exactly 0 there (the reference multiplies by (1-mask), generator.py:633),
-// rgb is reported as 0 (its weight is exactly 0).
+// valid: lane holds a point.  SKIP (fused renderer): tiles whose 16 points are all outside the cube
+// (or invalid) are skipped: sigma is exactly 0 there (the reference multiplies by (1-mask),
+// generator.py:633) and rgb is reported as 0 (its compositing weight is exactly 0).  Without SKIP
+// (the sampler closure) outside points get the border-clamped colour/distance the reference returns.
 // sem_base: null or global pointer to this wave's [64][A] semantics rows.
-template <int TEX, bool ATT>
+template <int TEX, bool ATT, bool SKIP>
 __device__ __forceinline__ SampleOut field_wave(const FieldParams& P, float scene_range, int lane, float px, float py,
                                                 float pz, bool valid, float* sem_base, bool* outside_flag) {
   // sem_base rows are written only for valid points (rows past the end of the array do not exist)
@@ -469,7 +482,7 @@ __device__ __forceinline__ SampleOut field_wave(const FieldParams& P, float scen
   if (!valid) { x0 = y0 = z0 = 0; fx = fy = fz = 0.0f; }  // keep NaN/garbage out of the address math
   uint32_t xi = (uint32_t)x0 | ((uint32_t)y0 << 10) | ((uint32_t)z0 << 20);
   float outf = out ? 1.0f : 0.0f;
-  uint64_t live = __ballot(valid && !out);
+  uint64_t live = SKIP ? __ballot(valid && !out) : __ballot(valid);
 
   SampleOut so;
   so.sdf = 0.0f; so.sigma = 0.0f; so.r = 0.0f; so.g = 0.0f; so.b = 0.0f;

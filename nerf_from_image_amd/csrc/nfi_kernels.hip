@@ -333,6 +333,27 @@ __global__ __launch_bounds__(256) void stratified_kernel(nfi_stratified_args a) 
   }
 }
 
+__global__ __launch_bounds__(256) void points_on_rays_kernel(const float* __restrict__ ro, const float* __restrict__ rd,
+                                                             const float* __restrict__ depth, int64_t total, int S,
+                                                             float* __restrict__ points) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  const int64_t ray = idx / S;
+  const float t = depth[idx];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) points[idx * 3 + c] = ro[ray * 3 + c] + rd[ray * 3 + c] * t;
+}
+
+extern "C" int nfi_points_on_rays(const float* ray_origins, const float* ray_directions, const float* depth,
+                                  int64_t n_rays, int n_samples, float* points, nfi_stream_t stream) {
+  REQUIRE(ray_origins && ray_directions && depth && points, "points_on_rays: null pointer");
+  REQUIRE(n_rays > 0 && n_samples > 0, "points_on_rays: bad shape");
+  int64_t total = n_rays * n_samples;
+  hipLaunchKernelGGL(points_on_rays_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     ray_origins, ray_directions, depth, total, n_samples, points);
+  return check_launch("points_on_rays");
+}
+
 extern "C" int nfi_stratified_points(const nfi_stratified_args* a, nfi_stream_t stream) {
   REQUIRE(a && a->ray_origins && a->ray_directions && a->near_plane && a->far_plane && a->depth, "stratified: null pointer");
   REQUIRE(a->n_rays > 0 && a->n_samples > 0, "stratified: bad shape");
@@ -377,6 +398,8 @@ __device__ __forceinline__ FieldParams make_field_params(const void* texels_scen
   P.inv_alpha = use_sdf ? 1.0f / alpha[0] : 1.0f;
   P.beta = use_sdf ? beta[0] : 1.0f;
   P.lds = lds;
+  P.vf = lds + kVF;
+  P.ablate = 0;
   return P;
 }
 
@@ -400,7 +423,7 @@ __global__ __launch_bounds__(256) void field_query_kernel(FieldKernelParams k) {
     if (valid) { px = k.points[gi * 3]; py = k.points[gi * 3 + 1]; pz = k.points[gi * 3 + 2]; }
     bool out;
     float* sem = k.sem ? k.sem + ((size_t)scene * k.P + chunk * 64) * k.A : nullptr;
-    SampleOut so = field_wave<TEX, ATT>(P, k.scene_range, lane, px, py, pz, valid, sem, &out);
+    SampleOut so = field_wave<TEX, ATT, false>(P, k.scene_range, lane, px, py, pz, valid, sem, &out);
     if (valid) {
       k.sigma[gi] = so.sigma;
       k.rgb[gi * 3] = so.r; k.rgb[gi * 3 + 1] = so.g; k.rgb[gi * 3 + 2] = so.b;
@@ -805,6 +828,7 @@ struct RenderKernelParams {
   // ray set-up results
   const float* ro; const float* rd; const float* near_raw; const float* far_raw; const uint8_t* hit;
   const uint32_t* reduce;
+  uint32_t* counter;   // work counter (zeroed with reduce[])
   // field
   const void* texels; int res;
   const float* image; int A; const float* att;
@@ -819,38 +843,67 @@ struct RenderKernelParams {
   float* t_fine; float* sigma_fine; float* rgb_fine;
   float* t_sorted; float* weights; int32_t* perm;
   int skip_missed;
+  int ablate;
 };
 
-template <int TEX, bool ATT>
-__global__ __launch_bounds__(256) void render_fwd_kernel(RenderKernelParams k) {
-  __shared__ __attribute__((aligned(16))) float lds[kFieldLdsFloats];
+// Persistent kernel: one wave per ray, rays handed out by one device-scope counter (scene-major,
+// so the chip works on one scene's 25 MB of texels at a time), next index prefetched while the
+// current ray is marched.  OCC = waves per SIMD the register budget is held to.
+template <int TEX, bool ATT, int OCC>
+__global__ __launch_bounds__(256, OCC) void render_fwd_kernel(RenderKernelParams k) {
+  __shared__ __attribute__((aligned(16))) float lds[kImageFloats];
+  __shared__ __attribute__((aligned(16))) float vfs[4][64];
   __shared__ WaveSlab slabs[4];
-  const int scene = blockIdx.y;
-  stage_field_lds(lds, k.image, k.att ? k.att + (size_t)scene * k.A * 3 : nullptr, k.A);
+  for (int i = threadIdx.x; i < kImageFloats; i += blockDim.x) lds[i] = k.image[i];
   __syncthreads();
-  const size_t tb = TEX == 0 ? 128 : 64;
-  const char* tex_scene = reinterpret_cast<const char*>(k.texels) + (size_t)scene * 3 * k.res * k.res * tb;
-  FieldParams P = make_field_params(tex_scene, k.res, TEX, k.A, k.use_sdf, k.beta, k.alpha, lds);
   const int lane = lane_id();
   const int wave = threadIdx.x >> 6;
   WaveSlab& slab = slabs[wave];
+  float* vf = vfs[wave];
   const int S = k.S;
   const float fill_near = ordered_key_inv(~k.reduce[0]), fill_far = ordered_key_inv(k.reduce[1]);
   const float bg = k.white ? 1.0f : 0.0f;
+  const size_t tb = TEX == 0 ? 128 : 64;
+  const uint32_t n_rays = (uint32_t)k.n_scenes * (uint32_t)k.hw;
+  uint32_t* counter = k.counter;
 
-  for (int pix = blockIdx.x * 4 + wave; pix < k.hw; pix += gridDim.x * 4) {
-    const int64_t ray = (int64_t)scene * k.hw + pix;
+  FieldParams P = make_field_params(k.texels, k.res, TEX, k.A, k.use_sdf, k.beta, k.alpha, lds);
+  P.vf = vf;
+  P.ablate = k.ablate;
+  int cur_scene = -1;
+
+  uint32_t next = 0;
+  if (lane == 0) next = atomicAdd(counter, 1u);
+  next = (uint32_t)__builtin_amdgcn_readfirstlane((int)next);
+  while (next < n_rays) {
+    const uint32_t ray = next;
+    if (lane == 0) next = atomicAdd(counter, 1u);          // prefetch the following ray index
     const uint8_t hitb = k.hit[ray];
     if (k.skip_missed && !(hitb & 2)) {
       // the ray's line stays outside the (inflated) scene cube: every sample has sigma == 0
       if (lane == 0) {
-        k.rgb[ray * 3] = bg; k.rgb[ray * 3 + 1] = bg; k.rgb[ray * 3 + 2] = bg;
+        k.rgb[(size_t)ray * 3] = bg; k.rgb[(size_t)ray * 3 + 1] = bg; k.rgb[(size_t)ray * 3 + 2] = bg;
         k.depth[ray] = 0.0f; k.mask[ray] = 0.0f;
       }
+      next = (uint32_t)__builtin_amdgcn_readfirstlane((int)next);
       continue;
     }
-    const float ox = k.ro[ray * 3], oy = k.ro[ray * 3 + 1], oz = k.ro[ray * 3 + 2];
-    const float dx = k.rd[ray * 3], dy = k.rd[ray * 3 + 1], dz = k.rd[ray * 3 + 2];
+    const int scene = (int)(ray / (uint32_t)k.hw);
+    if (scene != cur_scene) {
+      cur_scene = scene;
+      const char* tex_scene = reinterpret_cast<const char*>(k.texels) + (size_t)scene * 3 * k.res * k.res * tb;
+      P.rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(tex_scene), 0, (int)(3u * P.plane_bytes), 0x00020000);
+      wave_lds_fence();
+      {
+        int c = lane & 3, row = lane >> 2;
+        float v = 0.0f;
+        if (k.att && c < 3 && row >= 1 && row <= k.A) v = k.att[((size_t)scene * k.A + (row - 1)) * 3 + c];
+        vf[lane] = v;
+      }
+      wave_lds_fence();
+    }
+    const float ox = k.ro[(size_t)ray * 3], oy = k.ro[(size_t)ray * 3 + 1], oz = k.ro[(size_t)ray * 3 + 2];
+    const float dx = k.rd[(size_t)ray * 3], dy = k.rd[(size_t)ray * 3 + 1], dz = k.rd[(size_t)ray * 3 + 2];
     float near = k.near_raw[ray], far = k.far_raw[ray];
     finish_planes((hitb & 1) != 0, fill_near, fill_far, near, far);
     if (lane == 0) {
@@ -859,16 +912,17 @@ __global__ __launch_bounds__(256) void render_fwd_kernel(RenderKernelParams k) {
     }
     const bool valid = lane < S;
     const float dnorm = norm3(dx, dy, dz);
+    const size_t rs = (size_t)ray * S;
 
     // ---- coarse pass ----
     float tc = 0.0f;
-    if (valid) tc = stratified_depth(near, far, lane, S, k.noise_c ? k.noise_c[ray * S + lane] : 0.0f, k.noise_c != nullptr);
+    if (valid) tc = stratified_depth(near, far, lane, S, k.noise_c ? k.noise_c[rs + lane] : 0.0f, k.noise_c != nullptr);
     float px = ox + dx * tc, py = oy + dy * tc, pz = oz + dz * tc;
-    SampleOut c = field_wave<TEX, ATT>(P, k.scene_range, lane, px, py, pz, valid, nullptr, nullptr);
+    SampleOut c = field_wave<TEX, ATT, true>(P, k.scene_range, lane, px, py, pz, valid, nullptr, nullptr);
     if (valid) {
-      if (k.t_coarse) k.t_coarse[ray * S + lane] = tc;
-      if (k.sigma_coarse) k.sigma_coarse[ray * S + lane] = c.sigma;
-      if (k.rgb_coarse) { float* q = k.rgb_coarse + (ray * S + lane) * 3; q[0] = c.r; q[1] = c.g; q[2] = c.b; }
+      if (k.t_coarse) k.t_coarse[rs + lane] = tc;
+      if (k.sigma_coarse) k.sigma_coarse[rs + lane] = c.sigma;
+      if (k.rgb_coarse) { float* q = k.rgb_coarse + (rs + lane) * 3; q[0] = c.r; q[1] = c.g; q[2] = c.b; }
     }
 
     int n = S;
@@ -876,28 +930,26 @@ __global__ __launch_bounds__(256) void render_fwd_kernel(RenderKernelParams k) {
     int rank[2] = {lane, 64 + lane};
     if (k.fine) {
       // ---- hierarchical resampling + fine pass ----
-      float u = valid ? k.noise_f[ray * k.noise_f_stride + lane] : 0.0f;
+      float u = valid ? k.noise_f[(size_t)ray * k.noise_f_stride + lane] : 0.0f;
       float tf = resample_ray(slab, c.sigma, tc, S, dnorm, u, lane, nullptr);
       float fx = ox + dx * tf, fy = oy + dy * tf, fz = oz + dz * tf;
-      SampleOut f = field_wave<TEX, ATT>(P, k.scene_range, lane, fx, fy, fz, valid, nullptr, nullptr);
+      SampleOut f = field_wave<TEX, ATT, true>(P, k.scene_range, lane, fx, fy, fz, valid, nullptr, nullptr);
       if (valid) {
-        if (k.t_fine) k.t_fine[ray * S + lane] = tf;
-        if (k.sigma_fine) k.sigma_fine[ray * S + lane] = f.sigma;
-        if (k.rgb_fine) { float* q = k.rgb_fine + (ray * S + lane) * 3; q[0] = f.r; q[1] = f.g; q[2] = f.b; }
+        if (k.t_fine) k.t_fine[rs + lane] = tf;
+        if (k.sigma_fine) k.sigma_fine[rs + lane] = f.sigma;
+        if (k.rgb_fine) { float* q = k.rgb_fine + (rs + lane) * 3; q[0] = f.r; q[1] = f.g; q[2] = f.b; }
       }
       n = 2 * S;
-      // element e of cat(coarse, fine): e < S coarse, else fine.  With S < 64 both halves sit in
-      // slot 0/1 differently, so build the (slot, lane) view explicitly.
+      // element e of cat(coarse, fine): e < S coarse, else fine; build the (slot, lane) view
       if (S == 64) {
         dep[1] = tf; sig[1] = f.sigma; cr[1] = f.r; cg[1] = f.g; cb[1] = f.b;
       } else {
-        // lanes [S, 2S) of slot 0 take the fine sample of lane-S; slot 1 takes the rest
-        int src = lane - S;
-        float tf0 = __shfl(tf, src & 63, 64), sf0 = __shfl(f.sigma, src & 63, 64);
-        float rf0 = __shfl(f.r, src & 63, 64), gf0 = __shfl(f.g, src & 63, 64), bf0 = __shfl(f.b, src & 63, 64);
-        int src1 = 64 + lane - S;   // element 64+lane -> fine index 64+lane-S
-        float tf1 = __shfl(tf, src1 & 63, 64), sf1 = __shfl(f.sigma, src1 & 63, 64);
-        float rf1 = __shfl(f.r, src1 & 63, 64), gf1 = __shfl(f.g, src1 & 63, 64), bf1 = __shfl(f.b, src1 & 63, 64);
+        int src = (lane - S) & 63;          // slot 0, lanes [S, 64): fine sample lane-S
+        float tf0 = __shfl(tf, src, 64), sf0 = __shfl(f.sigma, src, 64);
+        float rf0 = __shfl(f.r, src, 64), gf0 = __shfl(f.g, src, 64), bf0 = __shfl(f.b, src, 64);
+        int src1 = (64 + lane - S) & 63;    // slot 1: element 64+lane -> fine sample 64+lane-S
+        float tf1 = __shfl(tf, src1, 64), sf1 = __shfl(f.sigma, src1, 64);
+        float rf1 = __shfl(f.r, src1, 64), gf1 = __shfl(f.g, src1, 64), bf1 = __shfl(f.b, src1, 64);
         if (lane >= S) { dep[0] = tf0; sig[0] = sf0; cr[0] = rf0; cg[0] = gf0; cb[0] = bf0; }
         dep[1] = tf1; sig[1] = sf1; cr[1] = rf1; cg[1] = gf1; cb[1] = bf1;
       }
@@ -913,19 +965,20 @@ __global__ __launch_bounds__(256) void render_fwd_kernel(RenderKernelParams k) {
     float w[2];
     CompositeOut o = composite_slab(slab, n, dnorm, k.white, lane, w);
     if (lane == 0) {
-      k.rgb[ray * 3] = o.r; k.rgb[ray * 3 + 1] = o.g; k.rgb[ray * 3 + 2] = o.b;
+      k.rgb[(size_t)ray * 3] = o.r; k.rgb[(size_t)ray * 3 + 1] = o.g; k.rgb[(size_t)ray * 3 + 2] = o.b;
       k.depth[ray] = o.depth; k.mask[ray] = o.mask;
     }
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       int e = j * 64 + lane;
       if (e < n) {
-        if (k.weights) k.weights[ray * n + e] = w[j];
-        if (k.t_sorted) k.t_sorted[ray * n + e] = slab.srt[0][e];
-        if (k.perm) k.perm[ray * n + rank[j]] = e;
+        if (k.weights) k.weights[(size_t)ray * n + e] = w[j];
+        if (k.t_sorted) k.t_sorted[(size_t)ray * n + e] = slab.srt[0][e];
+        if (k.perm) k.perm[(size_t)ray * n + rank[j]] = e;
       }
     }
     wave_lds_fence();  // slab is reused by the next ray
+    next = (uint32_t)__builtin_amdgcn_readfirstlane((int)next);
   }
 }
 
@@ -978,18 +1031,29 @@ extern "C" int nfi_render_fwd(const nfi_render_args* a, nfi_stream_t stream) {
   k.t_sorted = a->t_sorted; k.weights = a->weights; k.perm = a->perm;
   k.skip_missed = (a->skip_missed_rays && !any_tap) ? 1 : 0;
 
-  int blocks_x = (k.hw + 3) / 4;
-  int cap = 4096 / a->n_scenes;            // persistent grid: a few blocks per CU in total
-  if (cap < 64) cap = 64;
-  if (blocks_x > cap) blocks_x = cap;
-  dim3 grid((unsigned)blocks_x, (unsigned)a->n_scenes);
+  k.counter = reduce + 3;
+  k.ablate = (a->tuning >> 4) & 3;
+  // persistent 1-D grid: OCC blocks of 4 waves per CU, never more blocks than rays need
+  int occ = a->tuning & 3;               // 0 = default
+  if (occ == 0) occ = 3;
+  if (occ == 1) occ = 2;
+  int64_t blocks = (int64_t)256 * occ;
+  if (blocks > (n + 3) / 4) blocks = (n + 3) / 4;
+  dim3 grid((unsigned)blocks);
   bool att = a->n_attention > 0;
+  if (a->event_start) (void)hipEventRecord((hipEvent_t)a->event_start, s);
+#define NFI_LAUNCH_RENDER(TEX, ATT)                                                                        \
+  do {                                                                                                     \
+    if (occ == 2) hipLaunchKernelGGL((render_fwd_kernel<TEX, ATT, 2>), grid, dim3(256), 0, s, k);          \
+    else if (occ == 3) hipLaunchKernelGGL((render_fwd_kernel<TEX, ATT, 3>), grid, dim3(256), 0, s, k);     \
+    else hipLaunchKernelGGL((render_fwd_kernel<TEX, ATT, 4>), grid, dim3(256), 0, s, k);                   \
+  } while (0)
   if (a->texel_dtype == NFI_TEXEL_F32) {
-    if (att) hipLaunchKernelGGL((render_fwd_kernel<0, true>), grid, dim3(256), 0, s, k);
-    else hipLaunchKernelGGL((render_fwd_kernel<0, false>), grid, dim3(256), 0, s, k);
+    if (att) NFI_LAUNCH_RENDER(0, true); else NFI_LAUNCH_RENDER(0, false);
   } else {
-    if (att) hipLaunchKernelGGL((render_fwd_kernel<1, true>), grid, dim3(256), 0, s, k);
-    else hipLaunchKernelGGL((render_fwd_kernel<1, false>), grid, dim3(256), 0, s, k);
+    if (att) NFI_LAUNCH_RENDER(1, true); else NFI_LAUNCH_RENDER(1, false);
   }
+#undef NFI_LAUNCH_RENDER
+  if (a->event_stop) (void)hipEventRecord((hipEvent_t)a->event_stop, s);
   return check_launch("render_fwd");
 }

@@ -1,0 +1,202 @@
+"""The radiance-field side of the reference's ``models/generator.py`` on HIP kernels.
+
+What is replaced: the ``sampler`` closure that ``Generator.forward`` returns
+(models/generator.py:587-681), i.e. TriplanarDecoder.forward (301-331: three bilinear plane
+gathers, mean, Linear(32,64)-Softplus-Linear(64,1+A) with equalized-lr gains,
+models/stylegan.py:173-180), the SDF->density conversion (laplace_cdf 30-33, 629-636) or the
+softplus density (637-641), and the colour head (661-679).
+
+What is NOT replaced: the plane producer (mapping network, StyleGAN2 synthesis network,
+AttentionMapper) stays the reference's own PyTorch modules; ``hip_forward`` calls them exactly
+where ``Generator.forward`` does (407-503) and hands their output to the kernels.  So a reference
+``Generator`` instance keeps its parameters, ``state_dict`` keys and attributes and only gets a new
+``forward``:
+
+    from models.generator import Generator            # the reference's class
+    import nerf_from_image_amd.generator as nfi_gen
+    model = nfi_gen.attach(Generator(512, scene_range, attention_values=10, use_sdf=True))
+
+Any module with the attributes listed in ``REQUIRED_ATTRS`` works the same way (the GPU-box tests
+use a stand-in plane producer, the reference checkout is not available there).
+"""
+import math
+import types
+
+import torch
+
+from . import ops
+from .autograd import differentiable
+
+REQUIRED_ATTRS = ('scene_range', 'attention_values', 'use_sdf', 'use_viewdir', 'use_encoder', 'num_classes',
+                  'mapping_network', 'synthesis_network', 'decoder')
+
+_MODEL_OUTPUTS = ('sampler', 'sdf_eikonal_loss', 'sdf_distance_loss', 'path_length', 'total_variation_loss',
+                  'entropy_loss', 'attention_values', 'bbox')
+_MODEL_INPUTS = ('freeze_noise', 'attention_values', 'attention_values_bias')
+_SAMPLER_OUTPUTS = ('sdf_distance', 'sigma', 'rgb', 'normals', 'semantics', 'coords')
+
+
+class FusedField:
+    """Everything the fused renderer needs about one batch of scenes (``sampler.fused``)."""
+
+    def __init__(self, texels, decoder_image, attention_values, n_attention, use_sdf, beta, alpha, scene_range,
+                 planes=None, decoder_params=None):
+        self.texels = texels                    # [B,3,R,R,32] channel-last
+        self.decoder_image = decoder_image      # MFMA operand image of the decoder
+        self.attention_values = attention_values
+        self.n_attention = n_attention
+        self.use_sdf = use_sdf
+        self.beta = beta
+        self.alpha = alpha
+        self.scene_range = scene_range
+        self.planes = planes                    # autograd handles (None in inference)
+        self.decoder_params = decoder_params
+
+    @property
+    def requires_grad(self):
+        ts = [self.planes, self.attention_values, self.beta, self.alpha] + list(self.decoder_params or ())
+        return torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in ts)
+
+
+def decoder_parameters(decoder):
+    """(w1, b1, w2, b2) of a TriplanarDecoder-shaped module: decoder.net[0] / decoder.net[2]."""
+    l0, l2 = decoder.net[0], decoder.net[2]
+    return l0.weight, l0.bias, l2.weight, l2.bias
+
+
+def make_sampler(planes, decoder, scene_range, n_attention, attention_values, use_sdf, beta, alpha,
+                 texel_dtype=ops.TEXEL_F32, request_model_outputs=()):
+    """Builds the ``sampler(x_in, request_sampler_outputs)`` closure over HIP kernels.
+
+    planes [B,3,32,R,R] (view of the synthesis output), decoder: module with .net[0]/.net[2]."""
+    w1, b1, w2, b2 = decoder_parameters(decoder)
+    texels = ops.planes_to_texels(planes.detach(), texel_dtype)
+    image = ops.decoder_pack(w1.detach(), b1.detach(), w2.detach(), b2.detach(), n_attention, texel_dtype)
+    fused = FusedField(texels, image, attention_values, n_attention, use_sdf, beta, alpha, scene_range,
+                       planes=planes, decoder_params=(w1, b1, w2, b2))
+
+    def sampler(x_in, request_sampler_outputs=['sigma', 'rgb']):
+        for output in request_sampler_outputs:
+            assert output in _SAMPLER_OUTPUTS
+        if 'normals' in request_sampler_outputs:
+            raise NotImplementedError('sampler: analytic normals are not implemented on the HIP path yet')
+        bs = x_in.shape[0]
+        pts = x_in.reshape(bs, -1, 3)
+        want_sem = 'semantics' in request_sampler_outputs
+        if want_sem:
+            assert n_attention > 0
+        want_sdf = 'sdf_distance' in request_sampler_outputs
+
+        def fwd(p, pl, a_w1, a_b1, a_w2, a_b2, att, be, al):
+            q = ops.field_query(p, texels, image, scene_range, n_attention, att, use_sdf, be, al,
+                                want_sdf=want_sdf, want_semantics=want_sem)
+            return tuple(q[k] for k in ('sigma', 'rgb') + (('sdf',) if want_sdf else ()) +
+                         (('semantics',) if want_sem else ()))
+        res = differentiable('field_query', fwd, pts, planes, w1, b1, w2, b2,
+                             attention_values if n_attention > 0 else None,
+                             beta if use_sdf else None, alpha if use_sdf else None)
+        out = {}
+        i = 2
+        if want_sdf:
+            out['sdf_distance'] = res[i].unsqueeze(-1)
+            i += 1
+        if 'sigma' in request_sampler_outputs:
+            out['sigma'] = res[0]
+        if 'coords' in request_sampler_outputs:
+            out['coords'] = x_in
+            if 'bbox' in request_model_outputs:
+                raise NotImplementedError("sampler: the 'bbox' visualisation overlay is not implemented")
+        if want_sem:
+            out['semantics'] = res[i]
+        if 'rgb' in request_sampler_outputs:
+            out['rgb'] = res[1]
+        return out
+
+    sampler.fused = fused
+    return sampler
+
+
+def hip_forward(self, viewdir, c, request_model_outputs=['sampler'], model_inputs={}):
+    """Replacement for Generator.forward (models/generator.py:407-686): same arguments, same
+    returned dict; the plane producer is called as in the reference, the field is HIP."""
+    for output in request_model_outputs:
+        assert output in _MODEL_OUTPUTS
+    for k in model_inputs.keys():
+        assert k in _MODEL_INPUTS
+    for reg in ('sdf_eikonal_loss', 'sdf_distance_loss', 'total_variation_loss', 'entropy_loss'):
+        if reg in request_model_outputs:
+            raise NotImplementedError('%s (regulariser branch, generator.py:505-585) is outside the HIP hot path' % reg)
+    if self.use_viewdir:
+        raise NotImplementedError('use_viewdir (ViewDirectionMapper, carla only) is not implemented on the HIP path')
+
+    # ---- latent handling (generator.py:423-446) ----
+    label = None
+    if self.use_encoder:
+        z, image = c
+        ws = self.mapping_network(z, self.emb(image))
+        batch = z.shape[0]
+    else:
+        if self.num_classes:
+            if isinstance(c, (list, tuple)):
+                c, label_idx = c
+                assert c.dim() == 2
+                label = self.class_embedding(label_idx)
+            else:
+                assert c.dim() == 3
+        batch = c.shape[0]
+        if c.dim() == 3:
+            num_ws = self.mapping_network.backbone.num_ws
+            ws = c.expand(-1, num_ws, -1).contiguous() if c.shape[1] == 1 else c
+        else:
+            ws = self.mapping_network(c, label)
+    if 'path_length' in request_model_outputs:
+        assert torch.is_grad_enabled()
+        ws = ws.contiguous().requires_grad_()
+
+    # ---- colour table + planes (generator.py:448-477) ----
+    attention_values = None
+    if self.attention_values > 0:
+        assert ws.shape[1] == 15
+        w_tex, w_syn = ws[:, 14], ws[:, :14]
+        if 'attention_values' in model_inputs:
+            attention_values = model_inputs['attention_values']
+        elif 'sampler' in request_model_outputs:
+            attention_values = self.texture_mapper(w_tex)
+            if 'attention_values_bias' in model_inputs:
+                attention_values = attention_values + model_inputs['attention_values_bias']
+    else:
+        w_syn = ws
+    kwargs = {'noise_mode': 'const'} if model_inputs.get('freeze_noise') else {}
+    planes = self.synthesis_network(w_syn, **kwargs)
+    planes = planes.view(batch, 3, 32, planes.shape[-2], planes.shape[-1])
+
+    model_outputs = {}
+    if 'attention_values' in request_model_outputs:
+        assert self.attention_values > 0
+        model_outputs['attention_values'] = attention_values
+    if 'path_length' in request_model_outputs:
+        # path-length regulariser of the plane producer (generator.py:484-499); lives on the
+        # producer side of the hand-off, plain autograd through the synthesis network
+        scale = 1.0 / math.sqrt(planes.shape[-2] * planes.shape[-1])
+        target = (planes * (torch.randn_like(planes) * scale)).sum()
+        if self.attention_values > 0:
+            target = target + (attention_values * torch.randn_like(attention_values)).sum()
+        grad, = torch.autograd.grad(target, inputs=ws, create_graph=True)
+        model_outputs['path_length'] = grad.square().sum(dim=-1).mean(dim=-1).sqrt()
+
+    if 'sampler' in request_model_outputs:
+        model_outputs['sampler'] = make_sampler(
+            planes, self.decoder, self.scene_range, self.attention_values, attention_values, self.use_sdf,
+            self.beta if self.use_sdf else None, self.alpha if self.use_sdf else None,
+            texel_dtype=getattr(self, 'nfi_texel_dtype', ops.TEXEL_F32), request_model_outputs=request_model_outputs)
+    return model_outputs
+
+
+def attach(model, texel_dtype=ops.TEXEL_F32):
+    """Gives a reference-style Generator the HIP forward.  Returns the same module."""
+    missing = [a for a in REQUIRED_ATTRS if not hasattr(model, a)]
+    if missing:
+        raise AttributeError('attach(): module lacks %s' % missing)
+    model.nfi_texel_dtype = texel_dtype
+    model.forward = types.MethodType(hip_forward, model)
+    return model

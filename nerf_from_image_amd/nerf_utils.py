@@ -1,0 +1,153 @@
+"""Drop-in for the reference's ``lib/nerf_utils.py`` (same names, same positional/keyword
+arguments, same shapes), every function running as HIP kernels through the C ABI.
+
+Reference lines: cumprod_exclusive 20-25, get_ray_bundle 28-91, compute_query_points_from_rays
+94-120, render_volume_density 123-161, render_volume_density_weights_only 164-180, sample_pdf
+183-222, compute_near_far_planes 225-273 (all in lib/nerf_utils.py).
+
+Randomness: like the reference, ``compute_query_points_from_rays(randomize=True)`` draws
+``torch.rand`` of shape [..., S] and ``sample_pdf(deterministic=False)`` draws ``torch.rand([N, K])``
+on the rays' device (same shapes and order, hence the same Philox stream as the reference's
+PyTorch-ROCm run); the noise is then handed to the kernels.
+"""
+from typing import Optional
+
+import torch
+
+from . import ops
+from .autograd import differentiable
+
+
+def cumprod_exclusive(tensor: torch.Tensor) -> torch.Tensor:
+    """tf.math.cumprod(..., exclusive=True) along the last dim.  Kept for API completeness only:
+    nothing in this package calls it (the running transmittance lives inside the weights and
+    compositing kernels), so it is the one helper left as a plain tensor expression."""
+    ones = torch.ones_like(tensor[..., :1])
+    return torch.cat((ones, torch.cumprod(tensor[..., :-1], dim=-1)), dim=-1)
+
+
+def get_ray_bundle(height: int, width: int, focal_length: Optional[torch.Tensor], tform_cam2world: torch.Tensor,
+                   bbox: Optional[torch.Tensor], center: Optional[torch.Tensor] = None):
+    """Returns (ray_origins, ray_directions), each [B,H,W,3]; directions are NOT normalised
+    (the caller normalises, run.py:196).  focal_length=None selects the orthographic model."""
+    def fwd(cam, focal, bb, cen):
+        return ops.raygen(height, width, focal, cam, bb, cen, normalize=False)
+    return differentiable('get_ray_bundle', fwd, tform_cam2world, focal_length, bbox, center)
+
+
+def get_ray_bundle_normalized(height: int, width: int, focal_length: Optional[torch.Tensor],
+                              tform_cam2world: torch.Tensor, bbox: Optional[torch.Tensor],
+                              center: Optional[torch.Tensor] = None):
+    """get_ray_bundle followed by F.normalize(ray_directions, dim=-1) (run.py:193-196) in one launch."""
+    def fwd(cam, focal, bb, cen):
+        return ops.raygen(height, width, focal, cam, bb, cen, normalize=True)
+    return differentiable('get_ray_bundle_normalized', fwd, tform_cam2world, focal_length, bbox, center)
+
+
+def points_on_rays(ray_origins: torch.Tensor, ray_directions: torch.Tensor, depth_values: torch.Tensor):
+    """ray_origins[..., None, :] + ray_directions[..., None, :] * depth[..., :, None] (run.py:286-288)."""
+    def fwd(ro, rd):
+        return ops.points_on_rays(ro, rd, depth_values.detach())
+    return differentiable('points_on_rays', fwd, ray_origins, ray_directions)
+
+
+def compute_near_far_planes(ray_origins: torch.Tensor, ray_directions: torch.Tensor, scene_range: float):
+    """Slab test against [-scene_range, scene_range]^3 with the reference's miss-fill, clamps and
+    its failure when no ray hits.  No gradient (the reference detaches its inputs)."""
+    near, far, _ = ops.near_far(ray_origins.detach(), ray_directions.detach(), scene_range, strict=True)
+    return near, far
+
+
+def compute_query_points_from_rays(ray_origins: torch.Tensor, ray_directions: torch.Tensor, near_thresh: torch.Tensor,
+                                   far_thresh: torch.Tensor, num_samples: int, randomize: bool = True):
+    """Returns (query_points [...,S,3], depth_values [...,S])."""
+    if near_thresh.dim() != ray_origins.dim() - 1:
+        raise NotImplementedError('per-batch scalar near/far planes are not used by run.py::render and not supported')
+    noise = torch.rand((*near_thresh.shape, num_samples), dtype=torch.float32, device=near_thresh.device) \
+        if randomize else None
+
+    def fwd(ro, rd):
+        return ops.stratified_points(ro, rd, near_thresh.detach(), far_thresh.detach(), num_samples, noise)
+    return differentiable('compute_query_points_from_rays', fwd, ray_origins, ray_directions)
+
+
+def render_volume_density_weights_only(sigma_a: torch.Tensor, ray_origins: torch.Tensor, ray_directions: torch.Tensor,
+                                       depth_values: torch.Tensor) -> torch.Tensor:
+    def fwd(sig, rd, dep):
+        return ops.ray_weights(sig, rd, dep)
+    return differentiable('render_volume_density_weights_only', fwd, sigma_a, ray_directions, depth_values)
+
+
+def sample_pdf(bins, weights, num_samples: int, deterministic: bool = False) -> torch.Tensor:
+    """bins [N,M], weights [N,M-1] -> samples [N,num_samples] (no gradient is defined through the
+    index search; the reference calls it under no_grad, run.py:261)."""
+    n = bins.shape[0]
+    if deterministic:
+        u = torch.linspace(0.0, 1.0, steps=num_samples, dtype=weights.dtype, device=weights.device)
+        u = u.expand(n, num_samples)
+    else:
+        u = torch.rand([n, num_samples], dtype=weights.dtype, device=weights.device)
+    samples, _, _ = ops.sample_pdf(bins.detach(), weights.detach(), u)
+    return samples
+
+
+def render_volume_density(sigma_a: torch.Tensor, rgb: torch.Tensor, ray_origins: torch.Tensor,
+                          ray_directions: torch.Tensor, depth_values: torch.Tensor,
+                          normals: Optional[torch.Tensor] = None, semantics: Optional[torch.Tensor] = None,
+                          white_background: bool = True):
+    """Returns (rgb_map, depth_map, mask, normal_map, semantic_map)."""
+    extras = [t for t in (normals, semantics) if t is not None]
+    n_norm = normals.shape[-1] if normals is not None else 0
+
+    def fwd(sig, col, rd, dep, *ex):
+        extra = torch.cat(ex, dim=-1) if len(ex) > 1 else (ex[0] if ex else None)
+        rgb_map, depth_map, mask, extra_map, _ = ops.composite(rd, dep, sig, col, extra_a=extra,
+                                                               white_background=white_background)
+        return (rgb_map, depth_map, mask) + ((extra_map,) if extra_map is not None else ())
+    out = differentiable('render_volume_density', fwd, sigma_a, rgb, ray_directions, depth_values, *extras,
+                         non_differentiable_outputs=(1,))
+    rgb_map, depth_map, mask = out[0], out[1], out[2]
+    normal_map = semantic_map = None
+    if extras:
+        extra_map = out[3]
+        if normals is not None:
+            normal_map = extra_map[..., :n_norm]
+            if white_background:
+                normal_map = normal_map + (1. - mask[..., None])
+        if semantics is not None:
+            semantic_map = extra_map[..., n_norm:]
+    return rgb_map, depth_map, mask, normal_map, semantic_map
+
+
+def merge_and_composite(ray_directions, depth_a, sigma_a, rgb_a, depth_b, sigma_b, rgb_b, normals_a=None,
+                        normals_b=None, extra_a=None, extra_b=None, white_background=True):
+    """The sort/merge of run.py:283-335 fused with render_volume_density: the coarse (a) and fine (b)
+    sample lists are merged by depth inside the kernel (stable, a first on ties) and composited.
+    Returns (rgb_map, depth_map, mask, normal_map, extra_map)."""
+    ex_a = [t for t in (normals_a, extra_a) if t is not None]
+    ex_b = [t for t in (normals_b, extra_b) if t is not None]
+    n_norm = normals_a.shape[-1] if normals_a is not None else 0
+    n_ex = len(ex_a)
+
+    def fwd(rd, sa, ca, sb, cb, *ex):
+        ea = eb = None
+        if n_ex:
+            ea = torch.cat(ex[:n_ex], dim=-1) if n_ex > 1 else ex[0]
+            eb = torch.cat(ex[n_ex:], dim=-1) if n_ex > 1 else ex[n_ex]
+        rgb_map, depth_map, mask, extra_map, _ = ops.composite(
+            rd, depth_a.detach(), sa, ca, depth_b.detach(), sb, cb, extra_a=ea, extra_b=eb,
+            white_background=white_background)
+        return (rgb_map, depth_map, mask) + ((extra_map,) if extra_map is not None else ())
+    out = differentiable('merge_and_composite', fwd, ray_directions, sigma_a, rgb_a, sigma_b, rgb_b, *ex_a, *ex_b,
+                         non_differentiable_outputs=(1,))
+    rgb_map, depth_map, mask = out[0], out[1], out[2]
+    normal_map = extra_map = None
+    if n_ex:
+        em = out[3]
+        if normals_a is not None:
+            normal_map = em[..., :n_norm]
+            if white_background:
+                normal_map = normal_map + (1. - mask[..., None])
+        if extra_a is not None:
+            extra_map = em[..., n_norm:]
+    return rgb_map, depth_map, mask, normal_map, extra_map

@@ -122,6 +122,18 @@ def stratified_points(ray_origins, ray_directions, near, far, num_samples, noise
     return points, depth
 
 
+def points_on_rays(ray_origins, ray_directions, depth):
+    ro, rd, depth = _f32c(ray_origins, 'ray_origins'), _f32c(ray_directions, 'ray_directions'), _f32c(depth, 'depth')
+    S = depth.shape[-1]
+    n = depth.numel() // S
+    points = torch.empty((*depth.shape, 3), dtype=torch.float32, device=depth.device)
+    lib = _lib.load()
+    with torch.cuda.device(depth.device):
+        _lib.check(lib.nfi_points_on_rays(_lib.ptr(ro), _lib.ptr(rd), _lib.ptr(depth), n, S, _lib.ptr(points),
+                                          _stream(depth)), 'nfi_points_on_rays')
+    return points
+
+
 # --------------------------------------------------------------------------- #
 def field_query(points, texels, decoder_image, scene_range, n_attention, attention_values=None, use_sdf=True,
                 beta=None, alpha=None, want_sdf=False, want_semantics=False, want_outside=False):
@@ -247,7 +259,7 @@ TAP_NAMES = ('ray_origins', 'ray_directions', 'near_plane', 'far_plane', 'hit', 
 def render_fwd(cam2world, focal, height, width, num_samples, texels, decoder_image, scene_range, n_attention,
                attention_values=None, use_sdf=True, beta=None, alpha=None, bbox=None, center=None,
                noise_coarse=None, noise_fine=None, fine_sampling=True, white_background=True, taps=(),
-               skip_missed_rays=True, workspace=None):
+               skip_missed_rays=True, workspace=None, events=None, tuning=0):
     """Fused forward render.  Returns dict(rgb [B,H,W,3], depth, mask [B,H,W], + requested taps)."""
     cam2world = _f32c(cam2world, 'tform_cam2world')
     B = cam2world.shape[0]
@@ -297,7 +309,9 @@ def render_fwd(cam2world, focal, height, width, num_samples, texels, decoder_ima
             use_sdf=int(use_sdf), beta=_f32c(beta, 'beta') if use_sdf else None,
             alpha=_f32c(alpha, 'alpha') if use_sdf else None, noise_coarse=_f32c(noise_coarse, 'noise_coarse'),
             noise_fine=u, noise_fine_row_stride=ustride, rgb=out['rgb'], depth=out['depth'], mask=out['mask'],
-            workspace=workspace, workspace_bytes=workspace.numel(), skip_missed_rays=int(skip_missed_rays), **tap_t)
+            workspace=workspace, workspace_bytes=workspace.numel(), skip_missed_rays=int(skip_missed_rays),
+            event_start=None if events is None else events[0], event_stop=None if events is None else events[1],
+            tuning=int(tuning), **tap_t)
     out.update(tap_t)
     out['_workspace'] = workspace
     return out

@@ -1,0 +1,78 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library builds for gfx950, loads, exports
+every symbol include/nfi_hip.h declares, and rejects bad arguments without touching a GPU."""
+import ctypes
+import os
+import re
+import subprocess
+
+import pytest
+import torch
+
+from nerf_from_image_amd import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope='module')
+def lib():
+    import __graft_entry__ as g
+    g.build()
+    return _lib.load()
+
+
+def test_header_declares_the_expected_entry_points():
+    src = open(_lib.HEADER).read()
+    declared = set(re.findall(r'\b(nfi_[a-z_0-9]+)\s*\(', src))
+    assert declared == set(_lib.FUNCTIONS), declared ^ set(_lib.FUNCTIONS)
+    for name in ('nfi_render_fwd', 'nfi_field_query_fwd', 'nfi_raygen', 'nfi_near_far', 'nfi_sample_pdf',
+                 'nfi_composite_fwd', 'nfi_planes_to_texels', 'nfi_decoder_pack'):
+        assert name in declared
+
+
+def test_library_exports_every_declared_symbol(lib):
+    for name in _lib.FUNCTIONS:
+        assert hasattr(lib, name), name
+    assert lib.nfi_version() >= 100
+    assert lib.nfi_decoder_image_floats() == 3152
+    # 8 floats + 1 byte per ray + reduce words
+    assert lib.nfi_render_workspace_bytes(16384) >= 16384 * 33
+
+
+def test_library_contains_gfx950_code_objects_only(lib):
+    blob = open(_lib.LIBRARY, 'rb').read()
+    targets = set(re.findall(rb'amdgcn-amd-amdhsa--(gfx[0-9a-z]+)', blob))
+    assert targets == {b'gfx950'}, targets
+
+
+def test_struct_layout_matches_header():
+    # spot checks: field order and the natural-alignment size ctypes derives from the parsed header
+    f = [n for n, _ in _lib.STRUCT_FIELDS['nfi_render_args']]
+    assert f[:4] == ['n_scenes', 'height', 'width', 'n_samples'] and f[-1] == 'tuning'
+    assert ctypes.sizeof(_lib.STRUCTS['nfi_sample_pdf_args']) == 8 + 4 + 4 + 3 * 8 + 8 + 3 * 8
+    for name, st in _lib.STRUCTS.items():
+        assert ctypes.sizeof(st) % 8 == 0 or ctypes.sizeof(st) % 4 == 0, name
+
+
+def test_bad_arguments_are_rejected_before_any_launch(lib):
+    rc = lib.nfi_decoder_pack(None, None, None, None, 10, 0, None, None)
+    assert rc == -1 and b'null' in lib.nfi_last_error()
+    rc = lib.nfi_planes_to_texels(ctypes.c_void_p(16), ctypes.c_void_p(16), 1, 4096, 0, None)
+    assert rc == -1 and b'plane_res' in lib.nfi_last_error()
+    a = _lib.make_args('nfi_render_args', n_scenes=1, height=4, width=4, n_samples=200, cam2world=16, rgb=16, depth=16,
+                       mask=16, workspace=16)
+    rc = lib.nfi_render_fwd(ctypes.byref(a), None)
+    assert rc == -1 and b'n_samples' in lib.nfi_last_error()
+    a = _lib.make_args('nfi_composite_args', n_rays=4, n_a=100, n_b=100, ray_directions=16, depth_a=16, sigma_a=16,
+                       rgb_a=16, rgb_map=16, depth_map=16, mask=16)
+    assert lib.nfi_composite_fwd(ctypes.byref(a), None) == -1
+
+
+def test_product_path_has_no_cpu_fallback():
+    from nerf_from_image_amd import ops
+    with pytest.raises(RuntimeError, match='GPU'):
+        ops.planes_to_texels(torch.zeros(1, 3, 32, 4, 4))
+    # nothing under the package may import the oracle
+    pkg = os.path.join(ROOT, 'nerf_from_image_amd')
+    for fn in os.listdir(pkg):
+        if fn.endswith('.py'):
+            assert 'oracle' not in open(os.path.join(pkg, fn)).read().replace('no oracle', ''), fn

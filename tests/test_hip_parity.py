@@ -1,0 +1,204 @@
+"""GPU parity tests: every HIP stage and the fused renderer against the oracle, through the C ABI.
+
+Tolerances (fp32):
+  * indices / masks / permutations: bit-exact on identical float inputs;
+  * elementwise stages that ATen evaluates op by op (near/far, stratified depths, query points,
+    smoothing): bit-exact on identical inputs;
+  * rendered rgb / depth / mask and per-sample rgb: 1e-4 absolute (north star);
+  * sigma: 1e-4 * max(1, 1/alpha) absolute - sigma = laplace_cdf(-d/beta)/alpha amplifies the
+    decoder's 1e-7-level rounding differences by up to 0.5/(alpha*beta); the reference's own
+    CPU-vs-GPU difference is of the same size (see tools/gpu_diag.py output in DESIGN.md).
+"""
+import pytest
+import torch
+
+from conftest import golden_case_names, load_golden
+from parity_util import err, hip_field_setup, hip_render, oracle_render
+from nerf_from_image_amd import ops
+from oracle import nfi_oracle as orc
+
+pytestmark = pytest.mark.gpu
+ATOL = 1e-4
+
+
+def sigma_tol(meta, t):
+    return ATOL * max(1.0, 1.0 / float(t['alpha'])) if meta['sdf'] else ATOL
+
+
+@pytest.fixture(scope='module', params=golden_case_names())
+def case(request, gpu_device):
+    meta, t = load_golden(request.param)
+    o = oracle_render(meta, t, 'cpu')
+    return request.param, meta, t, o, gpu_device
+
+
+def close(a, b, tol, what):
+    e = err(a, b)
+    assert e['nonfinite'] == 0 and e['max'] <= tol, (what, e)
+
+
+def exact(a, b, what):
+    a, b = a.detach().cpu(), b.detach().cpu()
+    assert a.shape == b.shape and torch.equal(a, b), (what, err(a.float(), b.float()))
+
+
+def test_texel_layout_roundtrip(gpu_device):
+    g = torch.Generator().manual_seed(3)
+    planes = torch.randn(2, 3, 32, 20, 20, generator=g).to(gpu_device)
+    tex = ops.planes_to_texels(planes)
+    exact(tex, planes.permute(0, 1, 3, 4, 2).contiguous(), 'texels')
+    exact(ops.texels_to_planes(tex), planes, 'roundtrip')
+    tb = ops.planes_to_texels(planes, ops.TEXEL_BF16)
+    exact(tb, planes.permute(0, 1, 3, 4, 2).contiguous().to(torch.bfloat16), 'bf16 texels')
+
+
+def test_rays_and_planes(case):
+    name, meta, t, o, dev = case
+    g = lambda k: t[k].to(dev) if k in t else None
+    ro, rd = ops.raygen(meta['H'], meta['W'], g('focal'), g('cam2world'), g('bbox'), None, normalize=True)
+    exact(ro, o['ro'], 'ray origins')
+    close(rd, o['rd'], 2e-7, 'ray directions')          # <= 1 ulp
+    ro_r, rd_r = ops.raygen(meta['H'], meta['W'], g('focal'), g('cam2world'), g('bbox'), None, normalize=False)
+    ro_o, rd_o = orc.ray_bundle(meta['H'], meta['W'], t.get('focal'), t['cam2world'], t.get('bbox'))
+    close(rd_r, rd_o, 2e-7, 'raw directions')
+    near, far, hit = ops.near_far(o['ro'].contiguous().to(dev), o['rd'].to(dev), meta['scene_range'])
+    exact(near, o['near'], 'near'); exact(far, o['far'], 'far'); exact(hit, o['hit'], 'hit')
+    pts, dep = ops.stratified_points(o['ro'].contiguous().to(dev), o['rd'].to(dev), o['near'].to(dev), o['far'].to(dev),
+                                     meta['S'], g('noise_coarse'))
+    exact(dep, o['t_coarse'], 'stratified depths')
+    exact(pts, orc.points_on_rays(o['ro'], o['rd'], o['t_coarse']), 'query points')
+
+
+def test_no_ray_hits_raises(gpu_device):
+    ro = torch.tensor([[5., 5., 5.]] * 70, device=gpu_device)
+    rd = torch.tensor([[0., 0., 1.]] * 70, device=gpu_device)
+    with pytest.raises(RuntimeError):
+        ops.near_far(ro, rd, 0.5)
+
+
+def test_field_query(case):
+    name, meta, t, o, dev = case
+    g = lambda k: t[k].to(dev) if k in t else None
+    texels, image = hip_field_setup(meta, t, dev)
+    B = meta['B']
+    x = orc.points_on_rays(o['ro'], o['rd'], o['t_coarse']).reshape(B, -1, 3)
+    q = ops.field_query(x.to(dev), texels, image, meta['scene_range'], meta['A'], g('attention_values'), meta['sdf'],
+                        g('beta'), g('alpha'), want_sdf=True, want_semantics=meta['A'] > 0, want_outside=True)
+    exact(q['outside'].float(), o['outside_coarse'].reshape(B, -1), 'outside mask')
+    close(q['sdf'], o['sdf_coarse'].reshape(B, -1), 1e-5, 'sdf')
+    close(q['sigma'], o['sigma_coarse'].reshape(B, -1), sigma_tol(meta, t), 'sigma')
+    close(q['rgb'], o['rgb_coarse'].reshape(B, -1, 3), ATOL, 'rgb')
+    if meta['A'] > 0:
+        ref = orc.field_query(t['planes'], t['w1'], t['b1'], t['w2'], t['b2'], x, meta['scene_range'], meta['sdf'],
+                              t.get('beta'), t.get('alpha'), t['attention_values'])
+        close(q['semantics'], ref['semantics'], 1e-5, 'semantics')
+
+
+def test_field_query_ragged_and_far_points(gpu_device):
+    """P not a multiple of 64, points far outside the cube and exactly on its faces."""
+    dev = gpu_device
+    meta, t = load_golden('persp_white_fine_rand')
+    texels, image = hip_field_setup(meta, t, dev)
+    g = torch.Generator().manual_seed(11)
+    r = meta['scene_range']
+    x = (torch.rand(2, 77, 3, generator=g) * 2 - 1) * r * 1.5
+    x[0, :3] = torch.tensor([[r, -r, r], [r, 0.0, 0.0], [-r, -r, -r]])
+    x[1, 5] = torch.tensor([1e6, -1e6, 3.0])
+    q = ops.field_query(x.to(dev), texels, image, r, meta['A'], t['attention_values'].to(dev), True,
+                        t['beta'].to(dev), t['alpha'].to(dev), want_sdf=True, want_outside=True)
+    ref = orc.field_query(t['planes'], t['w1'], t['b1'], t['w2'], t['b2'], x, r, True, t['beta'], t['alpha'],
+                          t['attention_values'])
+    exact(q['outside'].float(), ref['outside'], 'outside mask')
+    close(q['sigma'], ref['sigma'], sigma_tol(meta, t), 'sigma')
+    close(q['rgb'], ref['rgb'], ATOL, 'rgb')
+    close(q['sdf'], ref['sdf'], 1e-5, 'sdf')
+
+
+def test_sampling_stages(case):
+    name, meta, t, o, dev = case
+    if not meta['fine']:
+        pytest.skip('no fine sampling in this case')
+    S = meta['S']
+    n = o['weights_coarse'].shape[0]
+    w = ops.ray_weights(o['sigma_coarse'].to(dev), o['rd'].to(dev), o['t_coarse'].to(dev))
+    close(w.flatten(0, 2), o['weights_coarse'], 1e-6, 'coarse weights')
+    u = t['noise_fine'].to(dev) if 'noise_fine' in t else orc.deterministic_u(n, S, o['weights_coarse']).to(dev)
+    fine, taps = ops.resample(o['sigma_coarse'].to(dev), o['rd'].to(dev), o['t_coarse'].to(dev), u, want_taps=True)
+    close(taps['smooth'], o['weights_smooth'], 1e-6, 'smoothed weights')
+    close(taps['cdf'], o['cdf'], 1e-6, 'cdf')
+    # indices: bit-exact against searchsorted on the kernel's own cdf (identical float inputs) ...
+    exact(taps['inds'], torch.searchsorted(taps['cdf'].contiguous(), u.contiguous(), right=True), 'searchsorted indices')
+    # ... and within the flip budget against the reference end to end
+    flips = (taps['inds'].cpu() != o['inds']).float().mean().item()
+    assert flips <= 1e-3, flips
+    close(fine, o['t_fine'].flatten(0, 2), 1e-5, 'fine depths')
+    # stand-alone sample_pdf on the oracle's exact inputs
+    mid = (.5 * (o['t_coarse'][..., 1:] + o['t_coarse'][..., :-1])).flatten(0, 2)
+    smp, inds, cdf = ops.sample_pdf(mid.to(dev), o['weights_smooth'][..., 1:-1].contiguous().to(dev), u, True, True)
+    exact(inds, torch.searchsorted(cdf.contiguous(), u.contiguous(), right=True), 'sample_pdf indices')
+    close(smp, o['t_fine'].flatten(0, 2), 1e-5, 'sample_pdf samples')
+
+
+def test_merge_and_composite(case):
+    name, meta, t, o, dev = case
+    d = lambda k: o[k].to(dev)
+    if meta['fine']:
+        rgb, dep, msk, _, taps = ops.composite(d('rd'), d('t_coarse'), d('sigma_coarse'), d('rgb_coarse'), d('t_fine'),
+                                               d('sigma_fine'), d('rgb_fine'), white_background=meta['white'],
+                                               want_taps=True)
+        exact(taps['depth_sorted'], o['t_sorted'], 'sorted depths')
+        ties = (o['t_sorted'][..., 1:] == o['t_sorted'][..., :-1]).any(-1)
+        exact(taps['perm'].cpu()[~ties], o['perm'][~ties], 'sort permutation (tie-free rays)')
+    else:
+        rgb, dep, msk, _, taps = ops.composite(d('rd'), d('t_coarse'), d('sigma_coarse'), d('rgb_coarse'),
+                                               white_background=meta['white'], want_taps=True)
+    close(taps['weights'], o['weights'], 1e-6, 'weights')
+    close(rgb, o['rgb'], 1e-5, 'rgb map'); close(dep, o['depth'], 1e-5, 'depth map'); close(msk, o['mask'], 1e-5, 'mask')
+
+
+def test_composite_extra_attribute(gpu_device):
+    """semantics compositing through the extra-attribute slot, against the oracle."""
+    meta, t = load_golden('persp_white_fine_rand')
+    o = oracle_render(meta, t, 'cpu')
+    dev = gpu_device
+    B, S, A = meta['B'], meta['S'], meta['A']
+    x_c = orc.points_on_rays(o['ro'], o['rd'], o['t_coarse'])
+    x_f = orc.points_on_rays(o['ro'], o['rd'], o['t_fine'])
+    f = lambda x: orc.field_query(t['planes'], t['w1'], t['b1'], t['w2'], t['b2'], x, meta['scene_range'], True, t['beta'],
+                                  t['alpha'], t['attention_values'])['semantics'].view(*x.shape[:-1], A)
+    sem_c, sem_f = f(x_c), f(x_f)
+    d = lambda k: o[k].to(dev)
+    _, _, _, sem_map, _ = ops.composite(d('rd'), d('t_coarse'), d('sigma_coarse'), d('rgb_coarse'), d('t_fine'),
+                                        d('sigma_fine'), d('rgb_fine'), extra_a=sem_c.to(dev), extra_b=sem_f.to(dev),
+                                        white_background=True)
+    close(sem_map, t['ref_semantics'], 1e-5, 'semantic map')
+
+
+def test_fused_render(case):
+    name, meta, t, o, dev = case
+    r = hip_render(meta, t, dev, taps=ops.TAP_NAMES)
+    for k in ('rgb', 'depth', 'mask'):
+        close(r[k], o[k], ATOL, 'fused ' + k)
+        close(r[k], t['ref_' + k], ATOL, 'fused %s vs committed reference output' % k)
+    close(r['t_coarse'], o['t_coarse'], 1e-5, 't_coarse')
+    close(r['sigma_coarse'], o['sigma_coarse'], sigma_tol(meta, t), 'sigma_coarse')
+    exact((r['hit'] & 1).bool(), o['hit'], 'hit mask')
+    if meta['fine']:
+        close(r['t_fine'], o['t_fine'], 1e-4, 't_fine')
+        close(r['t_sorted'], o['t_sorted'], 1e-4, 't_sorted')
+        mism = (r['perm'].cpu().long() != o['perm']).float().mean().item()
+        assert mism <= 5e-3, ('sort permutation flip budget', mism)
+    # skipping rays that miss the cube is exact
+    r2 = hip_render(meta, t, dev, skip_missed_rays=True)
+    for k in ('rgb', 'depth', 'mask'):
+        exact(r2[k], r[k], 'skip_missed_rays ' + k)
+
+
+def test_fused_render_bf16_texels(case):
+    """bf16 plane storage (BASELINE config 2 variant): parity against the fp32 reference at the
+    tolerance bf16 rounding of the planes allows."""
+    name, meta, t, o, dev = case
+    r = hip_render(meta, t, dev, texel_dtype=ops.TEXEL_BF16)
+    close(r['mask'], o['mask'], 0.08, 'bf16 mask')
+    close(r['rgb'], o['rgb'], 0.08, 'bf16 rgb')
+    assert err(r['rgb'], o['rgb'])['mean'] < 5e-3

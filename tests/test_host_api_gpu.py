@@ -1,0 +1,164 @@
+"""The reference-shaped host API (Generator.forward -> sampler closure, run.py::render,
+lib/nerf_utils.py functions) on the GPU, against the oracle fed with the same noise."""
+import types
+
+import pytest
+import torch
+
+from parity_util import err
+from stand_in import StandInGenerator, look_at_cameras
+import nerf_from_image_amd.generator as nfi_gen
+import nerf_from_image_amd.nerf_utils as nu
+import nerf_from_image_amd.render as nfi_render
+from oracle import nfi_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+def close(a, b, tol, what):
+    e = err(a, b)
+    assert e['nonfinite'] == 0 and e['max'] <= tol, (what, e)
+
+
+class RandTap:
+    """Records torch.rand draws made on the GPU so the CPU oracle can replay them."""
+
+    def __enter__(self):
+        self.draws = []
+        self._rand = torch.rand
+
+        def rand(*a, **k):
+            out = self._rand(*a, **k)
+            self.draws.append(out.detach().cpu())
+            return out
+        torch.rand = rand
+        return self
+
+    def __exit__(self, *a):
+        torch.rand = self._rand
+
+
+@pytest.fixture(scope='module')
+def setup(gpu_device):
+    torch.manual_seed(1234)
+    model = StandInGenerator(0.55, attention_values=10, use_sdf=True, plane_res=48).to(gpu_device).eval()
+    nfi_gen.attach(model)
+    g = torch.Generator().manual_seed(9)
+    B = 2
+    cam = look_at_cameras(B, 1.6, g).to(gpu_device)
+    focal = torch.full((B,), 1.0254, device=gpu_device)
+    z = torch.randn(B, 512, generator=g).to(gpu_device)
+    return model, cam, focal, z
+
+
+def oracle_for(model, z, cam, focal, H, W, S, cfg, dcfg, draws, bbox=None, want_semantics=False):
+    with torch.no_grad():
+        planes, att = model.planes_and_values(z)
+        dec = model.decoder.net
+        cpu = lambda t: None if t is None else t.detach().cpu()
+        return orc.render(cpu(planes), cpu(dec[0].weight), cpu(dec[0].bias), cpu(dec[2].weight), cpu(dec[2].bias),
+                          cpu(cam), cpu(focal), H, W, S, dcfg['scene_range'], white_background=dcfg['white_background'],
+                          fine_sampling=cfg.fine_sampling, bbox=cpu(bbox),
+                          noise_coarse=draws[0] if draws else None,
+                          noise_fine=draws[1] if len(draws) > 1 else None, use_sdf=True, beta=cpu(model.beta),
+                          alpha=cpu(model.alpha), attention_values=cpu(att), want_semantics=want_semantics)
+
+
+def test_sampler_closure_matches_reference_semantics(setup):
+    model, cam, focal, z = setup
+    with torch.no_grad():
+        out = model(None, z, ['sampler', 'attention_values'])
+        sampler = out['sampler']
+        g = torch.Generator().manual_seed(2)
+        x = ((torch.rand(2, 5, 6, 7, 3, generator=g) * 2 - 1) * 0.7).to(cam.device)
+        res = sampler(x, ['sigma', 'rgb', 'semantics', 'sdf_distance', 'coords'])
+        planes, att = model.planes_and_values(z)
+        dec = model.decoder.net
+        ref = orc.field_query(planes.cpu(), dec[0].weight.cpu(), dec[0].bias.cpu(), dec[2].weight.cpu(),
+                              dec[2].bias.cpu(), x.cpu(), 0.55, True, model.beta.cpu(), model.alpha.cpu(), att.cpu())
+    assert res['sigma'].shape == (2, 5 * 6 * 7) and res['rgb'].shape == (2, 210, 3)
+    assert res['semantics'].shape == (2, 210, 10) and res['sdf_distance'].shape == (2, 210, 1)
+    assert res['coords'] is x
+    close(out['attention_values'], att, 0, 'attention_values passthrough')
+    close(res['sigma'], ref['sigma'], 1e-4 / 0.05, 'sigma')
+    close(res['rgb'], ref['rgb'], 1e-4, 'rgb')
+    close(res['semantics'], ref['semantics'], 1e-5, 'semantics')
+    close(res['sdf_distance'][..., 0], ref['sdf'], 1e-5, 'sdf')
+
+
+@pytest.mark.parametrize('fine,randomize,white', [(True, True, True), (True, False, False), (False, True, True)])
+def test_render_dropin_fused(setup, fine, randomize, white):
+    model, cam, focal, z = setup
+    cfg = types.SimpleNamespace(use_viewdir=False, use_sdf=True, attention_values=10, fine_sampling=fine)
+    dcfg = {'scene_range': 0.55, 'white_background': white}
+    nfi_render.configure(cfg, dcfg)
+    H = W = 24
+    S = 32
+    with torch.no_grad(), RandTap() as tap:
+        rgb, depth, mask, normals, sem, extra = nfi_render.render(model, H, W, cam, focal, None, None, z, S,
+                                                                  randomize=randomize)
+    assert normals is None and sem is None and extra == {}
+    assert rgb.shape == (2, H, W, 3) and depth.shape == (2, H, W) and mask.shape == (2, H, W)
+    if randomize:
+        assert tuple(tap.draws[0].shape) == (2, H, W, S)
+        if fine:
+            assert tuple(tap.draws[1].shape) == (2 * H * W, S)
+    o = oracle_for(model, z, cam, focal, H, W, S, cfg, dcfg, tap.draws)
+    close(rgb, o['rgb'], 1e-4, 'rgb'); close(depth, o['depth'], 1e-4, 'depth'); close(mask, o['mask'], 1e-4, 'mask')
+
+
+def test_render_dropin_staged_semantics(setup):
+    """compute_semantics forces the staged path (one launch per stage through nerf_utils)."""
+    model, cam, focal, z = setup
+    cfg = types.SimpleNamespace(use_viewdir=False, use_sdf=True, attention_values=10, fine_sampling=True)
+    dcfg = {'scene_range': 0.55, 'white_background': True}
+    render = nfi_render.make_render(cfg, dcfg)
+    H, W, S = 20, 28, 32
+    with torch.no_grad(), RandTap() as tap:
+        rgb, depth, mask, normals, sem, _ = render(model, H, W, cam, focal, None, None, z, S, compute_semantics=True)
+    o = oracle_for(model, z, cam, focal, H, W, S, cfg, dcfg, tap.draws, want_semantics=True)
+    close(rgb, o['rgb'], 1e-4, 'rgb'); close(mask, o['mask'], 1e-4, 'mask'); close(depth, o['depth'], 1e-4, 'depth')
+    close(sem, o['semantics'], 1e-4, 'semantic map')
+
+
+def test_nerf_utils_api(setup):
+    model, cam, focal, z = setup
+    H, W, S = 16, 16, 16
+    with torch.no_grad():
+        ro, rd = nu.get_ray_bundle(H, W, focal, cam, None)
+        o_ro, o_rd = orc.ray_bundle(H, W, focal.cpu(), cam.cpu())
+        close(ro, o_ro.expand_as(ro.cpu()), 0, 'ro'); close(rd, o_rd, 2e-7, 'rd')
+        rdn = torch.nn.functional.normalize(rd, dim=-1)
+        near, far = nu.compute_near_far_planes(ro, rdn, 0.55)
+        o_near, o_far, _ = orc.near_far(ro.cpu(), rdn.cpu(), 0.55)
+        close(near, o_near, 0, 'near'); close(far, o_far, 0, 'far')
+        q, t = nu.compute_query_points_from_rays(ro, rdn, near, far, S, randomize=False)
+        o_t = orc.stratified_depths(o_near, o_far, S, None)
+        close(t, o_t, 0, 'depths'); close(q, orc.points_on_rays(ro.cpu(), rdn.cpu(), o_t), 0, 'points')
+        sigma = torch.rand(2, H, W, S, device=cam.device) * 30
+        rgbs = torch.rand(2, H, W, S, 3, device=cam.device) * 2 - 1
+        w = nu.render_volume_density_weights_only(sigma, ro, rdn, t)
+        close(w, orc.ray_weights(sigma.cpu(), rdn.cpu(), t.cpu()), 1e-6, 'weights')
+        sem = torch.rand(2, H, W, S, 4, device=cam.device)
+        rgb_map, depth_map, mask, nmap, smap = nu.render_volume_density(sigma, rgbs, ro, rdn, t, None, sem, True)
+        o_rgb, o_dep, o_acc, o_sem, _ = orc.composite(sigma.cpu(), rgbs.cpu(), rdn.cpu(), t.cpu(), sem.cpu(), True)
+        close(rgb_map, o_rgb, 1e-5, 'rgb map'); close(depth_map, o_dep, 1e-5, 'depth'); close(mask, o_acc, 1e-5, 'mask')
+        close(smap, o_sem, 1e-5, 'semantic map'); assert nmap is None
+        bins = torch.sort(torch.rand(50, 33, device=cam.device), dim=-1)[0]
+        wts = torch.rand(50, 32, device=cam.device)
+        s_det = nu.sample_pdf(bins, wts, 24, deterministic=True)
+        ref, _, _ = orc.inverse_cdf(bins.cpu(), wts.cpu(), orc.deterministic_u(50, 24, wts.cpu()))
+        close(s_det, ref, 1e-5, 'sample_pdf')
+
+
+def test_gradient_request_fails_loudly_not_silently(setup):
+    model, cam, focal, z = setup
+    cfg = types.SimpleNamespace(use_viewdir=False, use_sdf=True, attention_values=10, fine_sampling=True)
+    render = nfi_render.make_render(cfg, {'scene_range': 0.55, 'white_background': True})
+    from nerf_from_image_amd.autograd import BACKWARD
+    if 'field_query' in BACKWARD:
+        pytest.skip('backward kernels are registered')
+    zz = z.clone().requires_grad_()
+    rgb, *_ = render(model, 8, 8, cam, focal, None, None, zz, 16)
+    with pytest.raises(NotImplementedError):
+        rgb.sum().backward()
