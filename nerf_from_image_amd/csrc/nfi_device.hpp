@@ -259,9 +259,9 @@ struct FieldParams {
   int use_sdf;
   float inv_alpha;               // 1/alpha
   float beta;
+  float neg_log2e_over_beta;      // -log2(e)/beta: exp(-|d|/beta) = exp2(|d| * this)
   const float* lds;              // LDS: decoder operand image (shared by the block)
   const float* vf;               // LDS: this scene's attention values in accumulator layout [16 rows][4]
-  int ablate;                    // profiling only (tuning bits 4-5): 1 = no texel loads, 2 = no MFMA
 };
 
 // per-point gather set-up in sample layout: unnormalised, border-clamped plane coordinates.
@@ -304,94 +304,100 @@ struct TileOut {
   float sdf, sigma, r, g, b;
 };
 
-// One tile = 16 points.  Lane l works for point j = l&15 as channel group g = l>>4.
-//   xi: packed integer texel coordinates of point j (x | y<<10 | z<<20), fx,fy,fz fractions,
-//   outside: 1.0f if the point is outside the scene cube.
-// Returns (in every lane of the four groups) the decoder outputs for point j.
-// sem: if non-null, softmax probabilities are written to sem[point j][A] (global).
-template <int TEX, bool ATT>
-__device__ __forceinline__ TileOut field_tile(const FieldParams& P, int lane, uint32_t xi, float fx, float fy,
-                                              float fz, float outside, float* sem) {
-  const int g = lane >> 4;
+// One tile = 16 points, processed in three steps:
+//   tile_issue    - 24 x buffer_load_dwordx4 (3 planes x 4 bilinear corners x 2 half-lines); the lane
+//                   owns 16-byte chunk q of each half-line
+//   tile_bilinear - consumes the 96 texel registers into the lane's 8 interpolated features
+//   tile_mlp      - decoder MLP on MFMA + density / colour epilogue (MFMA lane layout)
+template <int TEX>
+struct TileTex {
+  float v[3][4][8];
+};
+
+// xi: packed integer texel coordinates of point j (x | y<<10 | z<<20)
+template <int TEX>
+__device__ __forceinline__ void tile_issue(const FieldParams& P, int g, uint32_t xi, TileTex<TEX>& T) {
   constexpr int TB = (TEX == 0) ? 128 : 64;                 // texel bytes
-  constexpr int GB = (TEX == 0) ? 16 : 16;                  // byte offset per group inside a texel
-  const int x0 = xi & 1023, y0 = (xi >> 10) & 1023, z0 = (xi >> 20) & 1023;
-
-  float feat[8];
-#pragma unroll
-  for (int s = 0; s < 8; ++s) feat[s] = 0.0f;
-
+  const uint32_t x0 = xi & 1023u, y0 = (xi >> 10) & 1023u, z0 = (xi >> 20) & 1023u;
 #pragma unroll
   for (int pl = 0; pl < 3; ++pl) {
-    const int a0 = (pl == 2) ? y0 : x0;      // W index: x, x, y
-    const int b0 = (pl == 0) ? y0 : z0;      // H index: y, z, z
+    const uint32_t a0 = (pl == 2) ? y0 : x0;      // W index: x, x, y
+    const uint32_t b0 = (pl == 0) ? y0 : z0;      // H index: y, z, z
+    const uint32_t voff = (uint32_t)pl * P.plane_bytes + (b0 * (uint32_t)P.res + a0) * TB + (uint32_t)g * 16u;
+    load_texel8<TEX>(P, voff, 0, 0, T.v[pl][0]);
+    load_texel8<TEX>(P, voff, 0, TB, T.v[pl][1]);
+    load_texel8<TEX>(P, voff, P.row_bytes, 0, T.v[pl][2]);
+    load_texel8<TEX>(P, voff, P.row_bytes, TB, T.v[pl][3]);
+  }
+}
+
+template <int TEX>
+__device__ __forceinline__ void tile_bilinear(const TileTex<TEX>& T, float fx, float fy, float fz, float (&feat)[8]) {
+#pragma unroll
+  for (int s = 0; s < 8; ++s) feat[s] = 0.0f;
+#pragma unroll
+  for (int pl = 0; pl < 3; ++pl) {
     const float fa = (pl == 2) ? fy : fx;
     const float fb = (pl == 0) ? fy : fz;
-    const uint32_t voff = (uint32_t)pl * P.plane_bytes + ((uint32_t)b0 * (uint32_t)P.res + (uint32_t)a0) * TB +
-                          (uint32_t)g * GB;
-    float t00[8], t10[8], t01[8], t11[8];
-    if (P.ablate & 1) {
-#pragma unroll
-      for (int s = 0; s < 8; ++s) { t00[s] = bits2f(0x3f000000u | (voff & 0xffff)); t10[s] = t00[s] * 0.5f; t01[s] = t00[s] * 0.25f; t11[s] = t00[s] * 0.125f; }
-    } else {
-    load_texel8<TEX>(P, voff, 0, 0, t00);
-    load_texel8<TEX>(P, voff, 0, TB, t10);
-    load_texel8<TEX>(P, voff, P.row_bytes, 0, t01);
-    load_texel8<TEX>(P, voff, P.row_bytes, TB, t11);
-    }
     const float ga = 1.0f - fa, gb = 1.0f - fb;
     const float w00 = ga * gb, w10 = fa * gb, w01 = ga * fb, w11 = fa * fb;
 #pragma unroll
     for (int s = 0; s < 8; ++s) {
       float acc = feat[s];
-      acc = fmaf(w00, t00[s], acc);
-      acc = fmaf(w10, t10[s], acc);
-      acc = fmaf(w01, t01[s], acc);
-      acc = fmaf(w11, t11[s], acc);
+      acc = fmaf(w00, T.v[pl][0][s], acc);
+      acc = fmaf(w10, T.v[pl][1][s], acc);
+      acc = fmaf(w01, T.v[pl][2][s], acc);
+      acc = fmaf(w11, T.v[pl][3][s], acc);
       feat[s] = acc;
     }
   }
+}
 
+// Returns (in every lane of the four groups) the decoder outputs for point j.
+//   outside: 1.0f if the point is outside the scene cube.
+//   sem: if non-null, softmax probabilities are written to sem[A] (global) for this point.
+template <bool ATT>
+__device__ __forceinline__ TileOut tile_mlp(const FieldParams& P, int lane, const float (&feat)[8], float outside,
+                                            float* sem) {
+  const int g = lane >> 4;
   // ---- layer 1: H^T[64 x 16] = W1'[64 x 32] * F^T[32 x 16], bias pre-loaded, log2 domain ----
   const f32x4* ldsv = reinterpret_cast<const f32x4*>(P.lds);
   f32x4 o;
-  if (P.ablate & 2) {
-    o.x = feat[0] + feat[4]; o.y = feat[1] + feat[5]; o.z = feat[2] + feat[6]; o.w = feat[3] + feat[7];
-  } else {
-  f32x4 acc1[4];
+  {
+    f32x4 acc1[4];
 #pragma unroll
-  for (int nt = 0; nt < 4; ++nt) acc1[nt] = ldsv[(kB1F >> 2) + g * 4 + nt];
+    for (int nt = 0; nt < 4; ++nt) acc1[nt] = ldsv[(kB1F >> 2) + g * 4 + nt];
 #pragma unroll
-  for (int s = 0; s < 8; ++s) {
-    f32x4 w = ldsv[(kW1F >> 2) + s * 64 + lane];
-    acc1[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(w.x, feat[s], acc1[0], 0, 0, 0);
-    acc1[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(w.y, feat[s], acc1[1], 0, 0, 0);
-    acc1[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(w.z, feat[s], acc1[2], 0, 0, 0);
-    acc1[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(w.w, feat[s], acc1[3], 0, 0, 0);
-  }
-  // softplus in base 2: sp2 = log2(1 + 2^h2)  (= softplus(h)/ln2; ln2 is folded into W2')
-#pragma unroll
-  for (int nt = 0; nt < 4; ++nt) {
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      float h = acc1[nt][r];
-      float e = __builtin_amdgcn_exp2f(h);
-      float s = __builtin_amdgcn_logf(1.0f + e);
-      acc1[nt][r] = (h > kSoftplusThr2) ? h : s;
+    for (int s = 0; s < 8; ++s) {
+      f32x4 w = ldsv[(kW1F >> 2) + s * 64 + lane];
+      acc1[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(w.x, feat[s], acc1[0], 0, 0, 0);
+      acc1[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(w.y, feat[s], acc1[1], 0, 0, 0);
+      acc1[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(w.z, feat[s], acc1[2], 0, 0, 0);
+      acc1[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(w.w, feat[s], acc1[3], 0, 0, 0);
     }
-  }
-  // ---- layer 2: O^T[16 x 16] = W2'[16 x 64] * SP^T[64 x 16]; two accumulators hide latency ----
-  f32x4 o0 = ldsv[(kB2F >> 2) + g];
-  f32x4 o1 = {0.0f, 0.0f, 0.0f, 0.0f};
+    // softplus in base 2: sp2 = log2(1 + 2^h2)  (= softplus(h)/ln2; ln2 is folded into W2')
 #pragma unroll
-  for (int nt = 0; nt < 4; ++nt) {
-    f32x4 w = ldsv[(kW2F >> 2) + nt * 64 + lane];
-    o0 = __builtin_amdgcn_mfma_f32_16x16x4f32(w.x, acc1[nt][0], o0, 0, 0, 0);
-    o1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w.y, acc1[nt][1], o1, 0, 0, 0);
-    o0 = __builtin_amdgcn_mfma_f32_16x16x4f32(w.z, acc1[nt][2], o0, 0, 0, 0);
-    o1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w.w, acc1[nt][3], o1, 0, 0, 0);
-  }
-  o = o0 + o1;  // lane (j,g): outputs 4g..4g+3 of point j; output 0 = sdf/density, 1.. = features*log2e
+    for (int nt = 0; nt < 4; ++nt) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float h = acc1[nt][r];
+        float e = __builtin_amdgcn_exp2f(h);
+        float sp = __builtin_amdgcn_logf(1.0f + e);
+        acc1[nt][r] = (h > kSoftplusThr2) ? h : sp;
+      }
+    }
+    // ---- layer 2: O^T[16 x 16] = W2'[16 x 64] * SP^T[64 x 16]; two accumulators hide latency ----
+    f32x4 o0 = ldsv[(kB2F >> 2) + g];
+    f32x4 o1 = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+      f32x4 w = ldsv[(kW2F >> 2) + nt * 64 + lane];
+      o0 = __builtin_amdgcn_mfma_f32_16x16x4f32(w.x, acc1[nt][0], o0, 0, 0, 0);
+      o1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w.y, acc1[nt][1], o1, 0, 0, 0);
+      o0 = __builtin_amdgcn_mfma_f32_16x16x4f32(w.z, acc1[nt][2], o0, 0, 0, 0);
+      o1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w.w, acc1[nt][3], o1, 0, 0, 0);
+    }
+    o = o0 + o1;  // lane (j,g): outputs 4g..4g+3 of point j; output 0 = sdf/density, 1.. = features*log2e
   }
 
   TileOut res;
@@ -399,9 +405,10 @@ __device__ __forceinline__ TileOut field_tile(const FieldParams& P, int lane, ui
   float sdf = __shfl(o.x, j, 64);  // broadcast group 0's row 0 to all groups
   res.sdf = sdf;
   if (P.use_sdf) {
-    float x = -sdf;
-    float sgn = (x > 0.0f) ? 1.0f : ((x < 0.0f) ? -1.0f : 0.0f);
-    float cdf = 0.5f + (0.5f * sgn) * (1.0f - __expf(-fabsf(x) / P.beta));
+    // sigma = (1/alpha) * (0.5 + 0.5*sign(-d)*(1 - exp(-|d|/beta))) * (1 - outside)
+    float e = __builtin_amdgcn_exp2f(fabsf(sdf) * P.neg_log2e_over_beta);
+    float sgn = (sdf < 0.0f) ? 0.5f : ((sdf > 0.0f) ? -0.5f : 0.0f);
+    float cdf = 0.5f + sgn * (1.0f - e);
     res.sigma = P.inv_alpha * (cdf * (1.0f - outside));
   } else {
     float d = sdf - 1.0f;
@@ -437,7 +444,8 @@ __device__ __forceinline__ TileOut field_tile(const FieldParams& P, int lane, ui
     }
     se += __shfl_xor(se, 16, 64); sr += __shfl_xor(sr, 16, 64); sg += __shfl_xor(sg, 16, 64); sb += __shfl_xor(sb, 16, 64);
     se += __shfl_xor(se, 32, 64); sr += __shfl_xor(sr, 32, 64); sg += __shfl_xor(sg, 32, 64); sb += __shfl_xor(sb, 32, 64);
-    float inv = 1.0f / se;
+    float inv = __builtin_amdgcn_rcpf(se);
+    inv = inv * (2.0f - se * inv);      // one Newton step: the quotient is then within 1 ulp
     res.r = sr * inv; res.g = sg * inv; res.b = sb * inv;
     if (sem) {
 #pragma unroll
@@ -465,11 +473,10 @@ struct SampleOut {
 // (or invalid) are skipped: sigma is exactly 0 there (the reference multiplies by (1-mask),
 // generator.py:633) and rgb is reported as 0 (its compositing weight is exactly 0).  Without SKIP
 // (the sampler closure) outside points get the border-clamped colour/distance the reference returns.
-// sem_base: null or global pointer to this wave's [64][A] semantics rows.
+// sem_base: null or global pointer to this wave's [64][A] semantics rows (written for valid points).
 template <int TEX, bool ATT, bool SKIP>
 __device__ __forceinline__ SampleOut field_wave(const FieldParams& P, float scene_range, int lane, float px, float py,
                                                 float pz, bool valid, float* sem_base, bool* outside_flag) {
-  // sem_base rows are written only for valid points (rows past the end of the array do not exist)
   // reference: x / scene_range, mask = any(|x| > 1)   (true division, generator.py:604-607)
   float qx = px / scene_range, qy = py / scene_range, qz = pz / scene_range;
   bool out = (fabsf(qx) > 1.0f) || (fabsf(qy) > 1.0f) || (fabsf(qz) > 1.0f);
@@ -480,23 +487,45 @@ __device__ __forceinline__ SampleOut field_wave(const FieldParams& P, float scen
   plane_coord(qy, P.res_m1, P.res, y0, fy);
   plane_coord(qz, P.res_m1, P.res, z0, fz);
   if (!valid) { x0 = y0 = z0 = 0; fx = fy = fz = 0.0f; }  // keep NaN/garbage out of the address math
-  uint32_t xi = (uint32_t)x0 | ((uint32_t)y0 << 10) | ((uint32_t)z0 << 20);
-  float outf = out ? 1.0f : 0.0f;
-  uint64_t live = SKIP ? __ballot(valid && !out) : __ballot(valid);
+  const int xi = (int)((uint32_t)x0 | ((uint32_t)y0 << 10) | ((uint32_t)z0 << 20));
+  // bit 0: outside, bit 1: valid
+  const int flags = (out ? 1 : 0) | (valid ? 2 : 0);
+  const uint64_t live = SKIP ? __ballot(valid && !out) : __ballot(valid);
+  uint32_t tm = 0;   // wave-uniform 4-bit mask of tiles with work
+#pragma unroll
+  for (int t = 0; t < 4; ++t) tm |= (((live >> (16 * t)) & 0xFFFFull) != 0 ? 1u : 0u) << t;
 
   SampleOut so;
   so.sdf = 0.0f; so.sigma = 0.0f; so.r = 0.0f; so.g = 0.0f; so.b = 0.0f;
+  if (tm == 0) return so;
   const int j = lane & 15, g = lane >> 4;
+
+  // Two lane layouts are used per tile (16 points):
+  //   load layout  L: lane = 4*p + q  (p = point, q = 16-byte chunk) - the 4 lanes of a point are
+  //                   CONSECUTIVE, so a wave load reads 16 x 64 contiguous bytes and the texture
+  //                   addresser coalesces each lane quad into one line access (4x fewer accesses
+  //                   than with the MFMA layout, whose consecutive lanes are different points);
+  //   MFMA layout  M: lane = 16*g + j (j = point, g = channel group) - fixed by v_mfma_*.
+  // The 8 interpolated features are moved L -> M with 8 ds_bpermute (a 4x16 lane-grid transpose);
+  // chunk q of L and channel group g of M hold the same channels, so the W1 operand image is
+  // independent of this choice.
+  const int lp = lane >> 2, lq = lane & 3;        // L layout
+  const int tr_src = 4 * j + g;                   // M lane (g, j) reads L lane 4j + g
 #pragma unroll 1
   for (int t = 0; t < 4; ++t) {
-    if (((live >> (16 * t)) & 0xFFFFull) == 0) continue;  // wave-uniform
-    int src = 16 * t + j;
-    uint32_t txi = (uint32_t)__shfl((int)xi, src, 64);
-    float tfx = __shfl(fx, src, 64), tfy = __shfl(fy, src, 64), tfz = __shfl(fz, src, 64);
-    float tout = __shfl(outf, src, 64);
-    int tvalid = __shfl(valid ? 1 : 0, src, 64);
-    float* sem = (sem_base && tvalid) ? sem_base + (size_t)src * P.n_attention : nullptr;
-    TileOut to = field_tile<TEX, ATT>(P, lane, txi, tfx, tfy, tfz, tout, sem);
+    if (!((tm >> t) & 1u)) continue;              // wave-uniform
+    const int srcL = 16 * t + lp, srcM = 16 * t + j;
+    const float cfx = __shfl(fx, srcL, 64), cfy = __shfl(fy, srcL, 64), cfz = __shfl(fz, srcL, 64);
+    const uint32_t cxi = (uint32_t)__shfl(xi, srcL, 64);
+    const int fcur = __shfl(flags, srcM, 64);
+    TileTex<TEX> T;
+    tile_issue<TEX>(P, lq, cxi, T);
+    float featL[8], feat[8];
+    tile_bilinear<TEX>(T, cfx, cfy, cfz, featL);
+#pragma unroll
+    for (int s8 = 0; s8 < 8; ++s8) feat[s8] = __shfl(featL[s8], tr_src, 64);
+    float* sem = (sem_base && (fcur & 2)) ? sem_base + (size_t)srcM * P.n_attention : nullptr;
+    TileOut to = tile_mlp<ATT>(P, lane, feat, (fcur & 1) ? 1.0f : 0.0f, sem);
     if (g == t) { so.sdf = to.sdf; so.sigma = to.sigma; so.r = to.r; so.g = to.g; so.b = to.b; }
   }
   return so;

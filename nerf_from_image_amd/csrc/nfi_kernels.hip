@@ -397,9 +397,9 @@ __device__ __forceinline__ FieldParams make_field_params(const void* texels_scen
   P.use_sdf = use_sdf;
   P.inv_alpha = use_sdf ? 1.0f / alpha[0] : 1.0f;
   P.beta = use_sdf ? beta[0] : 1.0f;
+  P.neg_log2e_over_beta = -kLog2e / P.beta;
   P.lds = lds;
   P.vf = lds + kVF;
-  P.ablate = 0;
   return P;
 }
 
@@ -595,6 +595,70 @@ __device__ __forceinline__ void merge_scatter(WaveSlab& slab, const float (&dep)
       slab.srt[0][r] = dep[j]; slab.srt[1][r] = sig[j];
       slab.srt[2][r] = cr[j]; slab.srt[3][r] = cg[j]; slab.srt[4][r] = cb[j];
     }
+  }
+  wave_lds_fence();
+}
+
+// Merge for the fused renderer, lane = sample index k < S: the coarse list is (checked to be)
+// ascending, so only the S fine keys have to be ranked by counting:
+//   rank(coarse k) = k + #{fine j : z_j <  t_k}
+//   rank(fine  k)  = #{coarse j : t_j <= z_k} + #{fine j : z_j < z_k or (z_j == z_k and j < k)}
+// i.e. the stable ascending order of cat(coarse, fine) (coarse first on ties), ~4x fewer compares
+// than ranking all 2S keys against all 2S keys.  Falls back to the general count when the coarse
+// depths are not ascending (possible only through 1-ulp rounding of the jittered depths).
+struct MergeIn { float t, sigma, r, g, b; };
+__device__ __forceinline__ void merge_pair_scatter(WaveSlab& slab, const MergeIn& c, const MergeIn& f, int S, int lane,
+                                                   int& rank_c, int& rank_f) {
+  const bool valid = lane < S;
+  const uint32_t kc = valid ? ordered_key(c.t) : 0xFFFFFFFFu;
+  const uint32_t kf = valid ? ordered_key(f.t) : 0xFFFFFFFFu;
+  const uint32_t kc_next = (uint32_t)__shfl_down((int)kc, 1, 64);
+  const bool ascending = __all(lane >= S - 1 || kc <= kc_next);
+  slab.key[lane] = kf;            // fine keys   [0,64)   (padding 0xFFFFFFFF ranks after everything)
+  slab.key[64 + lane] = kc;       // coarse keys [64,128)
+  wave_lds_fence();
+  const uint4* kv = reinterpret_cast<const uint4*>(slab.key);
+  const int n4 = (S + 3) >> 2;
+  int cnt_a = 0, cnt_b = 0, cnt_c = 0;
+  for (int i = 0; i < n4; ++i) {
+    const uint4 q = kv[i];
+    const uint32_t qq[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int idx = 4 * i + e;
+      cnt_a += (qq[e] < kc) ? 1 : 0;
+      cnt_b += ((qq[e] < kf) || (qq[e] == kf && idx < lane)) ? 1 : 0;
+    }
+  }
+  if (ascending) {
+    // #{coarse <= z_k}: branch-free upper bound over the ascending coarse keys
+    int pos = 0;
+#pragma unroll
+    for (int step = 64; step >= 1; step >>= 1) {
+      int idx = pos + step;
+      if (idx <= S && slab.key[64 + idx - 1] <= kf) pos = idx;
+    }
+    cnt_c = pos;
+    rank_c = lane + cnt_a;
+  } else {
+    int cnt_d = 0;   // coarse j before coarse k
+    for (int i = 0; i < n4; ++i) {
+      const uint4 q = kv[16 + i];
+      const uint32_t qq[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int idx = 4 * i + e;
+        cnt_c += (idx < S && qq[e] <= kf) ? 1 : 0;
+        cnt_d += (idx < S && (qq[e] < kc || (qq[e] == kc && idx < lane))) ? 1 : 0;
+      }
+    }
+    rank_c = cnt_d + cnt_a;
+  }
+  rank_f = cnt_c + cnt_b;
+  wave_lds_fence();
+  if (valid) {
+    slab.srt[0][rank_c] = c.t; slab.srt[1][rank_c] = c.sigma; slab.srt[2][rank_c] = c.r; slab.srt[3][rank_c] = c.g; slab.srt[4][rank_c] = c.b;
+    slab.srt[0][rank_f] = f.t; slab.srt[1][rank_f] = f.sigma; slab.srt[2][rank_f] = f.r; slab.srt[3][rank_f] = f.g; slab.srt[4][rank_f] = f.b;
   }
   wave_lds_fence();
 }
@@ -843,13 +907,18 @@ struct RenderKernelParams {
   float* t_fine; float* sigma_fine; float* rgb_fine;
   float* t_sorted; float* weights; int32_t* perm;
   int skip_missed;
-  int ablate;
 };
 
 // Persistent kernel: one wave per ray, rays handed out by one device-scope counter (scene-major,
-// so the chip works on one scene's 25 MB of texels at a time), next index prefetched while the
-// current ray is marched.  OCC = waves per SIMD the register budget is held to.
-template <int TEX, bool ATT, int OCC>
+// so the chip works on one scene's 25 MB of texels at a time).  The ray index two steps ahead is
+// being fetched and the next ray's inputs are loaded while the current ray is marched.
+// OCC = waves per SIMD the register budget is held to; TAPS = write the optional stage taps.
+struct RayInputs {
+  float ox, oy, oz, dx, dy, dz, near, far, noise, u;
+  uint32_t hit;
+};
+
+template <int TEX, bool ATT, int OCC, bool TAPS>
 __global__ __launch_bounds__(256, OCC) void render_fwd_kernel(RenderKernelParams k) {
   __shared__ __attribute__((aligned(16))) float lds[kImageFloats];
   __shared__ __attribute__((aligned(16))) float vfs[4][64];
@@ -861,6 +930,7 @@ __global__ __launch_bounds__(256, OCC) void render_fwd_kernel(RenderKernelParams
   WaveSlab& slab = slabs[wave];
   float* vf = vfs[wave];
   const int S = k.S;
+  const bool valid = lane < S;
   const float fill_near = ordered_key_inv(~k.reduce[0]), fill_far = ordered_key_inv(k.reduce[1]);
   const float bg = k.white ? 1.0f : 0.0f;
   const size_t tb = TEX == 0 ? 128 : 64;
@@ -869,116 +939,124 @@ __global__ __launch_bounds__(256, OCC) void render_fwd_kernel(RenderKernelParams
 
   FieldParams P = make_field_params(k.texels, k.res, TEX, k.A, k.use_sdf, k.beta, k.alpha, lds);
   P.vf = vf;
-  P.ablate = k.ablate;
   int cur_scene = -1;
 
-  uint32_t next = 0;
-  if (lane == 0) next = atomicAdd(counter, 1u);
-  next = (uint32_t)__builtin_amdgcn_readfirstlane((int)next);
-  while (next < n_rays) {
-    const uint32_t ray = next;
-    if (lane == 0) next = atomicAdd(counter, 1u);          // prefetch the following ray index
-    const uint8_t hitb = k.hit[ray];
+  auto load_inputs = [&](uint32_t ray, RayInputs& in) {
+    const size_t r3 = (size_t)ray * 3;
+    in.hit = k.hit[ray];
+    in.ox = k.ro[r3]; in.oy = k.ro[r3 + 1]; in.oz = k.ro[r3 + 2];
+    in.dx = k.rd[r3]; in.dy = k.rd[r3 + 1]; in.dz = k.rd[r3 + 2];
+    in.near = k.near_raw[ray]; in.far = k.far_raw[ray];
+    in.noise = (k.noise_c && valid) ? k.noise_c[(size_t)ray * S + lane] : 0.0f;
+    in.u = (k.fine && valid) ? k.noise_f[(size_t)ray * k.noise_f_stride + lane] : 0.0f;
+  };
+
+  // ray indices: cur (being marched), nxt (inputs being loaded), and one more in flight
+  uint32_t cur = 0, nxt = 0, fly = 0;
+  if (lane == 0) { cur = atomicAdd(counter, 1u); nxt = atomicAdd(counter, 1u); }
+  cur = (uint32_t)__builtin_amdgcn_readfirstlane((int)cur);
+  nxt = (uint32_t)__builtin_amdgcn_readfirstlane((int)nxt);
+  RayInputs in, pre;
+  if (cur < n_rays) load_inputs(cur, in);
+  while (cur < n_rays) {
+    if (lane == 0) fly = atomicAdd(counter, 1u);
+    if (nxt < n_rays) load_inputs(nxt, pre);
+    const uint32_t ray = cur;
+    const uint32_t hitb = in.hit;
     if (k.skip_missed && !(hitb & 2)) {
       // the ray's line stays outside the (inflated) scene cube: every sample has sigma == 0
       if (lane == 0) {
         k.rgb[(size_t)ray * 3] = bg; k.rgb[(size_t)ray * 3 + 1] = bg; k.rgb[(size_t)ray * 3 + 2] = bg;
         k.depth[ray] = 0.0f; k.mask[ray] = 0.0f;
       }
-      next = (uint32_t)__builtin_amdgcn_readfirstlane((int)next);
-      continue;
-    }
-    const int scene = (int)(ray / (uint32_t)k.hw);
-    if (scene != cur_scene) {
-      cur_scene = scene;
-      const char* tex_scene = reinterpret_cast<const char*>(k.texels) + (size_t)scene * 3 * k.res * k.res * tb;
-      P.rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(tex_scene), 0, (int)(3u * P.plane_bytes), 0x00020000);
-      wave_lds_fence();
-      {
-        int c = lane & 3, row = lane >> 2;
-        float v = 0.0f;
-        if (k.att && c < 3 && row >= 1 && row <= k.A) v = k.att[((size_t)scene * k.A + (row - 1)) * 3 + c];
-        vf[lane] = v;
-      }
-      wave_lds_fence();
-    }
-    const float ox = k.ro[(size_t)ray * 3], oy = k.ro[(size_t)ray * 3 + 1], oz = k.ro[(size_t)ray * 3 + 2];
-    const float dx = k.rd[(size_t)ray * 3], dy = k.rd[(size_t)ray * 3 + 1], dz = k.rd[(size_t)ray * 3 + 2];
-    float near = k.near_raw[ray], far = k.far_raw[ray];
-    finish_planes((hitb & 1) != 0, fill_near, fill_far, near, far);
-    if (lane == 0) {
-      if (k.near_plane) k.near_plane[ray] = near;
-      if (k.far_plane) k.far_plane[ray] = far;
-    }
-    const bool valid = lane < S;
-    const float dnorm = norm3(dx, dy, dz);
-    const size_t rs = (size_t)ray * S;
-
-    // ---- coarse pass ----
-    float tc = 0.0f;
-    if (valid) tc = stratified_depth(near, far, lane, S, k.noise_c ? k.noise_c[rs + lane] : 0.0f, k.noise_c != nullptr);
-    float px = ox + dx * tc, py = oy + dy * tc, pz = oz + dz * tc;
-    SampleOut c = field_wave<TEX, ATT, true>(P, k.scene_range, lane, px, py, pz, valid, nullptr, nullptr);
-    if (valid) {
-      if (k.t_coarse) k.t_coarse[rs + lane] = tc;
-      if (k.sigma_coarse) k.sigma_coarse[rs + lane] = c.sigma;
-      if (k.rgb_coarse) { float* q = k.rgb_coarse + (rs + lane) * 3; q[0] = c.r; q[1] = c.g; q[2] = c.b; }
-    }
-
-    int n = S;
-    float dep[2] = {tc, 0.0f}, sig[2] = {c.sigma, 0.0f}, cr[2] = {c.r, 0.0f}, cg[2] = {c.g, 0.0f}, cb[2] = {c.b, 0.0f};
-    int rank[2] = {lane, 64 + lane};
-    if (k.fine) {
-      // ---- hierarchical resampling + fine pass ----
-      float u = valid ? k.noise_f[(size_t)ray * k.noise_f_stride + lane] : 0.0f;
-      float tf = resample_ray(slab, c.sigma, tc, S, dnorm, u, lane, nullptr);
-      float fx = ox + dx * tf, fy = oy + dy * tf, fz = oz + dz * tf;
-      SampleOut f = field_wave<TEX, ATT, true>(P, k.scene_range, lane, fx, fy, fz, valid, nullptr, nullptr);
-      if (valid) {
-        if (k.t_fine) k.t_fine[rs + lane] = tf;
-        if (k.sigma_fine) k.sigma_fine[rs + lane] = f.sigma;
-        if (k.rgb_fine) { float* q = k.rgb_fine + (rs + lane) * 3; q[0] = f.r; q[1] = f.g; q[2] = f.b; }
-      }
-      n = 2 * S;
-      // element e of cat(coarse, fine): e < S coarse, else fine; build the (slot, lane) view
-      if (S == 64) {
-        dep[1] = tf; sig[1] = f.sigma; cr[1] = f.r; cg[1] = f.g; cb[1] = f.b;
-      } else {
-        int src = (lane - S) & 63;          // slot 0, lanes [S, 64): fine sample lane-S
-        float tf0 = __shfl(tf, src, 64), sf0 = __shfl(f.sigma, src, 64);
-        float rf0 = __shfl(f.r, src, 64), gf0 = __shfl(f.g, src, 64), bf0 = __shfl(f.b, src, 64);
-        int src1 = (64 + lane - S) & 63;    // slot 1: element 64+lane -> fine sample 64+lane-S
-        float tf1 = __shfl(tf, src1, 64), sf1 = __shfl(f.sigma, src1, 64);
-        float rf1 = __shfl(f.r, src1, 64), gf1 = __shfl(f.g, src1, 64), bf1 = __shfl(f.b, src1, 64);
-        if (lane >= S) { dep[0] = tf0; sig[0] = sf0; cr[0] = rf0; cg[0] = gf0; cb[0] = bf0; }
-        dep[1] = tf1; sig[1] = sf1; cr[1] = rf1; cg[1] = gf1; cb[1] = bf1;
-      }
-      merge_scatter(slab, dep, sig, cr, cg, cb, n, lane, rank);
     } else {
-#pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        int e = j * 64 + lane;
-        if (e < n) { slab.srt[0][e] = dep[j]; slab.srt[1][e] = sig[j]; slab.srt[2][e] = cr[j]; slab.srt[3][e] = cg[j]; slab.srt[4][e] = cb[j]; }
+      const int scene = (int)(ray / (uint32_t)k.hw);
+      if (scene != cur_scene) {
+        cur_scene = scene;
+        const char* tex_scene = reinterpret_cast<const char*>(k.texels) + (size_t)scene * 3 * k.res * k.res * tb;
+        P.rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(tex_scene), 0, (int)(3u * P.plane_bytes), 0x00020000);
+        wave_lds_fence();
+        {
+          int c = lane & 3, row = lane >> 2;
+          float v = 0.0f;
+          if (k.att && c < 3 && row >= 1 && row <= k.A) v = k.att[((size_t)scene * k.A + (row - 1)) * 3 + c];
+          vf[lane] = v;
+        }
+        wave_lds_fence();
       }
-      wave_lds_fence();
-    }
-    float w[2];
-    CompositeOut o = composite_slab(slab, n, dnorm, k.white, lane, w);
-    if (lane == 0) {
-      k.rgb[(size_t)ray * 3] = o.r; k.rgb[(size_t)ray * 3 + 1] = o.g; k.rgb[(size_t)ray * 3 + 2] = o.b;
-      k.depth[ray] = o.depth; k.mask[ray] = o.mask;
-    }
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      int e = j * 64 + lane;
-      if (e < n) {
-        if (k.weights) k.weights[(size_t)ray * n + e] = w[j];
-        if (k.t_sorted) k.t_sorted[(size_t)ray * n + e] = slab.srt[0][e];
-        if (k.perm) k.perm[(size_t)ray * n + rank[j]] = e;
+      const float ox = in.ox, oy = in.oy, oz = in.oz, dx = in.dx, dy = in.dy, dz = in.dz;
+      float near = in.near, far = in.far;
+      finish_planes((hitb & 1) != 0, fill_near, fill_far, near, far);
+      const float dnorm = norm3(dx, dy, dz);
+      const size_t rs = (size_t)ray * S;
+
+      // ---- coarse pass ----
+      float tc = 0.0f;
+      if (valid) tc = stratified_depth(near, far, lane, S, in.noise, k.noise_c != nullptr);
+      MergeIn c;
+      {
+        SampleOut q = field_wave<TEX, ATT, true>(P, k.scene_range, lane, ox + dx * tc, oy + dy * tc, oz + dz * tc, valid,
+                                                 nullptr, nullptr);
+        c.t = tc; c.sigma = q.sigma; c.r = q.r; c.g = q.g; c.b = q.b;
       }
+      int n = S;
+      int rank_c = lane, rank_f = 0;
+      if (k.fine) {
+        // ---- hierarchical resampling + fine pass ----
+        const float tf = resample_ray(slab, c.sigma, tc, S, dnorm, in.u, lane, nullptr);
+        MergeIn f;
+        {
+          SampleOut q = field_wave<TEX, ATT, true>(P, k.scene_range, lane, ox + dx * tf, oy + dy * tf, oz + dz * tf, valid,
+                                                   nullptr, nullptr);
+          f.t = tf; f.sigma = q.sigma; f.r = q.r; f.g = q.g; f.b = q.b;
+        }
+        if constexpr (TAPS) {
+          if (valid) {
+            if (k.t_fine) k.t_fine[rs + lane] = tf;
+            if (k.sigma_fine) k.sigma_fine[rs + lane] = f.sigma;
+            if (k.rgb_fine) { float* q = k.rgb_fine + (rs + lane) * 3; q[0] = f.r; q[1] = f.g; q[2] = f.b; }
+          }
+        }
+        n = 2 * S;
+        merge_pair_scatter(slab, c, f, S, lane, rank_c, rank_f);
+      } else {
+        if (valid) { slab.srt[0][lane] = c.t; slab.srt[1][lane] = c.sigma; slab.srt[2][lane] = c.r; slab.srt[3][lane] = c.g; slab.srt[4][lane] = c.b; }
+        wave_lds_fence();
+      }
+      float w[2];
+      CompositeOut o = composite_slab(slab, n, dnorm, k.white, lane, w);
+      if (lane == 0) {
+        k.rgb[(size_t)ray * 3] = o.r; k.rgb[(size_t)ray * 3 + 1] = o.g; k.rgb[(size_t)ray * 3 + 2] = o.b;
+        k.depth[ray] = o.depth; k.mask[ray] = o.mask;
+      }
+      if constexpr (TAPS) {
+        if (lane == 0) {
+          if (k.near_plane) k.near_plane[ray] = near;
+          if (k.far_plane) k.far_plane[ray] = far;
+        }
+        if (valid) {
+          if (k.t_coarse) k.t_coarse[rs + lane] = tc;
+          if (k.sigma_coarse) k.sigma_coarse[rs + lane] = c.sigma;
+          if (k.rgb_coarse) { float* q = k.rgb_coarse + (rs + lane) * 3; q[0] = c.r; q[1] = c.g; q[2] = c.b; }
+          if (k.perm) {
+            k.perm[(size_t)ray * n + rank_c] = lane;
+            if (k.fine) k.perm[(size_t)ray * n + rank_f] = S + lane;
+          }
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          int e = j * 64 + lane;
+          if (e < n) {
+            if (k.weights) k.weights[(size_t)ray * n + e] = w[j];
+            if (k.t_sorted) k.t_sorted[(size_t)ray * n + e] = slab.srt[0][e];
+          }
+        }
+      }
+      wave_lds_fence();  // slab is reused by the next ray
     }
-    wave_lds_fence();  // slab is reused by the next ray
-    next = (uint32_t)__builtin_amdgcn_readfirstlane((int)next);
+    in = pre;
+    cur = nxt;
+    nxt = (uint32_t)__builtin_amdgcn_readfirstlane((int)fly);
   }
 }
 
@@ -1032,7 +1110,6 @@ extern "C" int nfi_render_fwd(const nfi_render_args* a, nfi_stream_t stream) {
   k.skip_missed = (a->skip_missed_rays && !any_tap) ? 1 : 0;
 
   k.counter = reduce + 3;
-  k.ablate = (a->tuning >> 4) & 3;
   // persistent 1-D grid: OCC blocks of 4 waves per CU, never more blocks than rays need
   int occ = a->tuning & 3;               // 0 = default
   if (occ == 0) occ = 3;
@@ -1044,9 +1121,10 @@ extern "C" int nfi_render_fwd(const nfi_render_args* a, nfi_stream_t stream) {
   if (a->event_start) (void)hipEventRecord((hipEvent_t)a->event_start, s);
 #define NFI_LAUNCH_RENDER(TEX, ATT)                                                                        \
   do {                                                                                                     \
-    if (occ == 2) hipLaunchKernelGGL((render_fwd_kernel<TEX, ATT, 2>), grid, dim3(256), 0, s, k);          \
-    else if (occ == 3) hipLaunchKernelGGL((render_fwd_kernel<TEX, ATT, 3>), grid, dim3(256), 0, s, k);     \
-    else hipLaunchKernelGGL((render_fwd_kernel<TEX, ATT, 4>), grid, dim3(256), 0, s, k);                   \
+    if (any_tap) hipLaunchKernelGGL((render_fwd_kernel<TEX, ATT, 2, true>), grid, dim3(256), 0, s, k);          \
+    else if (occ == 2) hipLaunchKernelGGL((render_fwd_kernel<TEX, ATT, 2, false>), grid, dim3(256), 0, s, k);   \
+    else if (occ == 3) hipLaunchKernelGGL((render_fwd_kernel<TEX, ATT, 3, false>), grid, dim3(256), 0, s, k);   \
+    else hipLaunchKernelGGL((render_fwd_kernel<TEX, ATT, 4, false>), grid, dim3(256), 0, s, k);                 \
   } while (0)
   if (a->texel_dtype == NFI_TEXEL_F32) {
     if (att) NFI_LAUNCH_RENDER(0, true); else NFI_LAUNCH_RENDER(0, false);
