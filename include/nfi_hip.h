@@ -279,6 +279,10 @@ typedef struct nfi_render_args {
   /* tuning knob, 0 = default: bits 0-1 select the register/occupancy variant of the render kernel
    * (1: 2, 2 or 0: 3, 3: 4 waves per SIMD).  Results do not depend on it. */
   int tuning;
+  /* optional uint64[12] device array: per-phase shader-cycle sums over all waves (profiling build of
+   * the kernel; NULL = off): field tile {issue, wait+interp, mlp, count}, ray set-up, coarse field,
+   * resample, fine field, merge, composite, rays marched, wave lifetime */
+  void* profile_cycles;
 } nfi_render_args;
 size_t nfi_render_workspace_bytes(int64_t n_rays);
 int nfi_render_fwd(const nfi_render_args* a, nfi_stream_t stream);

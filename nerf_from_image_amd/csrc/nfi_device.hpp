@@ -57,64 +57,102 @@ __device__ __forceinline__ float ordered_key_inv(uint32_t k) {
   return bits2f(b);
 }
 
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+// ---- cross-lane primitives without LDS traffic ------------------------------------------------
+// gfx950 has DPP row operations (incl. row_bcast:15/31, wave_shl/shr) and v_permlane16/32_swap:
+// reductions, scans and neighbour exchanges stay on the VALU instead of going through
+// ds_bpermute (LDS crossbar, ~100 cycles of dependent latency per hop).
+template <int CTRL, int ROW_MASK = 0xf>
+__device__ __forceinline__ float dpp_f32(float old, float v) {
+  return bits2f((uint32_t)__builtin_amdgcn_update_dpp((int)f2bits(old), (int)f2bits(v), CTRL, ROW_MASK, 0xf, false));
+}
+template <int CTRL, int ROW_MASK = 0xf>
+__device__ __forceinline__ double dpp_f64(double old, double v) {
+  const uint64_t ob = __builtin_bit_cast(uint64_t, old), vb = __builtin_bit_cast(uint64_t, v);
+  const uint32_t lo = (uint32_t)__builtin_amdgcn_update_dpp((int)(uint32_t)ob, (int)(uint32_t)vb, CTRL, ROW_MASK, 0xf, false);
+  const uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp((int)(uint32_t)(ob >> 32), (int)(uint32_t)(vb >> 32), CTRL, ROW_MASK, 0xf, false);
+  return __builtin_bit_cast(double, ((uint64_t)hi << 32) | lo);
+}
+constexpr int kDppQuadXor1 = 0xB1, kDppQuadXor2 = 0x4E, kDppRowHalfMirror = 0x141, kDppRowMirror = 0x140;
+constexpr int kDppRowBcast15 = 0x142, kDppRowBcast31 = 0x143, kDppWaveShl1 = 0x130, kDppWaveShr1 = 0x138;
+#define NFI_DPP_ROW_SHR(n) (0x110 + (n))
+
+// value of lane l^16 / l^32 paired with the own value, as (x, y) with x+y == v[l] + v[l^16]
+__device__ __forceinline__ void swap16(float v, float& x, float& y) {
+  auto p = __builtin_amdgcn_permlane16_swap(f2bits(v), f2bits(v), false, false);
+  x = bits2f(p[0]); y = bits2f(p[1]);
+}
+__device__ __forceinline__ void swap32(float v, float& x, float& y) {
+  auto p = __builtin_amdgcn_permlane32_swap(f2bits(v), f2bits(v), false, false);
+  x = bits2f(p[0]); y = bits2f(p[1]);
+}
+__device__ __forceinline__ float sum_xor16(float v) { float x, y; swap16(v, x, y); return x + y; }
+__device__ __forceinline__ float sum_xor32(float v) { float x, y; swap32(v, x, y); return x + y; }
+__device__ __forceinline__ float max_xor16(float v) { float x, y; swap16(v, x, y); return fmaxf(x, y); }
+__device__ __forceinline__ float max_xor32(float v) { float x, y; swap32(v, x, y); return fmaxf(x, y); }
+// value held by row 0 (lanes 0-15) copied to the same column of all four rows
+__device__ __forceinline__ float bcast_row0(float v) {
+  float x, y;
+  swap16(v, x, y);        // x = [r0, r0, r2, r2]
+  swap32(x, x, y);        // x = [r0, r0, r0, r0]
+  return x;
+}
+// neighbours in lane order (lane 63 / lane 0 receive `edge`)
+__device__ __forceinline__ float lane_next(float v, float edge) { return dpp_f32<kDppWaveShl1>(edge, v); }
+__device__ __forceinline__ float lane_prev(float v, float edge) { return dpp_f32<kDppWaveShr1>(edge, v); }
+
+__device__ __forceinline__ float row_allreduce_sum(float v) {
+  v += dpp_f32<kDppQuadXor1>(0.0f, v);
+  v += dpp_f32<kDppQuadXor2>(0.0f, v);
+  v += dpp_f32<kDppRowHalfMirror>(0.0f, v);
+  v += dpp_f32<kDppRowMirror>(0.0f, v);
   return v;
 }
+__device__ __forceinline__ float wave_sum(float v) { return sum_xor32(sum_xor16(row_allreduce_sum(v))); }
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-  for (int d = 32; d >= 1; d >>= 1) v = fmaxf(v, __shfl_xor(v, d, 64));
-  return v;
+  v = fmaxf(v, dpp_f32<kDppQuadXor1>(v, v));
+  v = fmaxf(v, dpp_f32<kDppQuadXor2>(v, v));
+  v = fmaxf(v, dpp_f32<kDppRowHalfMirror>(v, v));
+  v = fmaxf(v, dpp_f32<kDppRowMirror>(v, v));
+  return max_xor32(max_xor16(v));
 }
-__device__ __forceinline__ float wave_min(float v) {
-#pragma unroll
-  for (int d = 32; d >= 1; d >>= 1) v = fminf(v, __shfl_xor(v, d, 64));
-  return v;
-}
+// inclusive scans over the 64 lanes in double: 4 in-row Hillis-Steele steps + 2 row broadcasts
 __device__ __forceinline__ double wave_incl_scan_add(double v, int lane) {
-#pragma unroll
-  for (int d = 1; d < 64; d <<= 1) {
-    double o = __shfl_up(v, d, 64);
-    if (lane >= d) v += o;
-  }
+  (void)lane;
+  v += dpp_f64<NFI_DPP_ROW_SHR(1)>(0.0, v);
+  v += dpp_f64<NFI_DPP_ROW_SHR(2)>(0.0, v);
+  v += dpp_f64<NFI_DPP_ROW_SHR(4)>(0.0, v);
+  v += dpp_f64<NFI_DPP_ROW_SHR(8)>(0.0, v);
+  v += dpp_f64<kDppRowBcast15, 0xa>(0.0, v);
+  v += dpp_f64<kDppRowBcast31, 0xc>(0.0, v);
   return v;
 }
 __device__ __forceinline__ double wave_incl_scan_mul(double v, int lane) {
-#pragma unroll
-  for (int d = 1; d < 64; d <<= 1) {
-    double o = __shfl_up(v, d, 64);
-    if (lane >= d) v *= o;
-  }
+  (void)lane;
+  v *= dpp_f64<NFI_DPP_ROW_SHR(1)>(1.0, v);
+  v *= dpp_f64<NFI_DPP_ROW_SHR(2)>(1.0, v);
+  v *= dpp_f64<NFI_DPP_ROW_SHR(4)>(1.0, v);
+  v *= dpp_f64<NFI_DPP_ROW_SHR(8)>(1.0, v);
+  v *= dpp_f64<kDppRowBcast15, 0xa>(1.0, v);
+  v *= dpp_f64<kDppRowBcast31, 0xc>(1.0, v);
   return v;
+}
+__device__ __forceinline__ double readlane_f64(double v, int l) {
+  const uint64_t b = __builtin_bit_cast(uint64_t, v);
+  const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)b, l);
+  const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(b >> 32), l);
+  return __builtin_bit_cast(double, ((uint64_t)hi << 32) | lo);
 }
 
 // Element layout for per-ray arrays of up to SPL*64 entries: element e lives in slot e/64 of
 // lane e%64.
 template <int SPL>
 __device__ __forceinline__ void next_elem(const float (&x)[SPL], float (&y)[SPL], int lane) {
+  (void)lane;
 #pragma unroll
   for (int j = 0; j < SPL; ++j) {
-    float v = __shfl_down(x[j], 1, 64);
-    if (j + 1 < SPL) {
-      float w = __shfl(x[j + 1 < SPL ? j + 1 : j], 0, 64);
-      if (lane == 63) v = w;
-    }
-    y[j] = v;
-  }
-}
-template <int SPL>
-__device__ __forceinline__ void prev_elem(const float (&x)[SPL], float (&y)[SPL], int lane, float first) {
-#pragma unroll
-  for (int j = 0; j < SPL; ++j) {
-    float v = __shfl_up(x[j], 1, 64);
-    if (j > 0) {
-      float w = __shfl(x[j > 0 ? j - 1 : 0], 63, 64);
-      if (lane == 0) v = w;
-    } else if (lane == 0) {
-      v = first;
-    }
-    y[j] = v;
+    float edge = 0.0f;
+    if (j + 1 < SPL) edge = bits2f((uint32_t)__builtin_amdgcn_readlane((int)f2bits(x[j + 1 < SPL ? j + 1 : j]), 0));
+    y[j] = lane_next(x[j], edge);
   }
 }
 
@@ -127,12 +165,9 @@ __device__ __forceinline__ void excl_cumprod(const float (&x)[SPL], float (&out)
 #pragma unroll
   for (int j = 0; j < SPL; ++j) {
     double inc = wave_incl_scan_mul((double)x[j], lane);
-    double exc = __shfl_up(inc, 1, 64);
-    if (lane == 0) exc = 1.0;
-    // the reference rounds every inclusive product to float before the next multiply would
-    // see it only through the double accumulator, i.e. it does not: keep double throughout.
+    double exc = dpp_f64<kDppWaveShr1>(1.0, inc);
     out[j] = (float)(carry * exc);
-    carry = carry * __shfl(inc, 63, 64);
+    carry = carry * readlane_f64(inc, 63);
   }
 }
 template <int SPL>
@@ -142,7 +177,7 @@ __device__ __forceinline__ void incl_cumsum(const float (&x)[SPL], float (&out)[
   for (int j = 0; j < SPL; ++j) {
     double inc = wave_incl_scan_add((double)x[j], lane);
     out[j] = (float)(carry + inc);
-    carry = carry + __shfl(inc, 63, 64);
+    carry = carry + readlane_f64(inc, 63);
   }
 }
 
@@ -402,7 +437,7 @@ __device__ __forceinline__ TileOut tile_mlp(const FieldParams& P, int lane, cons
 
   TileOut res;
   const int j = lane & 15;
-  float sdf = __shfl(o.x, j, 64);  // broadcast group 0's row 0 to all groups
+  float sdf = bcast_row0(o.x);     // group 0's output row 0 -> all four channel groups
   res.sdf = sdf;
   if (P.use_sdf) {
     // sigma = (1/alpha) * (0.5 + 0.5*sign(-d)*(1 - exp(-|d|/beta))) * (1 - outside)
@@ -425,8 +460,7 @@ __device__ __forceinline__ TileOut tile_mlp(const FieldParams& P, int lane, cons
       bool valid = (row >= 1) && (row <= A);
       m = valid ? fmaxf(m, o[r]) : m;
     }
-    m = fmaxf(m, __shfl_xor(m, 16, 64));
-    m = fmaxf(m, __shfl_xor(m, 32, 64));
+    m = max_xor32(max_xor16(m));
     const f32x4* vf = reinterpret_cast<const f32x4*>(P.vf) + g * 4;
     float se = 0.0f, sr = 0.0f, sg = 0.0f, sb = 0.0f;
     float e4[4];
@@ -442,8 +476,7 @@ __device__ __forceinline__ TileOut tile_mlp(const FieldParams& P, int lane, cons
       sg = fmaf(e, v.y, sg);
       sb = fmaf(e, v.z, sb);
     }
-    se += __shfl_xor(se, 16, 64); sr += __shfl_xor(sr, 16, 64); sg += __shfl_xor(sg, 16, 64); sb += __shfl_xor(sb, 16, 64);
-    se += __shfl_xor(se, 32, 64); sr += __shfl_xor(sr, 32, 64); sg += __shfl_xor(sg, 32, 64); sb += __shfl_xor(sb, 32, 64);
+    se = sum_xor32(sum_xor16(se)); sr = sum_xor32(sum_xor16(sr)); sg = sum_xor32(sum_xor16(sg)); sb = sum_xor32(sum_xor16(sb));
     float inv = __builtin_amdgcn_rcpf(se);
     inv = inv * (2.0f - se * inv);      // one Newton step: the quotient is then within 1 ulp
     res.r = sr * inv; res.g = sg * inv; res.b = sb * inv;
@@ -456,7 +489,7 @@ __device__ __forceinline__ TileOut tile_mlp(const FieldParams& P, int lane, cons
     }
   } else {
     // rgb = sigmoid(f)*2.004 - 1.002, features (rows 1..3 of group 0) pre-scaled by log2e
-    float r1 = __shfl(o.y, j, 64), r2 = __shfl(o.z, j, 64), r3 = __shfl(o.w, j, 64);
+    float r1 = bcast_row0(o.y), r2 = bcast_row0(o.z), r3 = bcast_row0(o.w);
     res.r = (1.0f / (1.0f + __builtin_amdgcn_exp2f(-r1))) * 2.004f - 1.002f;
     res.g = (1.0f / (1.0f + __builtin_amdgcn_exp2f(-r2))) * 2.004f - 1.002f;
     res.b = (1.0f / (1.0f + __builtin_amdgcn_exp2f(-r3))) * 2.004f - 1.002f;
@@ -474,9 +507,13 @@ struct SampleOut {
 // generator.py:633) and rgb is reported as 0 (its compositing weight is exactly 0).  Without SKIP
 // (the sampler closure) outside points get the border-clamped colour/distance the reference returns.
 // sem_base: null or global pointer to this wave's [64][A] semantics rows (written for valid points).
+// stage: 16 x 36 floats of LDS owned by this wave (feature-tile transpose).
+// prof: null, or 4 cycle accumulators {tile set-up + load issue, load wait + interpolation,
+// transpose + MLP + epilogue, tiles} filled with s_memtime deltas (profiling builds only)
 template <int TEX, bool ATT, bool SKIP>
 __device__ __forceinline__ SampleOut field_wave(const FieldParams& P, float scene_range, int lane, float px, float py,
-                                                float pz, bool valid, float* sem_base, bool* outside_flag) {
+                                                float pz, bool valid, float* sem_base, bool* outside_flag,
+                                                float* stage, unsigned long long* prof = nullptr) {
   // reference: x / scene_range, mask = any(|x| > 1)   (true division, generator.py:604-607)
   float qx = px / scene_range, qy = py / scene_range, qz = pz / scene_range;
   bool out = (fabsf(qx) > 1.0f) || (fabsf(qy) > 1.0f) || (fabsf(qz) > 1.0f);
@@ -506,27 +543,49 @@ __device__ __forceinline__ SampleOut field_wave(const FieldParams& P, float scen
   //                   addresser coalesces each lane quad into one line access (4x fewer accesses
   //                   than with the MFMA layout, whose consecutive lanes are different points);
   //   MFMA layout  M: lane = 16*g + j (j = point, g = channel group) - fixed by v_mfma_*.
-  // The 8 interpolated features are moved L -> M with 8 ds_bpermute (a 4x16 lane-grid transpose);
+  // The 16 x 32 interpolated features are moved L -> M through a small LDS tile (2 b128 writes + 2
+  // b128 reads per lane);
   // chunk q of L and channel group g of M hold the same channels, so the W1 operand image is
   // independent of this choice.
   const int lp = lane >> 2, lq = lane & 3;        // L layout
-  const int tr_src = 4 * j + g;                   // M lane (g, j) reads L lane 4j + g
 #pragma unroll 1
   for (int t = 0; t < 4; ++t) {
     if (!((tm >> t) & 1u)) continue;              // wave-uniform
+    unsigned long long c0 = prof ? __builtin_readcyclecounter() : 0;
     const int srcL = 16 * t + lp, srcM = 16 * t + j;
     const float cfx = __shfl(fx, srcL, 64), cfy = __shfl(fy, srcL, 64), cfz = __shfl(fz, srcL, 64);
     const uint32_t cxi = (uint32_t)__shfl(xi, srcL, 64);
     const int fcur = __shfl(flags, srcM, 64);
     TileTex<TEX> T;
     tile_issue<TEX>(P, lq, cxi, T);
+    unsigned long long c1 = prof ? __builtin_readcyclecounter() : 0;
     float featL[8], feat[8];
     tile_bilinear<TEX>(T, cfx, cfy, cfz, featL);
-#pragma unroll
-    for (int s8 = 0; s8 < 8; ++s8) feat[s8] = __shfl(featL[s8], tr_src, 64);
+    if (prof) { asm volatile("" :: "v"(featL[0]), "v"(featL[7])); }
+    unsigned long long c2 = prof ? __builtin_readcyclecounter() : 0;
+    // L -> M transpose of the 16 x 32 feature tile through the wave's LDS staging rows (pitch 36
+    // floats: conflict-free for both the 16-byte writes and the 16-byte reads)
+    __builtin_amdgcn_sched_barrier(0);
+    {
+      f32x4* wr = reinterpret_cast<f32x4*>(stage + lp * 36 + lq * 4);
+      wr[0] = f32x4{featL[0], featL[1], featL[2], featL[3]};
+      wr[4] = f32x4{featL[4], featL[5], featL[6], featL[7]};
+      wave_lds_fence();
+      const f32x4* rd = reinterpret_cast<const f32x4*>(stage + j * 36 + g * 4);
+      const f32x4 lo = rd[0], hi = rd[4];
+      feat[0] = lo.x; feat[1] = lo.y; feat[2] = lo.z; feat[3] = lo.w;
+      feat[4] = hi.x; feat[5] = hi.y; feat[6] = hi.z; feat[7] = hi.w;
+      wave_lds_fence();
+    }
+    __builtin_amdgcn_sched_barrier(0);
     float* sem = (sem_base && (fcur & 2)) ? sem_base + (size_t)srcM * P.n_attention : nullptr;
     TileOut to = tile_mlp<ATT>(P, lane, feat, (fcur & 1) ? 1.0f : 0.0f, sem);
     if (g == t) { so.sdf = to.sdf; so.sigma = to.sigma; so.r = to.r; so.g = to.g; so.b = to.b; }
+    if (prof) {
+      asm volatile("" :: "v"(so.sigma), "v"(so.r));
+      unsigned long long c3 = __builtin_readcyclecounter();
+      prof[0] += c1 - c0; prof[1] += c2 - c1; prof[2] += c3 - c2; prof[3] += 1;
+    }
   }
   return so;
 }

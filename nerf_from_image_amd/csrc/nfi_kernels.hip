@@ -406,6 +406,7 @@ __device__ __forceinline__ FieldParams make_field_params(const void* texels_scen
 template <int TEX, bool ATT>
 __global__ __launch_bounds__(256) void field_query_kernel(FieldKernelParams k) {
   __shared__ __attribute__((aligned(16))) float lds[kFieldLdsFloats];
+  __shared__ __attribute__((aligned(16))) float stages[4][16 * 36];
   const int scene = blockIdx.y;
   stage_field_lds(lds, k.image, k.att ? k.att + (size_t)scene * k.A * 3 : nullptr, k.A);
   __syncthreads();
@@ -423,7 +424,7 @@ __global__ __launch_bounds__(256) void field_query_kernel(FieldKernelParams k) {
     if (valid) { px = k.points[gi * 3]; py = k.points[gi * 3 + 1]; pz = k.points[gi * 3 + 2]; }
     bool out;
     float* sem = k.sem ? k.sem + ((size_t)scene * k.P + chunk * 64) * k.A : nullptr;
-    SampleOut so = field_wave<TEX, ATT, false>(P, k.scene_range, lane, px, py, pz, valid, sem, &out);
+    SampleOut so = field_wave<TEX, ATT, false>(P, k.scene_range, lane, px, py, pz, valid, sem, &out, stages[wave]);
     if (valid) {
       k.sigma[gi] = so.sigma;
       k.rgb[gi * 3] = so.r; k.rgb[gi * 3 + 1] = so.g; k.rgb[gi * 3 + 2] = so.b;
@@ -525,9 +526,8 @@ __device__ __forceinline__ float invert_cdf(const WaveSlab& slab, int M, float u
 
 // EG3D smoothing of S weights held one per lane (run.py:264-272); lanes >= S return garbage
 __device__ __forceinline__ float smooth_weights(float w, int S, int lane) {
-  float wp = __shfl_up(w, 1, 64);
-  float wn = __shfl_down(w, 1, 64);
-  if (lane == 0) wp = -INFINITY;
+  float wp = lane_prev(w, -INFINITY);
+  float wn = lane_next(w, -INFINITY);
   if (lane >= S - 1) wn = -INFINITY;
   float m0 = fmaxf(wp, w);   // max(w[k-1], w[k])
   float m1 = fmaxf(w, wn);   // max(w[k], w[k+1])
@@ -542,9 +542,9 @@ __device__ __forceinline__ float resample_ray(WaveSlab& slab, float sigma, float
   float sg[1] = {lane < S ? sigma : 0.0f}, tt[1] = {t}, w[1];
   ray_weights<1>(sg, tt, S, dnorm, lane, w);
   float sm = smooth_weights(w[0], S, lane);
-  float tn = __shfl_down(t, 1, 64);
+  float tn = lane_next(t, 0.0f);
   float mid[1] = {0.5f * (tn + t)};                       // bins e = 0..S-2
-  float wts[1] = {__shfl_down(sm, 1, 64)};                 // weights e = 0..S-3  <- smooth[e+1]
+  float wts[1] = {lane_next(sm, 0.0f)};                    // weights e = 0..S-3  <- smooth[e+1]
   build_cdf<1>(slab, mid, wts, S - 1, lane);
   int ind;
   float z = invert_cdf(slab, S - 1, u, ind);
@@ -612,7 +612,7 @@ __device__ __forceinline__ void merge_pair_scatter(WaveSlab& slab, const MergeIn
   const bool valid = lane < S;
   const uint32_t kc = valid ? ordered_key(c.t) : 0xFFFFFFFFu;
   const uint32_t kf = valid ? ordered_key(f.t) : 0xFFFFFFFFu;
-  const uint32_t kc_next = (uint32_t)__shfl_down((int)kc, 1, 64);
+  const uint32_t kc_next = f2bits(lane_next(bits2f(kc), bits2f(0xFFFFFFFFu)));
   const bool ascending = __all(lane >= S - 1 || kc <= kc_next);
   slab.key[lane] = kf;            // fine keys   [0,64)   (padding 0xFFFFFFFF ranks after everything)
   slab.key[64 + lane] = kc;       // coarse keys [64,128)
@@ -907,6 +907,7 @@ struct RenderKernelParams {
   float* t_fine; float* sigma_fine; float* rgb_fine;
   float* t_sorted; float* weights; int32_t* perm;
   int skip_missed;
+  unsigned long long* prof;
 };
 
 // Persistent kernel: one wave per ray, rays handed out by one device-scope counter (scene-major,
@@ -918,7 +919,7 @@ struct RayInputs {
   uint32_t hit;
 };
 
-template <int TEX, bool ATT, int OCC, bool TAPS>
+template <int TEX, bool ATT, int OCC, bool TAPS, bool PROF = false>
 __global__ __launch_bounds__(256, OCC) void render_fwd_kernel(RenderKernelParams k) {
   __shared__ __attribute__((aligned(16))) float lds[kImageFloats];
   __shared__ __attribute__((aligned(16))) float vfs[4][64];
@@ -957,6 +958,10 @@ __global__ __launch_bounds__(256, OCC) void render_fwd_kernel(RenderKernelParams
   cur = (uint32_t)__builtin_amdgcn_readfirstlane((int)cur);
   nxt = (uint32_t)__builtin_amdgcn_readfirstlane((int)nxt);
   RayInputs in, pre;
+  // PROF: per-wave cycle accumulators [0..3] field tiles (see field_wave), [4] ray set-up, [5] coarse field,
+  // [6] resample, [7] fine field, [8] merge, [9] composite + store, [10] rays, [11] total
+  unsigned long long pc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long tk0 = PROF ? __builtin_readcyclecounter() : 0;
   if (cur < n_rays) load_inputs(cur, in);
   while (cur < n_rays) {
     if (lane == 0) fly = atomicAdd(counter, 1u);
@@ -970,6 +975,7 @@ __global__ __launch_bounds__(256, OCC) void render_fwd_kernel(RenderKernelParams
         k.depth[ray] = 0.0f; k.mask[ray] = 0.0f;
       }
     } else {
+      unsigned long long t0 = PROF ? __builtin_readcyclecounter() : 0;
       const int scene = (int)(ray / (uint32_t)k.hw);
       if (scene != cur_scene) {
         cur_scene = scene;
@@ -994,20 +1000,23 @@ __global__ __launch_bounds__(256, OCC) void render_fwd_kernel(RenderKernelParams
       float tc = 0.0f;
       if (valid) tc = stratified_depth(near, far, lane, S, in.noise, k.noise_c != nullptr);
       MergeIn c;
+      unsigned long long t1 = PROF ? __builtin_readcyclecounter() : 0;
       {
         SampleOut q = field_wave<TEX, ATT, true>(P, k.scene_range, lane, ox + dx * tc, oy + dy * tc, oz + dz * tc, valid,
-                                                 nullptr, nullptr);
+                                                 nullptr, nullptr, &slab.srt[0][0], PROF ? pc : nullptr);
         c.t = tc; c.sigma = q.sigma; c.r = q.r; c.g = q.g; c.b = q.b;
       }
       int n = S;
       int rank_c = lane, rank_f = 0;
+      unsigned long long t2 = PROF ? __builtin_readcyclecounter() : 0, t3 = t2, t4 = t2, t5 = t2;
       if (k.fine) {
         // ---- hierarchical resampling + fine pass ----
         const float tf = resample_ray(slab, c.sigma, tc, S, dnorm, in.u, lane, nullptr);
         MergeIn f;
+        if (PROF) { asm volatile("" :: "v"(tf)); t3 = __builtin_readcyclecounter(); }
         {
           SampleOut q = field_wave<TEX, ATT, true>(P, k.scene_range, lane, ox + dx * tf, oy + dy * tf, oz + dz * tf, valid,
-                                                   nullptr, nullptr);
+                                                   nullptr, nullptr, &slab.srt[0][0], PROF ? pc : nullptr);
           f.t = tf; f.sigma = q.sigma; f.r = q.r; f.g = q.g; f.b = q.b;
         }
         if constexpr (TAPS) {
@@ -1018,7 +1027,9 @@ __global__ __launch_bounds__(256, OCC) void render_fwd_kernel(RenderKernelParams
           }
         }
         n = 2 * S;
+        if (PROF) t4 = __builtin_readcyclecounter();
         merge_pair_scatter(slab, c, f, S, lane, rank_c, rank_f);
+        if (PROF) t5 = __builtin_readcyclecounter();
       } else {
         if (valid) { slab.srt[0][lane] = c.t; slab.srt[1][lane] = c.sigma; slab.srt[2][lane] = c.r; slab.srt[3][lane] = c.g; slab.srt[4][lane] = c.b; }
         wave_lds_fence();
@@ -1053,10 +1064,18 @@ __global__ __launch_bounds__(256, OCC) void render_fwd_kernel(RenderKernelParams
         }
       }
       wave_lds_fence();  // slab is reused by the next ray
+      if (PROF) {
+        unsigned long long t6 = __builtin_readcyclecounter();
+        pc[4] += t1 - t0; pc[5] += t2 - t1; pc[6] += t3 - t2; pc[7] += t4 - t3; pc[8] += t5 - t4; pc[9] += t6 - t5; pc[10] += 1;
+      }
     }
     in = pre;
     cur = nxt;
     nxt = (uint32_t)__builtin_amdgcn_readfirstlane((int)fly);
+  }
+  if (PROF && k.prof && lane == 0) {
+    pc[11] = __builtin_readcyclecounter() - tk0;
+    for (int i = 0; i < 12; ++i) atomicAdd(k.prof + i, pc[i]);
   }
 }
 
@@ -1110,6 +1129,7 @@ extern "C" int nfi_render_fwd(const nfi_render_args* a, nfi_stream_t stream) {
   k.skip_missed = (a->skip_missed_rays && !any_tap) ? 1 : 0;
 
   k.counter = reduce + 3;
+  k.prof = (unsigned long long*)a->profile_cycles;
   // persistent 1-D grid: OCC blocks of 4 waves per CU, never more blocks than rays need
   int occ = a->tuning & 3;               // 0 = default
   if (occ == 0) occ = 3;
@@ -1121,7 +1141,8 @@ extern "C" int nfi_render_fwd(const nfi_render_args* a, nfi_stream_t stream) {
   if (a->event_start) (void)hipEventRecord((hipEvent_t)a->event_start, s);
 #define NFI_LAUNCH_RENDER(TEX, ATT)                                                                        \
   do {                                                                                                     \
-    if (any_tap) hipLaunchKernelGGL((render_fwd_kernel<TEX, ATT, 2, true>), grid, dim3(256), 0, s, k);          \
+    if (k.prof) hipLaunchKernelGGL((render_fwd_kernel<TEX, ATT, 3, false, true>), grid, dim3(256), 0, s, k);     \
+    else if (any_tap) hipLaunchKernelGGL((render_fwd_kernel<TEX, ATT, 2, true>), grid, dim3(256), 0, s, k);     \
     else if (occ == 2) hipLaunchKernelGGL((render_fwd_kernel<TEX, ATT, 2, false>), grid, dim3(256), 0, s, k);   \
     else if (occ == 3) hipLaunchKernelGGL((render_fwd_kernel<TEX, ATT, 3, false>), grid, dim3(256), 0, s, k);   \
     else hipLaunchKernelGGL((render_fwd_kernel<TEX, ATT, 4, false>), grid, dim3(256), 0, s, k);                 \

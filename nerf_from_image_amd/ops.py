@@ -259,7 +259,7 @@ TAP_NAMES = ('ray_origins', 'ray_directions', 'near_plane', 'far_plane', 'hit', 
 def render_fwd(cam2world, focal, height, width, num_samples, texels, decoder_image, scene_range, n_attention,
                attention_values=None, use_sdf=True, beta=None, alpha=None, bbox=None, center=None,
                noise_coarse=None, noise_fine=None, fine_sampling=True, white_background=True, taps=(),
-               skip_missed_rays=True, workspace=None, events=None, tuning=0):
+               skip_missed_rays=True, workspace=None, events=None, tuning=0, profile_cycles=None):
     """Fused forward render.  Returns dict(rgb [B,H,W,3], depth, mask [B,H,W], + requested taps)."""
     cam2world = _f32c(cam2world, 'tform_cam2world')
     B = cam2world.shape[0]
@@ -311,7 +311,7 @@ def render_fwd(cam2world, focal, height, width, num_samples, texels, decoder_ima
             noise_fine=u, noise_fine_row_stride=ustride, rgb=out['rgb'], depth=out['depth'], mask=out['mask'],
             workspace=workspace, workspace_bytes=workspace.numel(), skip_missed_rays=int(skip_missed_rays),
             event_start=None if events is None else events[0], event_stop=None if events is None else events[1],
-            tuning=int(tuning), **tap_t)
+            tuning=int(tuning), profile_cycles=profile_cycles, **tap_t)
     out.update(tap_t)
     out['_workspace'] = workspace
     return out

@@ -128,9 +128,12 @@ def test_sampling_stages(case):
     close(taps['cdf'], o['cdf'], 1e-6, 'cdf')
     # indices: bit-exact against searchsorted on the kernel's own cdf (identical float inputs) ...
     exact(taps['inds'], torch.searchsorted(taps['cdf'].contiguous(), u.contiguous(), right=True), 'searchsorted indices')
-    # ... and within the flip budget against the reference end to end
+    # ... and within the flip budget against the reference end to end.  Deterministic u (linspace)
+    # lands exactly on cdf break points of flat pdfs, where a 1-ulp difference in the pdf
+    # normalisation (a float sum whose order no two implementations share) flips the index while
+    # the sample itself moves by an ulp; the budget is wider there and the samples are checked below.
     flips = (taps['inds'].cpu() != o['inds']).float().mean().item()
-    assert flips <= 1e-3, flips
+    assert flips <= (1e-3 if meta['randomize'] else 2e-2), flips
     close(fine, o['t_fine'].flatten(0, 2), 1e-5, 'fine depths')
     # stand-alone sample_pdf on the oracle's exact inputs
     mid = (.5 * (o['t_coarse'][..., 1:] + o['t_coarse'][..., :-1])).flatten(0, 2)
