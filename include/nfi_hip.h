@@ -239,6 +239,65 @@ typedef struct nfi_composite_args {
 int nfi_composite_fwd(const nfi_composite_args* a, nfi_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Backward of the per-ray stages (the reference gets these from autograd).
+ * Gradients flow to sigma, rgb, extras and (through dists*||rd||) the ray directions; depth samples
+ * and depth_map carry none (lib/nerf_utils.py:145, run.py:197-200, 261).
+ * ------------------------------------------------------------------------------------------ */
+typedef struct nfi_composite_bwd_args {
+  int64_t n_rays;
+  int n_a; int n_b;             /* as nfi_composite_args */
+  const float* ray_directions;
+  const float* depth_a; const float* sigma_a; const float* rgb_a;
+  const float* depth_b; const float* sigma_b; const float* rgb_b;
+  int n_extra; const float* extra_a; const float* extra_b;
+  int white_background;
+  const float* g_rgb_map;    /* [N,3] upstream gradient */
+  const float* g_mask;       /* [N] or NULL */
+  const float* g_extra_map;  /* [N,n_extra] or NULL */
+  float* g_sigma_a; float* g_rgb_a;   /* [N,n_a], [N,n_a,3] out */
+  float* g_sigma_b; float* g_rgb_b;   /* [N,n_b], [N,n_b,3] out (n_b > 0) */
+  float* g_extra_a; float* g_extra_b; /* out or NULL */
+  float* g_ray_directions;            /* [N,3] out or NULL */
+} nfi_composite_bwd_args;
+int nfi_composite_bwd(const nfi_composite_bwd_args* a, nfi_stream_t stream);
+/* x = o + d*t: g_points [N,S,3], depth [N,S] -> g_ray_origins [N,3], g_ray_directions [N,3] (either may be NULL) */
+int nfi_points_bwd(const float* g_points, const float* depth, int64_t n_rays, int n_samples,
+                   float* g_ray_origins, float* g_ray_directions, nfi_stream_t stream);
+/* nfi_raygen backward: g_ray_origins / g_ray_directions [N,3] (either may be NULL) ->
+ * g_cam2world [B,4,4] (zeroed inside), g_focal [B] or NULL.  a->ray_origins/ray_directions are ignored. */
+int nfi_raygen_bwd(const nfi_raygen_args* a, const float* g_ray_origins, const float* g_ray_directions,
+                   float* g_cam2world, float* g_focal, nfi_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Field query backward: autograd of the sampler closure (models/generator.py:587-681), i.e.
+ * grid_sample backward (scatter-add into the planes + coordinate gradients), the decoder MLP, the
+ * Laplace-CDF density and the colour head, with the forward recomputed per tile.
+ *   upstream: g_sigma [B,P], g_rgb [B,P,3], optional g_sdf [B,P], g_semantics [B,P,A]
+ *   results : g_texels [B,3,R,R,32] (ACCUMULATED: caller zeroes it; convert with nfi_texels_to_planes),
+ *             g_w1 [64,32], g_b1 [64], g_w2 [n_out,64], g_b2 [n_out], g_attention_values [B,A,3],
+ *             g_beta [1], g_alpha [1] (all ACCUMULATED into caller-zeroed buffers, raw-parameter
+ *             gradients with the equalized-lr gains applied), g_points [B,P,3] or NULL (written).
+ * ------------------------------------------------------------------------------------------ */
+typedef struct nfi_field_bwd_args {
+  int n_scenes;
+  int64_t points_per_scene;
+  const float* points;
+  const void* texels; int plane_res; int texel_dtype;   /* fp32 texels only */
+  const float* decoder_image;                            /* forward operand image */
+  const float* w1; const float* w2;                      /* raw decoder weights (backward operands) */
+  int n_attention; const float* attention_values;
+  int use_sdf; const float* beta; const float* alpha;
+  float scene_range;
+  const float* g_sigma; const float* g_rgb; const float* g_sdf; const float* g_semantics;
+  float* g_texels; float* g_points;
+  float* g_w1; float* g_b1; float* g_w2; float* g_b2;
+  float* g_attention_values; float* g_beta; float* g_alpha;
+  void* workspace; size_t workspace_bytes;               /* >= nfi_decoder_bwd_image_floats()*4 bytes */
+} nfi_field_bwd_args;
+size_t nfi_decoder_bwd_image_floats(void);
+int nfi_field_query_bwd(const nfi_field_bwd_args* a, nfi_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
  * Fused forward render: run.py::render (176-350) from cameras + texels to pixels in one
  * persistent launch (plus the ray set-up launch), no per-sample HBM round trips.
  * ------------------------------------------------------------------------------------------ */

@@ -1,34 +1,23 @@
 """Autograd glue between the HIP kernels and PyTorch.
 
 Every host-level op goes through :func:`differentiable`: the forward runs the HIP kernel(s); if
-any input requires grad, the call is recorded as one autograd node whose backward is looked up in
-``BACKWARD`` (filled in by the modules that own backward kernels).  An op without a registered
-backward fails loudly when a gradient is actually requested, it never falls back to ATen.
+any input requires grad, the call is recorded as ONE autograd node whose backward is the ``bwd``
+closure handed in by the op (it launches the HIP backward kernels).  An op without a backward
+fails loudly when a gradient is actually requested; nothing ever falls back to ATen.
 """
 import torch
-
-BACKWARD = {}
-
-
-def register_backward(name):
-    def deco(fn):
-        BACKWARD[name] = fn
-        return fn
-    return deco
 
 
 class _HipNode(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, name, fn, nondiff, n_in, *tensors):
+    def forward(ctx, name, fn, bwd, nondiff, *tensors):
         ctx.name = name
-        ctx.present = [t is not None for t in tensors]
+        ctx.bwd = bwd
         with torch.no_grad():
             out = fn(*tensors)
-        single = not isinstance(out, tuple)
-        outs = (out,) if single else out
-        ctx.single = single
-        ctx.saved_inputs = tensors
-        ctx.saved_outputs = outs
+        outs = (out,) if not isinstance(out, tuple) else out
+        ctx.inputs = tensors
+        ctx.outputs = outs
         nd = [outs[i] for i in nondiff if i < len(outs) and outs[i] is not None]
         nd += [o for o in outs if o is not None and not o.dtype.is_floating_point]
         if nd:
@@ -37,19 +26,27 @@ class _HipNode(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, *grads):
-        bw = BACKWARD.get(ctx.name)
-        if bw is None:
+        if ctx.bwd is None:
             raise NotImplementedError(
-                'nerf_from_image_amd: no HIP backward is registered for %s yet (forward-only op); '
-                'wrap the call in torch.no_grad() or detach its inputs' % ctx.name)
-        gin = bw(ctx, *grads)
-        return (None, None, None, None) + tuple(gin)
+                'nerf_from_image_amd: %s has no HIP backward (forward-only op); wrap the call in '
+                'torch.no_grad() or detach its inputs' % ctx.name)
+        with torch.no_grad():
+            gin = ctx.bwd(ctx.inputs, ctx.outputs, grads, ctx.needs_input_grad[4:])
+        gin = tuple(g if need else None for g, need in zip(gin, ctx.needs_input_grad[4:]))
+        return (None, None, None, None) + gin
 
 
-def differentiable(name, fn, *tensors, non_differentiable_outputs=()):
-    """Runs fn(*tensors) (HIP kernels).  Records an autograd node only when needed."""
+def differentiable(name, fn, *tensors, bwd=None, non_differentiable_outputs=()):
+    """Runs fn(*tensors) (HIP kernels).  Records an autograd node only when a gradient can be asked for.
+
+    bwd(inputs, outputs, grad_outputs, needs) -> tuple of gradients, one per input (None allowed)."""
     needs = torch.is_grad_enabled() and any(t is not None and torch.is_tensor(t) and t.requires_grad for t in tensors)
     if not needs:
         with torch.no_grad():
             return fn(*tensors)
-    return _HipNode.apply(name, fn, tuple(non_differentiable_outputs), len(tensors), *tensors)
+    return _HipNode.apply(name, fn, bwd, tuple(non_differentiable_outputs), *tensors)
+
+
+def zeros_like_or(g, ref):
+    """Autograd hands None for outputs nobody used; kernels want dense tensors."""
+    return torch.zeros_like(ref) if g is None else g.contiguous()

@@ -882,6 +882,9 @@ extern "C" int nfi_composite_fwd(const nfi_composite_args* a, nfi_stream_t strea
   return check_launch("composite_fwd");
 }
 
+#include "nfi_backward_rays.inc"
+#include "nfi_backward_field.inc"
+
 // ------------------------------------------------------------------------------------------------
 // fused forward render
 // ------------------------------------------------------------------------------------------------

@@ -1,0 +1,63 @@
+"""Tensor-level wrapper of nfi_field_query_bwd and the autograd closure of the sampler's field query."""
+import torch
+
+from . import _lib, ops
+
+
+def field_query_bwd(points, texels, decoder_image, w1, w2, scene_range, n_attention, attention_values, use_sdf, beta,
+                    alpha, g_sigma, g_rgb, g_sdf=None, g_semantics=None, want_points=False):
+    """Returns dict(g_texels [B,3,R,R,32], g_w1, g_b1, g_w2, g_b2, g_attention_values?, g_beta?, g_alpha?, g_points?)."""
+    f = ops._f32c
+    points = f(points, 'points')
+    B, P = points.shape[0], points.shape[1]
+    dev = points.device
+    if texels.dtype != torch.float32:
+        raise TypeError('field_query_bwd: gradients need fp32 texels')
+    n_out = 1 + n_attention if n_attention > 0 else 4
+    lib = _lib.load()
+    out = {'g_texels': torch.zeros_like(texels),
+           'g_w1': torch.zeros((64, 32), dtype=torch.float32, device=dev),
+           'g_b1': torch.zeros((64,), dtype=torch.float32, device=dev),
+           'g_w2': torch.zeros((n_out, 64), dtype=torch.float32, device=dev),
+           'g_b2': torch.zeros((n_out,), dtype=torch.float32, device=dev)}
+    if n_attention > 0:
+        out['g_attention_values'] = torch.zeros((B, n_attention, 3), dtype=torch.float32, device=dev)
+    if use_sdf:
+        out['g_beta'] = torch.zeros((1,), dtype=torch.float32, device=dev)
+        out['g_alpha'] = torch.zeros((1,), dtype=torch.float32, device=dev)
+    if want_points:
+        out['g_points'] = torch.zeros((B, P, 3), dtype=torch.float32, device=dev)
+    ws = torch.empty((lib.nfi_decoder_bwd_image_floats(),), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        _lib.call_struct(
+            'nfi_field_query_bwd', 'nfi_field_bwd_args', ops._stream(points), n_scenes=B, points_per_scene=P,
+            points=points, texels=texels, plane_res=texels.shape[2], texel_dtype=ops.TEXEL_F32,
+            decoder_image=decoder_image, w1=f(w1, 'w1'), w2=f(w2, 'w2'), n_attention=n_attention,
+            attention_values=f(attention_values, 'attention_values') if n_attention > 0 else None,
+            use_sdf=int(use_sdf), beta=f(beta, 'beta') if use_sdf else None, alpha=f(alpha, 'alpha') if use_sdf else None,
+            scene_range=float(scene_range), g_sigma=f(g_sigma, 'g_sigma'), g_rgb=f(g_rgb, 'g_rgb'),
+            g_sdf=f(g_sdf, 'g_sdf'), g_semantics=f(g_semantics, 'g_semantics'), workspace=ws,
+            workspace_bytes=ws.numel() * 4, **out)
+    return out
+
+
+def make_field_bwd(texels, decoder_image, scene_range, n_attention, use_sdf, want_sdf, want_sem):
+    """Backward closure for ``autograd.differentiable('field_query', ...)``.
+    inputs = (points, planes, w1, b1, w2, b2, attention_values, beta, alpha); outputs = (sigma, rgb[, sdf][, semantics])."""
+    def bwd(inputs, outputs, grads, needs):
+        pts, planes, w1, b1, w2, b2, att, be, al = inputs
+        g_sigma = torch.zeros_like(outputs[0]) if grads[0] is None else grads[0]
+        g_rgb = torch.zeros_like(outputs[1]) if grads[1] is None else grads[1]
+        i = 2
+        g_sdf = g_sem = None
+        if want_sdf:
+            g_sdf = grads[i]
+            i += 1
+        if want_sem:
+            g_sem = grads[i]
+        g = field_query_bwd(pts, texels, decoder_image, w1, w2, scene_range, n_attention, att, use_sdf, be, al,
+                            g_sigma, g_rgb, g_sdf, g_sem, want_points=bool(needs[0]))
+        g_planes = ops.texels_to_planes(g['g_texels']) if needs[1] else None
+        return (g.get('g_points'), g_planes, g['g_w1'], g['g_b1'], g['g_w2'], g['g_b2'],
+                g.get('g_attention_values'), g.get('g_beta'), g.get('g_alpha'))
+    return bwd

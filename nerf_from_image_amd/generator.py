@@ -26,6 +26,7 @@ import torch
 
 from . import ops
 from .autograd import differentiable
+from .field_backward import make_field_bwd
 
 REQUIRED_ATTRS = ('scene_range', 'attention_values', 'use_sdf', 'use_viewdir', 'use_encoder', 'num_classes',
                   'mapping_network', 'synthesis_network', 'decoder')
@@ -92,9 +93,12 @@ def make_sampler(planes, decoder, scene_range, n_attention, attention_values, us
                                 want_sdf=want_sdf, want_semantics=want_sem)
             return tuple(q[k] for k in ('sigma', 'rgb') + (('sdf',) if want_sdf else ()) +
                          (('semantics',) if want_sem else ()))
+        bwd = None
+        if texel_dtype == ops.TEXEL_F32:
+            bwd = make_field_bwd(texels, image, scene_range, n_attention, use_sdf, want_sdf, want_sem)
         res = differentiable('field_query', fwd, pts, planes, w1, b1, w2, b2,
                              attention_values if n_attention > 0 else None,
-                             beta if use_sdf else None, alpha if use_sdf else None)
+                             beta if use_sdf else None, alpha if use_sdf else None, bwd=bwd)
         out = {}
         i = 2
         if want_sdf:

@@ -1,5 +1,6 @@
 """Drop-in for the reference's ``lib/nerf_utils.py`` (same names, same positional/keyword
-arguments, same shapes), every function running as HIP kernels through the C ABI.
+arguments, same shapes), every function running as HIP kernels through the C ABI, forward and
+backward.
 
 Reference lines: cumprod_exclusive 20-25, get_ray_bundle 28-91, compute_query_points_from_rays
 94-120, render_volume_density 123-161, render_volume_density_weights_only 164-180, sample_pdf
@@ -9,13 +10,17 @@ Randomness: like the reference, ``compute_query_points_from_rays(randomize=True)
 ``torch.rand`` of shape [..., S] and ``sample_pdf(deterministic=False)`` draws ``torch.rand([N, K])``
 on the rays' device (same shapes and order, hence the same Philox stream as the reference's
 PyTorch-ROCm run); the noise is then handed to the kernels.
+
+Gradients: as in the reference's autograd graph, depth samples and depth_map carry none;
+rgb/mask/extra maps differentiate w.r.t. sigma, rgb, extras and the ray directions; query points
+differentiate w.r.t. ray origins/directions; rays w.r.t. tform_cam2world and focal_length.
 """
 from typing import Optional
 
 import torch
 
 from . import ops
-from .autograd import differentiable
+from .autograd import differentiable, zeros_like_or
 
 
 def cumprod_exclusive(tensor: torch.Tensor) -> torch.Tensor:
@@ -26,29 +31,34 @@ def cumprod_exclusive(tensor: torch.Tensor) -> torch.Tensor:
     return torch.cat((ones, torch.cumprod(tensor[..., :-1], dim=-1)), dim=-1)
 
 
+def _ray_bundle(name, height, width, focal_length, tform_cam2world, bbox, center, normalize):
+    def fwd(cam, focal, bb, cen):
+        return ops.raygen(height, width, focal, cam, bb, cen, normalize=normalize)
+
+    def bwd(inputs, outputs, grads, needs):
+        cam, focal, bb, cen = inputs
+        g_ro, g_rd = grads
+        if g_ro is None and g_rd is None:
+            return None, None, None, None
+        g_cam, g_focal = ops.raygen_bwd(height, width, focal, cam, bb, cen, normalize,
+                                        None if g_ro is None else g_ro.contiguous(),
+                                        None if g_rd is None else g_rd.contiguous())
+        return g_cam, g_focal, None, None
+    return differentiable(name, fwd, tform_cam2world, focal_length, bbox, center, bwd=bwd)
+
+
 def get_ray_bundle(height: int, width: int, focal_length: Optional[torch.Tensor], tform_cam2world: torch.Tensor,
                    bbox: Optional[torch.Tensor], center: Optional[torch.Tensor] = None):
     """Returns (ray_origins, ray_directions), each [B,H,W,3]; directions are NOT normalised
     (the caller normalises, run.py:196).  focal_length=None selects the orthographic model."""
-    def fwd(cam, focal, bb, cen):
-        return ops.raygen(height, width, focal, cam, bb, cen, normalize=False)
-    return differentiable('get_ray_bundle', fwd, tform_cam2world, focal_length, bbox, center)
+    return _ray_bundle('get_ray_bundle', height, width, focal_length, tform_cam2world, bbox, center, False)
 
 
 def get_ray_bundle_normalized(height: int, width: int, focal_length: Optional[torch.Tensor],
                               tform_cam2world: torch.Tensor, bbox: Optional[torch.Tensor],
                               center: Optional[torch.Tensor] = None):
     """get_ray_bundle followed by F.normalize(ray_directions, dim=-1) (run.py:193-196) in one launch."""
-    def fwd(cam, focal, bb, cen):
-        return ops.raygen(height, width, focal, cam, bb, cen, normalize=True)
-    return differentiable('get_ray_bundle_normalized', fwd, tform_cam2world, focal_length, bbox, center)
-
-
-def points_on_rays(ray_origins: torch.Tensor, ray_directions: torch.Tensor, depth_values: torch.Tensor):
-    """ray_origins[..., None, :] + ray_directions[..., None, :] * depth[..., :, None] (run.py:286-288)."""
-    def fwd(ro, rd):
-        return ops.points_on_rays(ro, rd, depth_values.detach())
-    return differentiable('points_on_rays', fwd, ray_origins, ray_directions)
+    return _ray_bundle('get_ray_bundle_normalized', height, width, focal_length, tform_cam2world, bbox, center, True)
 
 
 def compute_near_far_planes(ray_origins: torch.Tensor, ray_directions: torch.Tensor, scene_range: float):
@@ -58,6 +68,15 @@ def compute_near_far_planes(ray_origins: torch.Tensor, ray_directions: torch.Ten
     return near, far
 
 
+def _points_bwd(depth):
+    def bwd(inputs, outputs, grads, needs):
+        g_points = grads[0]
+        if g_points is None:
+            return None, None
+        return ops.points_bwd(g_points.contiguous(), depth, want_ro=True, want_rd=True)
+    return bwd
+
+
 def compute_query_points_from_rays(ray_origins: torch.Tensor, ray_directions: torch.Tensor, near_thresh: torch.Tensor,
                                    far_thresh: torch.Tensor, num_samples: int, randomize: bool = True):
     """Returns (query_points [...,S,3], depth_values [...,S])."""
@@ -65,14 +84,24 @@ def compute_query_points_from_rays(ray_origins: torch.Tensor, ray_directions: to
         raise NotImplementedError('per-batch scalar near/far planes are not used by run.py::render and not supported')
     noise = torch.rand((*near_thresh.shape, num_samples), dtype=torch.float32, device=near_thresh.device) \
         if randomize else None
+    # depth first (no gradient), then the points as a differentiable function of the rays
+    _, depth = ops.stratified_points(ray_origins.detach(), ray_directions.detach(), near_thresh.detach(),
+                                     far_thresh.detach(), num_samples, noise, want_points=False)
+    return points_on_rays(ray_origins, ray_directions, depth), depth
+
+
+def points_on_rays(ray_origins: torch.Tensor, ray_directions: torch.Tensor, depth_values: torch.Tensor):
+    """ray_origins[..., None, :] + ray_directions[..., None, :] * depth[..., :, None] (run.py:286-288)."""
+    depth = depth_values.detach()
 
     def fwd(ro, rd):
-        return ops.stratified_points(ro, rd, near_thresh.detach(), far_thresh.detach(), num_samples, noise)
-    return differentiable('compute_query_points_from_rays', fwd, ray_origins, ray_directions)
+        return ops.points_on_rays(ro, rd, depth)
+    return differentiable('points_on_rays', fwd, ray_origins, ray_directions, bwd=_points_bwd(depth))
 
 
 def render_volume_density_weights_only(sigma_a: torch.Tensor, ray_origins: torch.Tensor, ray_directions: torch.Tensor,
                                        depth_values: torch.Tensor) -> torch.Tensor:
+    """Per-sample weights.  run.py calls this under no_grad (run.py:261); no backward is provided."""
     def fwd(sig, rd, dep):
         return ops.ray_weights(sig, rd, dep)
     return differentiable('render_volume_density_weights_only', fwd, sigma_a, ray_directions, depth_values)
@@ -91,55 +120,61 @@ def sample_pdf(bins, weights, num_samples: int, deterministic: bool = False) -> 
     return samples
 
 
-def render_volume_density(sigma_a: torch.Tensor, rgb: torch.Tensor, ray_origins: torch.Tensor,
-                          ray_directions: torch.Tensor, depth_values: torch.Tensor,
-                          normals: Optional[torch.Tensor] = None, semantics: Optional[torch.Tensor] = None,
-                          white_background: bool = True):
-    """Returns (rgb_map, depth_map, mask, normal_map, semantic_map)."""
-    extras = [t for t in (normals, semantics) if t is not None]
-    n_norm = normals.shape[-1] if normals is not None else 0
-
-    def fwd(sig, col, rd, dep, *ex):
-        extra = torch.cat(ex, dim=-1) if len(ex) > 1 else (ex[0] if ex else None)
-        rgb_map, depth_map, mask, extra_map, _ = ops.composite(rd, dep, sig, col, extra_a=extra,
-                                                               white_background=white_background)
-        return (rgb_map, depth_map, mask) + ((extra_map,) if extra_map is not None else ())
-    out = differentiable('render_volume_density', fwd, sigma_a, rgb, ray_directions, depth_values, *extras,
-                         non_differentiable_outputs=(1,))
-    rgb_map, depth_map, mask = out[0], out[1], out[2]
-    normal_map = semantic_map = None
-    if extras:
-        extra_map = out[3]
-        if normals is not None:
-            normal_map = extra_map[..., :n_norm]
-            if white_background:
-                normal_map = normal_map + (1. - mask[..., None])
-        if semantics is not None:
-            semantic_map = extra_map[..., n_norm:]
-    return rgb_map, depth_map, mask, normal_map, semantic_map
-
-
-def merge_and_composite(ray_directions, depth_a, sigma_a, rgb_a, depth_b, sigma_b, rgb_b, normals_a=None,
-                        normals_b=None, extra_a=None, extra_b=None, white_background=True):
-    """The sort/merge of run.py:283-335 fused with render_volume_density: the coarse (a) and fine (b)
-    sample lists are merged by depth inside the kernel (stable, a first on ties) and composited.
-    Returns (rgb_map, depth_map, mask, normal_map, extra_map)."""
+def _composite(name, ray_directions, depth_a, sigma_a, rgb_a, depth_b, sigma_b, rgb_b, normals_a, normals_b,
+               extra_a, extra_b, white_background):
+    """Shared body of render_volume_density (one list) and merge_and_composite (two lists)."""
+    two = depth_b is not None
     ex_a = [t for t in (normals_a, extra_a) if t is not None]
-    ex_b = [t for t in (normals_b, extra_b) if t is not None]
+    ex_b = [t for t in (normals_b, extra_b) if t is not None] if two else []
     n_norm = normals_a.shape[-1] if normals_a is not None else 0
     n_ex = len(ex_a)
+    da = depth_a.detach()
+    db = depth_b.detach() if two else None
 
-    def fwd(rd, sa, ca, sb, cb, *ex):
+    def split(args):
+        rd, sa, ca = args[0], args[1], args[2]
+        sb, cb = (args[3], args[4]) if two else (None, None)
+        ex = args[5:] if two else args[3:]
         ea = eb = None
         if n_ex:
             ea = torch.cat(ex[:n_ex], dim=-1) if n_ex > 1 else ex[0]
-            eb = torch.cat(ex[n_ex:], dim=-1) if n_ex > 1 else ex[n_ex]
-        rgb_map, depth_map, mask, extra_map, _ = ops.composite(
-            rd, depth_a.detach(), sa, ca, depth_b.detach(), sb, cb, extra_a=ea, extra_b=eb,
-            white_background=white_background)
+            if two:
+                eb = torch.cat(ex[n_ex:], dim=-1) if n_ex > 1 else ex[n_ex]
+        return rd, sa, ca, sb, cb, ea, eb
+
+    def fwd(*args):
+        rd, sa, ca, sb, cb, ea, eb = split(args)
+        rgb_map, depth_map, mask, extra_map, _ = ops.composite(rd, da, sa, ca, db, sb, cb, extra_a=ea, extra_b=eb,
+                                                               white_background=white_background)
         return (rgb_map, depth_map, mask) + ((extra_map,) if extra_map is not None else ())
-    out = differentiable('merge_and_composite', fwd, ray_directions, sigma_a, rgb_a, sigma_b, rgb_b, *ex_a, *ex_b,
-                         non_differentiable_outputs=(1,))
+
+    def bwd(inputs, outputs, grads, needs):
+        rd, sa, ca, sb, cb, ea, eb = split(inputs)
+        g_rgb = zeros_like_or(grads[0], outputs[0])
+        g_mask = None if grads[2] is None else grads[2].contiguous()
+        g_ex = None
+        if n_ex and len(grads) > 3 and grads[3] is not None:
+            g_ex = grads[3].contiguous()
+        g = ops.composite_bwd(rd, da, sa, ca, g_rgb, g_mask, db, sb, cb, ea, eb, g_ex, white_background, want_rd=True)
+        out = [g['g_ray_directions'], g['g_sigma_a'], g['g_rgb_a']]
+        if two:
+            out += [g['g_sigma_b'], g['g_rgb_b']]
+
+        def unsplit(ge, parts):
+            if ge is None:
+                return [None] * len(parts)
+            if len(parts) == 1:
+                return [ge]
+            sizes = [p.shape[-1] for p in parts]
+            return list(torch.split(ge, sizes, dim=-1))
+        if n_ex:
+            out += unsplit(g.get('g_extra_a'), ex_a)
+            if two:
+                out += unsplit(g.get('g_extra_b'), ex_b)
+        return tuple(out)
+
+    tensors = [ray_directions, sigma_a, rgb_a] + ([sigma_b, rgb_b] if two else []) + ex_a + ex_b
+    out = differentiable(name, fwd, *tensors, bwd=bwd, non_differentiable_outputs=(1,))
     rgb_map, depth_map, mask = out[0], out[1], out[2]
     normal_map = extra_map = None
     if n_ex:
@@ -151,3 +186,21 @@ def merge_and_composite(ray_directions, depth_a, sigma_a, rgb_a, depth_b, sigma_
         if extra_a is not None:
             extra_map = em[..., n_norm:]
     return rgb_map, depth_map, mask, normal_map, extra_map
+
+
+def render_volume_density(sigma_a: torch.Tensor, rgb: torch.Tensor, ray_origins: torch.Tensor,
+                          ray_directions: torch.Tensor, depth_values: torch.Tensor,
+                          normals: Optional[torch.Tensor] = None, semantics: Optional[torch.Tensor] = None,
+                          white_background: bool = True):
+    """Returns (rgb_map, depth_map, mask, normal_map, semantic_map)."""
+    return _composite('render_volume_density', ray_directions, depth_values, sigma_a, rgb, None, None, None,
+                      normals, None, semantics, None, white_background)
+
+
+def merge_and_composite(ray_directions, depth_a, sigma_a, rgb_a, depth_b, sigma_b, rgb_b, normals_a=None,
+                        normals_b=None, extra_a=None, extra_b=None, white_background=True):
+    """The sort/merge of run.py:283-335 fused with render_volume_density: the coarse (a) and fine (b)
+    sample lists are merged by depth inside the kernel (stable, a first on ties) and composited.
+    Returns (rgb_map, depth_map, mask, normal_map, extra_map)."""
+    return _composite('merge_and_composite', ray_directions, depth_a, sigma_a, rgb_a, depth_b, sigma_b, rgb_b,
+                      normals_a, normals_b, extra_a, extra_b, white_background)

@@ -315,3 +315,69 @@ def render_fwd(cam2world, focal, height, width, num_samples, texels, decoder_ima
     out.update(tap_t)
     out['_workspace'] = workspace
     return out
+
+
+# --------------------------------------------------------------------------- #
+# backward wrappers
+# --------------------------------------------------------------------------- #
+def composite_bwd(ray_directions, depth_a, sigma_a, rgb_a, g_rgb_map, g_mask=None, depth_b=None, sigma_b=None,
+                  rgb_b=None, extra_a=None, extra_b=None, g_extra_map=None, white_background=True, want_rd=True):
+    rd = _f32c(ray_directions, 'ray_directions')
+    depth_a, sigma_a, rgb_a = _f32c(depth_a, 'depth'), _f32c(sigma_a, 'sigma'), _f32c(rgb_a, 'rgb')
+    na = depth_a.shape[-1]
+    n = depth_a.numel() // na
+    nb = 0
+    if depth_b is not None:
+        depth_b, sigma_b, rgb_b = _f32c(depth_b, 'depth_b'), _f32c(sigma_b, 'sigma_b'), _f32c(rgb_b, 'rgb_b')
+        nb = depth_b.shape[-1]
+    n_extra = 0
+    if extra_a is not None and g_extra_map is not None:
+        extra_a, extra_b = _f32c(extra_a, 'extra_a'), _f32c(extra_b, 'extra_b')
+        n_extra = extra_a.shape[-1]
+    out = dict(g_sigma_a=torch.empty_like(sigma_a), g_rgb_a=torch.empty_like(rgb_a))
+    if nb:
+        out.update(g_sigma_b=torch.empty_like(sigma_b), g_rgb_b=torch.empty_like(rgb_b))
+    if n_extra:
+        out['g_extra_a'] = torch.empty_like(extra_a)
+        if nb:
+            out['g_extra_b'] = torch.empty_like(extra_b)
+    if want_rd:
+        out['g_ray_directions'] = torch.empty_like(rd)
+    with torch.cuda.device(rd.device):
+        _lib.call_struct('nfi_composite_bwd', 'nfi_composite_bwd_args', _stream(rd), n_rays=n, n_a=na, n_b=nb,
+                         ray_directions=rd, depth_a=depth_a, sigma_a=sigma_a, rgb_a=rgb_a, depth_b=depth_b,
+                         sigma_b=sigma_b, rgb_b=rgb_b, n_extra=n_extra, extra_a=extra_a if n_extra else None,
+                         extra_b=extra_b if n_extra else None, white_background=int(white_background),
+                         g_rgb_map=_f32c(g_rgb_map, 'g_rgb_map'), g_mask=_f32c(g_mask, 'g_mask'),
+                         g_extra_map=_f32c(g_extra_map, 'g_extra_map') if n_extra else None, **out)
+    return out
+
+
+def points_bwd(g_points, depth, want_ro=True, want_rd=True):
+    g_points, depth = _f32c(g_points, 'g_points'), _f32c(depth, 'depth')
+    S = depth.shape[-1]
+    n = depth.numel() // S
+    shape = depth.shape[:-1]
+    g_ro = torch.empty((*shape, 3), dtype=torch.float32, device=depth.device) if want_ro else None
+    g_rd = torch.empty((*shape, 3), dtype=torch.float32, device=depth.device) if want_rd else None
+    lib = _lib.load()
+    with torch.cuda.device(depth.device):
+        _lib.check(lib.nfi_points_bwd(_lib.ptr(g_points), _lib.ptr(depth), n, S, _lib.ptr(g_ro), _lib.ptr(g_rd),
+                                      _stream(depth)), 'nfi_points_bwd')
+    return g_ro, g_rd
+
+
+def raygen_bwd(height, width, focal, cam2world, bbox, center, normalize, g_ro, g_rd):
+    cam2world = _f32c(cam2world, 'tform_cam2world')
+    B = cam2world.shape[0]
+    focal, bbox, center = _f32c(focal, 'focal_length'), _f32c(bbox, 'bbox'), _f32c(center, 'center')
+    g_cam = torch.empty((B, 4, 4), dtype=torch.float32, device=cam2world.device)
+    g_focal = torch.empty((B,), dtype=torch.float32, device=cam2world.device) if focal is not None else None
+    lib = _lib.load()
+    a = _lib.make_args('nfi_raygen_args', n_scenes=B, height=height, width=width, cam2world=cam2world, focal=focal,
+                       bbox=bbox, center=center, normalize=int(normalize))
+    import ctypes
+    with torch.cuda.device(cam2world.device):
+        _lib.check(lib.nfi_raygen_bwd(ctypes.byref(a), _lib.ptr(_f32c(g_ro, 'g_ro')), _lib.ptr(_f32c(g_rd, 'g_rd')),
+                                      _lib.ptr(g_cam), _lib.ptr(g_focal), _stream(cam2world)), 'nfi_raygen_bwd')
+    return g_cam, g_focal

@@ -127,7 +127,7 @@ def stratified_depths(near: torch.Tensor, far: torch.Tensor, num_samples: int,
     """t_k = lerp(near, far, k/S) (+ noise_k * (far-near)/S).  noise: [..., S] in [0,1)."""
     n = near.unsqueeze(-1)
     f = far.unsqueeze(-1)
-    frac = torch.arange(num_samples, device=near.device) / num_samples
+    frac = (torch.arange(num_samples, device=near.device) / num_samples).to(near.dtype)   # fp32 in the reference
     t = torch.lerp(n, f, frac)
     if noise is not None:
         t = t + noise * ((f - n) / num_samples)
@@ -259,7 +259,8 @@ def render(planes, w1, b1, w2, b2, cam2world, focal, height, width, num_samples,
     o = {}
     ro, rd = ray_bundle(height, width, focal, cam2world, bbox, center)
     rd = unit_dirs(rd)
-    near, far, hit = near_far(ro, rd, scene_range)
+    with torch.no_grad():           # run.py:197-200
+        near, far, hit = near_far(ro, rd, scene_range)
     o.update(ro=ro, rd=rd, near=near, far=far, hit=hit)
     t_c = stratified_depths(near, far, num_samples, noise_coarse)
     x_c = points_on_rays(ro, rd, t_c)
@@ -272,12 +273,13 @@ def render(planes, w1, b1, w2, b2, cam2world, focal, height, width, num_samples,
              sdf_coarse=q['sdf'].view(*shp))
     t = t_c
     if fine_sampling:
-        w = ray_weights(sigma, rd, t_c).flatten(0, 2)
-        ws = smooth_weights(w)
-        mid = (.5 * (t_c[..., 1:] + t_c[..., :-1])).flatten(0, 2)
-        u = noise_fine if noise_fine is not None else deterministic_u(ws.shape[0], num_samples, ws)
-        t_f, inds, cdf = inverse_cdf(mid, ws[..., 1:-1], u)
-        t_f = t_f.view(*t_c.shape[:3], -1)
+        with torch.no_grad():       # run.py:261: the resampling carries no gradient
+            w = ray_weights(sigma, rd, t_c).flatten(0, 2)
+            ws = smooth_weights(w)
+            mid = (.5 * (t_c[..., 1:] + t_c[..., :-1])).flatten(0, 2)
+            u = noise_fine if noise_fine is not None else deterministic_u(ws.shape[0], num_samples, ws)
+            t_f, inds, cdf = inverse_cdf(mid, ws[..., 1:-1], u)
+            t_f = t_f.view(*t_c.shape[:3], -1)
         o.update(weights_coarse=w, weights_smooth=ws, cdf=cdf, inds=inds, t_fine=t_f)
         t, perm = torch.sort(torch.cat((t_c, t_f), dim=-1), dim=-1)
         x_f = points_on_rays(ro, rd, t_f)

@@ -1,0 +1,282 @@
+"""Backward kernels against autograd of the oracle (the reference gets these gradients from
+PyTorch autograd).  The oracle is differentiated in float64 on CPU; the
+HIP gradients (fp32) must agree to 1e-4 of the gradient's scale."""
+import pytest
+import torch
+
+from conftest import load_golden
+from nerf_from_image_amd import nerf_utils as nu
+from oracle import nfi_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+def rel_close(got, ref, what, tol=2e-4):
+    got, ref = got.detach().double().cpu(), ref.detach().double().cpu()
+    assert got.shape == ref.shape, (what, got.shape, ref.shape)
+    scale = ref.abs().max().clamp_min(1e-12)
+    err = (got - ref).abs().max() / scale
+    assert torch.isfinite(got).all() and err <= tol, (what, float(err), float(scale))
+
+
+def oracle_merge_composite(rd, t_a, s_a, c_a, t_b, s_b, c_b, e_a, e_b, white):
+    t = torch.cat((t_a, t_b), -1) if t_b is not None else t_a
+    s = torch.cat((s_a, s_b), -1) if t_b is not None else s_a
+    c = torch.cat((c_a, c_b), -2) if t_b is not None else c_a
+    e = (torch.cat((e_a, e_b), -2) if t_b is not None else e_a) if e_a is not None else None
+    if t_b is not None:
+        t, perm = torch.sort(t, dim=-1, stable=True)
+        s = s.gather(-1, perm)
+        c = c.gather(-2, perm.unsqueeze(-1).expand(*perm.shape, 3))
+        if e is not None:
+            e = e.gather(-2, perm.unsqueeze(-1).expand(*perm.shape, e.shape[-1]))
+    rgb_map, depth_map, acc, sem_map, _ = orc.composite(s, c, rd, t, e, white)
+    return rgb_map, acc, sem_map
+
+
+@pytest.mark.parametrize('two_lists,white,n_a,n_b,extras', [(True, True, 64, 64, 0), (True, False, 16, 16, 5),
+                                                            (False, True, 32, 0, 3), (True, True, 40, 24, 0)])
+def test_composite_backward(gpu_device, two_lists, white, n_a, n_b, extras):
+    g = torch.Generator().manual_seed(17 + n_a + extras)
+    N = (3, 5, 7)
+    rd = torch.nn.functional.normalize(torch.randn(*N, 3, generator=g), dim=-1) * (1 + 0.1 * torch.rand(*N, 1, generator=g))
+    t_a = torch.sort(torch.rand(*N, n_a, generator=g) * 2 + 0.5, dim=-1)[0]
+    s_a = torch.rand(*N, n_a, generator=g) * 8 * (torch.rand(*N, n_a, generator=g) > 0.3)
+    c_a = torch.rand(*N, n_a, 3, generator=g) * 2 - 1
+    t_b = s_b = c_b = e_a = e_b = None
+    if two_lists:
+        t_b = torch.rand(*N, n_b, generator=g) * 2 + 0.5
+        s_b = torch.rand(*N, n_b, generator=g) * 20
+        c_b = torch.rand(*N, n_b, 3, generator=g) * 2 - 1
+    if extras:
+        e_a = torch.rand(*N, n_a, extras, generator=g)
+        e_b = torch.rand(*N, n_b, extras, generator=g) if two_lists else None
+    w_rgb, w_mask = torch.randn(*N, 3, generator=g), torch.randn(*N, generator=g)
+    w_ex = torch.randn(*N, extras, generator=g) if extras else None
+
+    leaves = [x for x in (rd, s_a, c_a, s_b, c_b, e_a, e_b) if x is not None]
+    # ---- oracle, float64
+    ref_in = [x.double().requires_grad_() for x in leaves]
+    it = iter(ref_in)
+    r_rd, r_sa, r_ca = next(it), next(it), next(it)
+    r_sb, r_cb = (next(it), next(it)) if two_lists else (None, None)
+    r_ea = next(it) if extras else None
+    r_eb = next(it) if (extras and two_lists) else None
+    rgb_map, acc, sem = oracle_merge_composite(r_rd, t_a.double(), r_sa, r_ca, None if t_b is None else t_b.double(),
+                                               r_sb, r_cb, r_ea, r_eb, white)
+    loss = (rgb_map * w_rgb.double()).sum() + (acc * w_mask.double()).sum()
+    if extras:
+        loss = loss + (sem * w_ex.double()).sum()
+    ref_g = torch.autograd.grad(loss, ref_in)
+    # ---- HIP
+    dev = gpu_device
+    hip_in = [x.to(dev).requires_grad_() for x in leaves]
+    it = iter(hip_in)
+    h_rd, h_sa, h_ca = next(it), next(it), next(it)
+    h_sb, h_cb = (next(it), next(it)) if two_lists else (None, None)
+    h_ea = next(it) if extras else None
+    h_eb = next(it) if (extras and two_lists) else None
+    if two_lists:
+        rgb_h, dep_h, mask_h, _, ex_h = nu.merge_and_composite(h_rd, t_a.to(dev), h_sa, h_ca, t_b.to(dev), h_sb, h_cb,
+                                                              None, None, h_ea, h_eb, white_background=white)
+    else:
+        rgb_h, dep_h, mask_h, _, ex_h = nu.render_volume_density(h_sa, h_ca, None, h_rd, t_a.to(dev), None, h_ea, white)
+    rel_close(rgb_h, rgb_map, 'forward rgb', 1e-5)
+    assert not dep_h.requires_grad
+    loss_h = (rgb_h * w_rgb.to(dev)).sum() + (mask_h * w_mask.to(dev)).sum()
+    if extras:
+        loss_h = loss_h + (ex_h * w_ex.to(dev)).sum()
+    hip_g = torch.autograd.grad(loss_h, hip_in)
+    names = ['rd', 'sigma_a', 'rgb_a'] + (['sigma_b', 'rgb_b'] if two_lists else []) + \
+            (['extra_a'] + (['extra_b'] if two_lists else []) if extras else [])
+    for n, a, b in zip(names, hip_g, ref_g):
+        rel_close(a, b, 'grad ' + n)
+
+
+def test_points_backward(gpu_device):
+    g = torch.Generator().manual_seed(5)
+    ro, rd = torch.randn(2, 4, 6, 3, generator=g), torch.randn(2, 4, 6, 3, generator=g)
+    t = torch.rand(2, 4, 6, 40, generator=g) + 0.5
+    w = torch.randn(2, 4, 6, 40, 3, generator=g)
+    a, b = ro.double().requires_grad_(), rd.double().requires_grad_()
+    ref = torch.autograd.grad((orc.points_on_rays(a, b, t.double()) * w.double()).sum(), (a, b))
+    ha, hb = ro.to(gpu_device).requires_grad_(), rd.to(gpu_device).requires_grad_()
+    x = nu.points_on_rays(ha, hb, t.to(gpu_device))
+    got = torch.autograd.grad((x * w.to(gpu_device)).sum(), (ha, hb))
+    rel_close(got[0], ref[0], 'g_ro'); rel_close(got[1], ref[1], 'g_rd')
+    # through the stratified-sampling entry point too (depth is not differentiable)
+    near = torch.full((2, 4, 6), 0.7).to(gpu_device); far = torch.full((2, 4, 6), 2.0).to(gpu_device)
+    q, depth = nu.compute_query_points_from_rays(ha, hb, near, far, 24, randomize=True)
+    assert q.requires_grad and not depth.requires_grad
+    gq = torch.autograd.grad(q.sum(), (ha, hb))
+    rel_close(gq[0], torch.full_like(ro, 24.0), 'g_ro (stratified)')
+    rel_close(gq[1], depth.sum(-1, keepdim=True).expand_as(rd), 'g_rd (stratified)')
+
+
+@pytest.mark.parametrize('name', ['persp_white_fine_rand', 'persp_bbox_black_fine_rand', 'ortho_fine_det'])
+def test_raygen_backward(gpu_device, name):
+    meta, t = load_golden(name)
+    H, W = meta['H'], meta['W']
+    g = torch.Generator().manual_seed(3)
+    w_o, w_d = torch.randn(meta['B'], H, W, 3, generator=g), torch.randn(meta['B'], H, W, 3, generator=g)
+    cam = t['cam2world'].double().requires_grad_()
+    focal = t['focal'].double().requires_grad_() if 'focal' in t else None
+    bbox = t['bbox'].double() if 'bbox' in t else None
+    ro, rd = orc.ray_bundle(H, W, focal, cam, bbox)
+    rd = orc.unit_dirs(rd)
+    leaves = [cam] + ([focal] if focal is not None else [])
+    ref = torch.autograd.grad((ro * w_o.double()).sum() + (rd * w_d.double()).sum(), leaves)
+    dev = gpu_device
+    hcam = t['cam2world'].to(dev).requires_grad_()
+    hfocal = t['focal'].to(dev).requires_grad_() if 'focal' in t else None
+    hbbox = t['bbox'].to(dev) if 'bbox' in t else None
+    hro, hrd = nu.get_ray_bundle_normalized(H, W, hfocal, hcam, hbbox)
+    hleaves = [hcam] + ([hfocal] if hfocal is not None else [])
+    got = torch.autograd.grad((hro * w_o.to(dev)).sum() + (hrd * w_d.to(dev)).sum(), hleaves)
+    rel_close(got[0][:, :3], ref[0][:, :3], 'g_cam2world')
+    if meta['ortho']:
+        # normalised directions do not depend on the homogeneous scale: the reference gradient is 0,
+        # so compare on the scale of the whole matrix gradient
+        rel_close(got[0], ref[0], 'g_cam2world incl. [3,3]')
+    if hfocal is not None:
+        rel_close(got[1], ref[1], 'g_focal')
+    # un-normalised variant
+    cam2 = t['cam2world'].double().requires_grad_()
+    ro2, rd2 = orc.ray_bundle(H, W, None if focal is None else t['focal'].double(), cam2, bbox)
+    ref2 = torch.autograd.grad((rd2 * w_d.double()).sum(), cam2)[0]
+    hcam2 = t['cam2world'].to(dev).requires_grad_()
+    _, hrd2 = nu.get_ray_bundle(H, W, None if hfocal is None else hfocal.detach(), hcam2, hbbox)
+    got2 = torch.autograd.grad((hrd2 * w_d.to(dev)).sum(), hcam2)[0]
+    rel_close(got2[:, :3, :3], ref2[:, :3, :3], 'g_cam2world (raw directions)')
+
+
+# --------------------------------------------------------------------------------------------
+# field query backward (sampler closure) and the whole differentiable render
+# --------------------------------------------------------------------------------------------
+import types  # noqa: E402
+
+from stand_in import StandInGenerator, look_at_cameras, _Decoder  # noqa: E402
+import nerf_from_image_amd.generator as nfi_gen  # noqa: E402
+import nerf_from_image_amd.render as nfi_render  # noqa: E402
+
+
+@pytest.mark.parametrize('A,use_sdf,P', [(10, True, 200), (0, False, 70), (10, True, 64)])
+def test_field_query_backward(gpu_device, A, use_sdf, P):
+    dev = gpu_device
+    g = torch.Generator().manual_seed(100 + A + P)
+    B, R = 2, 24
+    r = float(torch.tensor(0.55, dtype=torch.float32))      # the fp32 value the kernels divide by (face points!)
+    low = torch.randn(B * 3, 32, 6, 6, generator=g)
+    planes = torch.nn.functional.interpolate(low, size=(R, R), mode='bilinear', align_corners=True)
+    planes = (planes + 0.1 * torch.randn(B * 3, 32, R, R, generator=g)).view(B, 3, 32, R, R)
+    dec = _Decoder(1 + A if A > 0 else 4, g)
+    x = (torch.rand(B, P, 3, generator=g) * 2 - 1) * r * 1.1          # some points outside the cube
+    x[0, 0] = torch.tensor([r, 0.1, -r])                               # on the faces: clamped coordinates
+    att = (torch.rand(B, A, 3, generator=g) * 2 - 1) if A > 0 else None
+    beta, alpha = torch.tensor([0.12]), torch.tensor([0.3])
+    w_sig, w_rgb = torch.randn(B, P, generator=g), torch.randn(B, P, 3, generator=g)
+    w_sdf = torch.randn(B, P, generator=g)
+    w_sem = torch.randn(B, P, A, generator=g) if A > 0 else None
+
+    # ---- oracle in float64
+    dd = lambda t: None if t is None else t.double().requires_grad_()
+    o_x, o_pl, o_att, o_be, o_al = dd(x), dd(planes), dd(att), dd(beta), dd(alpha)
+    o_w = [dd(p.detach()) for p in (dec.net[0].weight, dec.net[0].bias, dec.net[2].weight, dec.net[2].bias)]
+    q = orc.field_query(o_pl, o_w[0], o_w[1], o_w[2], o_w[3], o_x, r, use_sdf, o_be if use_sdf else None,
+                        o_al if use_sdf else None, o_att)
+    loss = (q['sigma'] * w_sig.double()).sum() + (q['rgb'] * w_rgb.double()).sum() + (q['sdf'] * w_sdf.double()).sum()
+    if A > 0:
+        loss = loss + (q['semantics'] * w_sem.double()).sum()
+    leaves = [o_x, o_pl] + o_w + ([o_att] if A > 0 else []) + ([o_be, o_al] if use_sdf else [])
+    ref = torch.autograd.grad(loss, leaves)
+
+    # ---- HIP through the sampler closure
+    dec = dec.to(dev)
+    h_pl = planes.to(dev).requires_grad_()
+    h_x = x.to(dev).requires_grad_()
+    h_att = att.to(dev).requires_grad_() if A > 0 else None
+    h_be = beta.to(dev).requires_grad_() if use_sdf else None
+    h_al = alpha.to(dev).requires_grad_() if use_sdf else None
+    sampler = nfi_gen.make_sampler(h_pl, dec, r, A, h_att, use_sdf, h_be, h_al)
+    req = ['sigma', 'rgb', 'sdf_distance'] + (['semantics'] if A > 0 else [])
+    res = sampler(h_x, req)
+    rel_close(res['sigma'], q['sigma'], 'forward sigma', 2e-4)
+    loss_h = (res['sigma'] * w_sig.to(dev)).sum() + (res['rgb'] * w_rgb.to(dev)).sum() + \
+             (res['sdf_distance'][..., 0] * w_sdf.to(dev)).sum()
+    if A > 0:
+        loss_h = loss_h + (res['semantics'] * w_sem.to(dev)).sum()
+    h_w = [dec.net[0].weight, dec.net[0].bias, dec.net[2].weight, dec.net[2].bias]
+    h_leaves = [h_x, h_pl] + h_w + ([h_att] if A > 0 else []) + ([h_be, h_al] if use_sdf else [])
+    got = torch.autograd.grad(loss_h, h_leaves)
+    names = ['points', 'planes', 'w1', 'b1', 'w2', 'b2'] + (['attention_values'] if A > 0 else []) + \
+            (['beta', 'alpha'] if use_sdf else [])
+    for n, a, b in zip(names, got, ref):
+        rel_close(a, b, 'grad ' + n, 5e-4)
+
+
+@pytest.mark.parametrize('fine,ortho', [(True, False), (False, False), (True, True)])
+def test_render_backward_end_to_end(gpu_device, fine, ortho):
+    """d(rgb, mask)/d(planes producer params, decoder, beta, alpha, attention values, camera, focal) through
+    nfi_render.render (staged HIP path) against autograd of the oracle with the same noise."""
+    from test_host_api_gpu import RandTap
+    dev = gpu_device
+    torch.manual_seed(7)
+    model = StandInGenerator(0.55, attention_values=10, use_sdf=True, plane_res=32).to(dev)
+    with torch.no_grad():
+        model.alpha.fill_(0.2)
+    nfi_gen.attach(model)
+    g = torch.Generator().manual_seed(21)
+    B, H, W, S = 2, 12, 10, 32
+    cam0 = look_at_cameras(B, 1.5, g)
+    focal0 = None if ortho else torch.full((B,), 1.1)
+    if ortho:
+        cam0[:, :3, 3] *= 2.0
+    z = torch.randn(B, 512, generator=g).to(dev)
+    w_rgb, w_mask = torch.randn(B, H, W, 3, generator=g), torch.randn(B, H, W, generator=g)
+    cfg = types.SimpleNamespace(use_viewdir=False, use_sdf=True, attention_values=10, fine_sampling=fine)
+    dcfg = {'scene_range': 0.55 if not ortho else 1.2, 'white_background': True}
+    model.scene_range = dcfg['scene_range']
+    render = nfi_render.make_render(cfg, dcfg)
+
+    cam = cam0.to(dev).requires_grad_()
+    focal = None if ortho else focal0.to(dev).requires_grad_()
+    with RandTap() as tap:
+        rgb, depth, mask, _, _, _ = render(model, H, W, cam, focal, None, None, z, S)
+    loss = (rgb * w_rgb.to(dev)).sum() + (mask * w_mask.to(dev)).sum()
+    params = [model.decoder.net[0].weight, model.decoder.net[0].bias, model.decoder.net[2].weight,
+              model.decoder.net[2].bias, model.beta, model.alpha, model.synthesis_network.basis,
+              model.texture_mapper.lin.weight, cam] + ([] if ortho else [focal])
+    got = torch.autograd.grad(loss, params)
+
+    # ---- oracle with identical noise: float64 (reference value) and float32 (the precision the
+    # reference runs at; its distance to float64 calibrates how much rounding alone moves a gradient
+    # that is a sum of cancelling terms and depends on discontinuous sample placement)
+    import copy
+
+    def oracle_grads(dtype):
+        ref_model = copy.deepcopy(model).cpu().to(dtype)
+        planes, att = ref_model.planes_and_values(z.cpu().to(dtype))
+        dec = ref_model.decoder.net
+        ocam = cam0.to(dtype).requires_grad_()
+        ofocal = None if ortho else focal0.to(dtype).requires_grad_()
+        draws = [d.to(dtype) for d in tap.draws]
+        o = orc.render(planes, dec[0].weight, dec[0].bias, dec[2].weight, dec[2].bias, ocam, ofocal, H, W, S,
+                       dcfg['scene_range'], white_background=True, fine_sampling=fine, noise_coarse=draws[0],
+                       noise_fine=draws[1] if fine else None, use_sdf=True, beta=ref_model.beta, alpha=ref_model.alpha,
+                       attention_values=att)
+        oloss = (o['rgb'] * w_rgb.to(dtype)).sum() + (o['mask'] * w_mask.to(dtype)).sum()
+        oparams = [dec[0].weight, dec[0].bias, dec[2].weight, dec[2].bias, ref_model.beta, ref_model.alpha,
+                   ref_model.synthesis_network.basis, ref_model.texture_mapper.lin.weight, ocam] + \
+                  ([] if ortho else [ofocal])
+        return o, torch.autograd.grad(oloss, oparams)
+    o, ref = oracle_grads(torch.float64)
+    _, ref32 = oracle_grads(torch.float32)
+    rel_close(rgb, o['rgb'], 'forward rgb', 2e-4)
+    names = ['w1', 'b1', 'w2', 'b2', 'beta', 'alpha', 'plane producer', 'texture mapper', 'cam2world'] + \
+            ([] if ortho else ['focal'])
+    for n, a, b, b32 in zip(names, got, ref, ref32):
+        if n == 'cam2world':
+            a, b, b32 = a[:, :3], b[:, :3], b32[:, :3]
+        scale = b.abs().max().clamp_min(1e-12)
+        noise = float((b32.double() - b).abs().max() / scale)
+        rel_close(a, b, 'grad ' + n, max(2e-3, 4 * noise))

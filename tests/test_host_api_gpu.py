@@ -151,14 +151,19 @@ def test_nerf_utils_api(setup):
         close(s_det, ref, 1e-5, 'sample_pdf')
 
 
-def test_gradient_request_fails_loudly_not_silently(setup):
+def test_gradient_request_without_a_backward_fails_loudly(setup):
+    """bf16 texels have no backward kernel: asking for a gradient must raise, never fall back."""
     model, cam, focal, z = setup
+    import copy
+    from nerf_from_image_amd import ops
+    m2 = nfi_gen.attach(copy.deepcopy(model), texel_dtype=ops.TEXEL_BF16)
     cfg = types.SimpleNamespace(use_viewdir=False, use_sdf=True, attention_values=10, fine_sampling=True)
     render = nfi_render.make_render(cfg, {'scene_range': 0.55, 'white_background': True})
-    from nerf_from_image_amd.autograd import BACKWARD
-    if 'field_query' in BACKWARD:
-        pytest.skip('backward kernels are registered')
     zz = z.clone().requires_grad_()
-    rgb, *_ = render(model, 8, 8, cam, focal, None, None, zz, 16)
+    rgb, *_ = render(m2, 8, 8, cam, focal, None, None, zz, 16)
     with pytest.raises(NotImplementedError):
         rgb.sum().backward()
+    # fp32 texels: the same call differentiates
+    rgb, *_ = render(model, 8, 8, cam, focal, None, None, zz, 16)
+    rgb.sum().backward()
+    assert zz.grad is not None and torch.isfinite(zz.grad).all() and zz.grad.abs().sum() > 0
