@@ -293,6 +293,11 @@ typedef struct nfi_field_bwd_args {
   float* g_w1; float* g_b1; float* g_w2; float* g_b2;
   float* g_attention_values; float* g_beta; float* g_alpha;
   void* workspace; size_t workspace_bytes;               /* >= nfi_decoder_bwd_image_floats()*4 bytes */
+  /* points_only = 1: only g_points is produced (no plane scatter, no parameter gradients; all
+   * other g_* outputs may be NULL).  normalize_g_points = 1: each g_points row is L2-normalised
+   * (eps 1e-12).  Together with g_sdf == 1 this yields the analytic surface normals
+   * normalize(d sdf / d x) of models/generator.py:599-623 without autograd. */
+  int points_only; int normalize_g_points;
 } nfi_field_bwd_args;
 size_t nfi_decoder_bwd_image_floats(void);
 int nfi_field_query_bwd(const nfi_field_bwd_args* a, nfi_stream_t stream);

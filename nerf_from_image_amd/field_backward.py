@@ -5,7 +5,8 @@ from . import _lib, ops
 
 
 def field_query_bwd(points, texels, decoder_image, w1, w2, scene_range, n_attention, attention_values, use_sdf, beta,
-                    alpha, g_sigma, g_rgb, g_sdf=None, g_semantics=None, want_points=False):
+                    alpha, g_sigma, g_rgb, g_sdf=None, g_semantics=None, want_points=False, points_only=False,
+                    normalize_points=False):
     """Returns dict(g_texels [B,3,R,R,32], g_w1, g_b1, g_w2, g_b2, g_attention_values?, g_beta?, g_alpha?, g_points?)."""
     f = ops._f32c
     points = f(points, 'points')
@@ -15,17 +16,19 @@ def field_query_bwd(points, texels, decoder_image, w1, w2, scene_range, n_attent
         raise TypeError('field_query_bwd: gradients need fp32 texels')
     n_out = 1 + n_attention if n_attention > 0 else 4
     lib = _lib.load()
-    out = {'g_texels': torch.zeros_like(texels),
-           'g_w1': torch.zeros((64, 32), dtype=torch.float32, device=dev),
-           'g_b1': torch.zeros((64,), dtype=torch.float32, device=dev),
-           'g_w2': torch.zeros((n_out, 64), dtype=torch.float32, device=dev),
-           'g_b2': torch.zeros((n_out,), dtype=torch.float32, device=dev)}
-    if n_attention > 0:
-        out['g_attention_values'] = torch.zeros((B, n_attention, 3), dtype=torch.float32, device=dev)
-    if use_sdf:
-        out['g_beta'] = torch.zeros((1,), dtype=torch.float32, device=dev)
-        out['g_alpha'] = torch.zeros((1,), dtype=torch.float32, device=dev)
-    if want_points:
+    out = {}
+    if not points_only:
+        out = {'g_texels': torch.zeros_like(texels),
+               'g_w1': torch.zeros((64, 32), dtype=torch.float32, device=dev),
+               'g_b1': torch.zeros((64,), dtype=torch.float32, device=dev),
+               'g_w2': torch.zeros((n_out, 64), dtype=torch.float32, device=dev),
+               'g_b2': torch.zeros((n_out,), dtype=torch.float32, device=dev)}
+        if n_attention > 0:
+            out['g_attention_values'] = torch.zeros((B, n_attention, 3), dtype=torch.float32, device=dev)
+        if use_sdf:
+            out['g_beta'] = torch.zeros((1,), dtype=torch.float32, device=dev)
+            out['g_alpha'] = torch.zeros((1,), dtype=torch.float32, device=dev)
+    if want_points or points_only:
         out['g_points'] = torch.zeros((B, P, 3), dtype=torch.float32, device=dev)
     ws = torch.empty((lib.nfi_decoder_bwd_image_floats(),), dtype=torch.float32, device=dev)
     with torch.cuda.device(dev):
@@ -37,7 +40,8 @@ def field_query_bwd(points, texels, decoder_image, w1, w2, scene_range, n_attent
             use_sdf=int(use_sdf), beta=f(beta, 'beta') if use_sdf else None, alpha=f(alpha, 'alpha') if use_sdf else None,
             scene_range=float(scene_range), g_sigma=f(g_sigma, 'g_sigma'), g_rgb=f(g_rgb, 'g_rgb'),
             g_sdf=f(g_sdf, 'g_sdf'), g_semantics=f(g_semantics, 'g_semantics'), workspace=ws,
-            workspace_bytes=ws.numel() * 4, **out)
+            workspace_bytes=ws.numel() * 4, points_only=int(points_only), normalize_g_points=int(normalize_points),
+            **out)
     return out
 
 
@@ -61,3 +65,17 @@ def make_field_bwd(texels, decoder_image, scene_range, n_attention, use_sdf, wan
         return (g.get('g_points'), g_planes, g['g_w1'], g['g_b1'], g['g_w2'], g['g_b2'],
                 g.get('g_attention_values'), g.get('g_beta'), g.get('g_alpha'))
     return bwd
+
+
+def surface_normals(points, texels, decoder_image, w1, w2, scene_range, n_attention, attention_values, use_sdf, beta,
+                    alpha):
+    """normalize(d sdf / d x) per point [B,P,3]: the `normals` output of the sampler closure
+    (models/generator.py:599-623), from the coordinate-gradient path of the backward kernel."""
+    B, P = points.shape[0], points.shape[1]
+    dev = points.device
+    zeros = torch.zeros((B, P), dtype=torch.float32, device=dev)
+    g = field_query_bwd(points, texels, decoder_image, w1, w2, scene_range, n_attention, attention_values, use_sdf,
+                        beta, alpha, zeros, torch.zeros((B, P, 3), dtype=torch.float32, device=dev),
+                        g_sdf=torch.ones((B, P), dtype=torch.float32, device=dev), points_only=True,
+                        normalize_points=True)
+    return g['g_points']

@@ -26,7 +26,7 @@ import torch
 
 from . import ops
 from .autograd import differentiable
-from .field_backward import make_field_bwd
+from .field_backward import make_field_bwd, surface_normals
 
 REQUIRED_ATTRS = ('scene_range', 'attention_values', 'use_sdf', 'use_viewdir', 'use_encoder', 'num_classes',
                   'mapping_network', 'synthesis_network', 'decoder')
@@ -79,8 +79,12 @@ def make_sampler(planes, decoder, scene_range, n_attention, attention_values, us
     def sampler(x_in, request_sampler_outputs=['sigma', 'rgb']):
         for output in request_sampler_outputs:
             assert output in _SAMPLER_OUTPUTS
-        if 'normals' in request_sampler_outputs:
-            raise NotImplementedError('sampler: analytic normals are not implemented on the HIP path yet')
+        want_normals = 'normals' in request_sampler_outputs
+        if want_normals:
+            # generator.py:599-602: SDF only, eval only; every other output is then detached
+            assert use_sdf and not getattr(decoder, 'training', False)
+            if texel_dtype != ops.TEXEL_F32:
+                raise NotImplementedError('sampler: normals need fp32 texels')
         bs = x_in.shape[0]
         pts = x_in.reshape(bs, -1, 3)
         want_sem = 'semantics' in request_sampler_outputs
@@ -96,10 +100,16 @@ def make_sampler(planes, decoder, scene_range, n_attention, attention_values, us
         bwd = None
         if texel_dtype == ops.TEXEL_F32:
             bwd = make_field_bwd(texels, image, scene_range, n_attention, use_sdf, want_sdf, want_sem)
-        res = differentiable('field_query', fwd, pts, planes, w1, b1, w2, b2,
-                             attention_values if n_attention > 0 else None,
-                             beta if use_sdf else None, alpha if use_sdf else None, bwd=bwd)
+        args = (pts, planes, w1, b1, w2, b2, attention_values if n_attention > 0 else None,
+                beta if use_sdf else None, alpha if use_sdf else None)
+        if want_normals:
+            args = tuple(None if t is None else t.detach() for t in args)
+        res = differentiable('field_query', fwd, *args, bwd=bwd)
         out = {}
+        if want_normals:
+            out['normals'] = surface_normals(pts.detach(), texels, image, w1.detach(), w2.detach(), scene_range,
+                                             n_attention, None if attention_values is None else attention_values.detach(),
+                                             use_sdf, beta.detach(), alpha.detach())
         i = 2
         if want_sdf:
             out['sdf_distance'] = res[i].unsqueeze(-1)

@@ -167,3 +167,47 @@ def test_gradient_request_without_a_backward_fails_loudly(setup):
     rgb, *_ = render(model, 8, 8, cam, focal, None, None, zz, 16)
     rgb.sum().backward()
     assert zz.grad is not None and torch.isfinite(zz.grad).all() and zz.grad.abs().sum() > 0
+
+
+def test_normals_sampler_and_render(setup):
+    """`normals` = normalize(d sdf / d x) (generator.py:599-623) from the HIP coordinate-gradient path, per point
+    and composited by render(compute_normals=True) (weights detached + white background, nerf_utils.py:146-159)."""
+    model, cam, focal, z = setup
+    dev = cam.device
+    with torch.no_grad():
+        sampler = model(None, z, ['sampler'])['sampler']
+        planes, att = model.planes_and_values(z)
+    g = torch.Generator().manual_seed(4)
+    x = ((torch.rand(2, 300, 3, generator=g) * 2 - 1) * 0.5)
+    res = sampler(x.to(dev), ['sigma', 'rgb', 'normals'])
+    dec = model.decoder.net
+    cpu = lambda t: t.detach().cpu()
+
+    def oracle_normals(pts):
+        p = pts.clone().requires_grad_()
+        q = orc.field_query(cpu(planes), cpu(dec[0].weight), cpu(dec[0].bias), cpu(dec[2].weight), cpu(dec[2].bias), p,
+                            0.55, True, cpu(model.beta), cpu(model.alpha), cpu(att))
+        gx, = torch.autograd.grad(q['sdf'].sum(), p)
+        return torch.nn.functional.normalize(gx, dim=-1), q
+    n_ref, q_ref = oracle_normals(x)
+    assert res['normals'].shape == (2, 300, 3)
+    close(res['normals'], n_ref, 2e-3, 'normals')              # unit vectors; fp32 finite differences of texels
+    close(res['rgb'], q_ref['rgb'], 1e-4, 'rgb alongside normals')
+    assert not res['sigma'].requires_grad
+
+    # ---- composited normal map
+    cfg = types.SimpleNamespace(use_viewdir=False, use_sdf=True, attention_values=10, fine_sampling=True)
+    dcfg = {'scene_range': 0.55, 'white_background': True}
+    render = nfi_render.make_render(cfg, dcfg)
+    H, W, S = 16, 16, 32
+    with torch.no_grad(), RandTap() as tap:
+        rgb, depth, mask, normal_map, sem, _ = render(model, H, W, cam, focal, None, None, z, S, compute_normals=True)
+    assert sem is None and normal_map.shape == (2, H, W, 3)
+    o = oracle_for(model, z, cam, focal, H, W, S, cfg, dcfg, tap.draws)
+    close(rgb, o['rgb'], 1e-4, 'rgb')
+    n_c, _ = oracle_normals(orc.points_on_rays(o['ro'], o['rd'], o['t_coarse']).reshape(2, -1, 3))
+    n_f, _ = oracle_normals(orc.points_on_rays(o['ro'], o['rd'], o['t_fine']).reshape(2, -1, 3))
+    n_all = torch.cat((n_c.view(2, H, W, S, 3), n_f.view(2, H, W, S, 3)), dim=-2)
+    n_sorted = n_all.gather(-2, o['perm'].unsqueeze(-1).expand(-1, -1, -1, -1, 3))
+    ref_map = (o['weights'][..., None] * n_sorted).sum(dim=-2) + (1. - o['mask'][..., None])
+    close(normal_map, ref_map, 3e-3, 'normal map')
