@@ -112,6 +112,58 @@ def cpu_baseline(seed):
             'sample': '1 image 128x128, 64+64 samples, planes precomputed (render only), fp32, 1 warm-up + 3 timed runs, median'}
 
 
+def extras(dev, ops, d):
+    """Untimed-side measurements reported next to the headline (never part of `value`):
+    the same render at B=1, with every ray crossing the cube (cars-like radius 1.3), with bf16 texels
+    (BASELINE config 2's storage variant; parity vs fp32 is tolerance-level, see tests), and the oracle
+    evaluated with PyTorch-ROCm ops on this GPU (= the reference's own GPU path, the north star's
+    >= 10x denominator)."""
+    from oracle import nfi_oracle as orc
+
+    def time_render(n_img, radius, texel_dtype, iters=20):
+        dd = synthetic_inputs(n_img, 4321, dev)
+        g = torch.Generator().manual_seed(77)
+        dd['cam'] = cameras(n_img, radius, g).to(dev)
+        texels = ops.planes_to_texels(dd['planes'], texel_dtype)
+        image = ops.decoder_pack(dd['w1'], dd['b1'], dd['w2'], dd['b2'], A, texel_dtype)
+        nc = torch.rand((n_img, R, R, S), device=dev)
+        nf = torch.rand((n_img * R * R, S), device=dev)
+        ws = None
+        for i in range(iters + 3):
+            if i == 3:
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+            out = ops.render_fwd(dd['cam'], dd['focal'], R, R, S, texels, image, SCENE_RANGE, A, dd['att'], True,
+                                 dd['beta'], dd['alpha'], noise_coarse=nc, noise_fine=nf, workspace=ws)
+            ws = out['_workspace']
+        torch.cuda.synchronize()
+        return n_img * R * R * iters / (time.perf_counter() - t0)
+
+    ex = {'render_only_rays_per_s': {
+        'b1_chairs_fp32': time_render(1, RADIUS, ops.TEXEL_F32),
+        'b8_chairs_fp32': time_render(8, RADIUS, ops.TEXEL_F32),
+        'b8_all_rays_hit_fp32': time_render(8, 1.3, ops.TEXEL_F32),
+        'b8_chairs_bf16_texels': time_render(8, RADIUS, ops.TEXEL_BF16)}}
+    # reference numerics on PyTorch-ROCm: the oracle with GPU ATen ops, 2 images, planes precomputed
+    dd = synthetic_inputs(2, 4321, dev)
+    nc = torch.rand((2, R, R, S), device=dev)
+    nf = torch.rand((2 * R * R, S), device=dev)
+    times = []
+    with torch.no_grad():
+        for i in range(3):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            orc.render(dd['planes'], dd['w1'], dd['b1'], dd['w2'], dd['b2'], dd['cam'], dd['focal'], R, R, S, SCENE_RANGE,
+                       white_background=True, noise_coarse=nc, noise_fine=nf, use_sdf=True, beta=dd['beta'],
+                       alpha=dd['alpha'], attention_values=dd['att'])
+            torch.cuda.synchronize()
+            times.append(time.perf_counter() - t0)
+    ex['pytorch_rocm_reference_path'] = {'value': 2 * R * R / min(times[1:]), 'unit': 'rays/s',
+                                         'sample': 'oracle (reference ATen op sequence) on this GPU, 2 images, '
+                                                   'render only, fp32, best of 2 after warm-up'}
+    return ex
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -120,6 +172,7 @@ def main():
     ap.add_argument('--images-per-gpu', type=int, default=IMAGES_PER_GPU)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-skip', action='store_true', help='march rays that miss the scene cube too')
+    ap.add_argument('--force-dist', action='store_true', help='initialise RCCL even with one rank (exercises the N>1 code path)')
     args = ap.parse_args()
 
     rank = int(os.environ.get('RANK', 0))
@@ -129,9 +182,12 @@ def main():
         raise SystemExit('--gpus %d but WORLD_SIZE=%d: launch N>1 with torch.distributed.run' % (args.gpus, world))
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
-    if world > 1:
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
         import torch.distributed as dist
-        dist.init_process_group('nccl', device_id=dev)
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29533')
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
 
     import __graft_entry__ as entry
     entry.build()
@@ -156,7 +212,7 @@ def main():
         return out
 
     def fence():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -168,7 +224,7 @@ def main():
         out = step()
     fence()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -215,10 +271,11 @@ def main():
         }
         if not args.no_cpu_baseline and world == 1:
             res['cpu_baseline'] = cpu_baseline(1234)
+            res['extras'] = extras(dev, ops, d)
         else:
             res['cpu_baseline'] = None
         print(json.dumps(res))
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

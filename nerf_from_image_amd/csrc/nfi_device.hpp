@@ -391,9 +391,24 @@ __device__ __forceinline__ void tile_bilinear(const TileTex<TEX>& T, float fx, f
 // Returns (in every lane of the four groups) the decoder outputs for point j.
 //   outside: 1.0f if the point is outside the scene cube.
 //   sem: if non-null, softmax probabilities are written to sem[A] (global) for this point.
-template <bool ATT>
+// Decoder operands of one lane, held in registers across the tiles of a pass when the register
+// budget allows (2 waves/SIMD variant): removes 17 ds_read_b128 + their waits from every tile.
+struct ResidentWeights {
+  f32x4 w1[8], w2[4], b1[4], b2;
+};
+__device__ __forceinline__ void load_resident(const FieldParams& P, int lane, ResidentWeights& R) {
+  const f32x4* ldsv = reinterpret_cast<const f32x4*>(P.lds);
+  const int g = lane >> 4;
+#pragma unroll
+  for (int s = 0; s < 8; ++s) R.w1[s] = ldsv[(kW1F >> 2) + s * 64 + lane];
+#pragma unroll
+  for (int nt = 0; nt < 4; ++nt) { R.w2[nt] = ldsv[(kW2F >> 2) + nt * 64 + lane]; R.b1[nt] = ldsv[(kB1F >> 2) + g * 4 + nt]; }
+  R.b2 = ldsv[(kB2F >> 2) + g];
+}
+
+template <bool ATT, bool RES = false>
 __device__ __forceinline__ TileOut tile_mlp(const FieldParams& P, int lane, const float (&feat)[8], float outside,
-                                            float* sem) {
+                                            float* sem, const ResidentWeights* RW = nullptr) {
   const int g = lane >> 4;
   // ---- layer 1: H^T[64 x 16] = W1'[64 x 32] * F^T[32 x 16], bias pre-loaded, log2 domain ----
   const f32x4* ldsv = reinterpret_cast<const f32x4*>(P.lds);
@@ -401,10 +416,10 @@ __device__ __forceinline__ TileOut tile_mlp(const FieldParams& P, int lane, cons
   {
     f32x4 acc1[4];
 #pragma unroll
-    for (int nt = 0; nt < 4; ++nt) acc1[nt] = ldsv[(kB1F >> 2) + g * 4 + nt];
+    for (int nt = 0; nt < 4; ++nt) acc1[nt] = RES ? RW->b1[nt] : ldsv[(kB1F >> 2) + g * 4 + nt];
 #pragma unroll
     for (int s = 0; s < 8; ++s) {
-      f32x4 w = ldsv[(kW1F >> 2) + s * 64 + lane];
+      f32x4 w = RES ? RW->w1[s] : ldsv[(kW1F >> 2) + s * 64 + lane];
       acc1[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(w.x, feat[s], acc1[0], 0, 0, 0);
       acc1[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(w.y, feat[s], acc1[1], 0, 0, 0);
       acc1[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(w.z, feat[s], acc1[2], 0, 0, 0);
@@ -422,11 +437,11 @@ __device__ __forceinline__ TileOut tile_mlp(const FieldParams& P, int lane, cons
       }
     }
     // ---- layer 2: O^T[16 x 16] = W2'[16 x 64] * SP^T[64 x 16]; two accumulators hide latency ----
-    f32x4 o0 = ldsv[(kB2F >> 2) + g];
+    f32x4 o0 = RES ? RW->b2 : ldsv[(kB2F >> 2) + g];
     f32x4 o1 = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt) {
-      f32x4 w = ldsv[(kW2F >> 2) + nt * 64 + lane];
+      f32x4 w = RES ? RW->w2[nt] : ldsv[(kW2F >> 2) + nt * 64 + lane];
       o0 = __builtin_amdgcn_mfma_f32_16x16x4f32(w.x, acc1[nt][0], o0, 0, 0, 0);
       o1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w.y, acc1[nt][1], o1, 0, 0, 0);
       o0 = __builtin_amdgcn_mfma_f32_16x16x4f32(w.z, acc1[nt][2], o0, 0, 0, 0);
@@ -510,10 +525,11 @@ struct SampleOut {
 // stage: 16 x 36 floats of LDS owned by this wave (feature-tile transpose).
 // prof: null, or 4 cycle accumulators {tile set-up + load issue, load wait + interpolation,
 // transpose + MLP + epilogue, tiles} filled with s_memtime deltas (profiling builds only)
-template <int TEX, bool ATT, bool SKIP>
+template <int TEX, bool ATT, bool SKIP, bool RES = false>
 __device__ __forceinline__ SampleOut field_wave(const FieldParams& P, float scene_range, int lane, float px, float py,
                                                 float pz, bool valid, float* sem_base, bool* outside_flag,
-                                                float* stage, unsigned long long* prof = nullptr) {
+                                                float* stage, unsigned long long* prof = nullptr,
+                                                const ResidentWeights* RW = nullptr) {
   // reference: x / scene_range, mask = any(|x| > 1)   (true division, generator.py:604-607)
   float qx = px / scene_range, qy = py / scene_range, qz = pz / scene_range;
   bool out = (fabsf(qx) > 1.0f) || (fabsf(qy) > 1.0f) || (fabsf(qz) > 1.0f);
@@ -579,7 +595,7 @@ __device__ __forceinline__ SampleOut field_wave(const FieldParams& P, float scen
     }
     __builtin_amdgcn_sched_barrier(0);
     float* sem = (sem_base && (fcur & 2)) ? sem_base + (size_t)srcM * P.n_attention : nullptr;
-    TileOut to = tile_mlp<ATT>(P, lane, feat, (fcur & 1) ? 1.0f : 0.0f, sem);
+    TileOut to = tile_mlp<ATT, RES>(P, lane, feat, (fcur & 1) ? 1.0f : 0.0f, sem, RW);
     if (g == t) { so.sdf = to.sdf; so.sigma = to.sigma; so.r = to.r; so.g = to.g; so.b = to.b; }
     if (prof) {
       asm volatile("" :: "v"(so.sigma), "v"(so.r));

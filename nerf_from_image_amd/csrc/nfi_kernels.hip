@@ -944,6 +944,9 @@ __global__ __launch_bounds__(256, OCC) void render_fwd_kernel(RenderKernelParams
   FieldParams P = make_field_params(k.texels, k.res, TEX, k.A, k.use_sdf, k.beta, k.alpha, lds);
   P.vf = vf;
   int cur_scene = -1;
+  constexpr bool RES = (OCC == 2) && !TAPS && !PROF;     // decoder operands resident in registers
+  ResidentWeights RW;
+  if (RES) load_resident(P, lane, RW);
 
   auto load_inputs = [&](uint32_t ray, RayInputs& in) {
     const size_t r3 = (size_t)ray * 3;
@@ -1005,8 +1008,8 @@ __global__ __launch_bounds__(256, OCC) void render_fwd_kernel(RenderKernelParams
       MergeIn c;
       unsigned long long t1 = PROF ? __builtin_readcyclecounter() : 0;
       {
-        SampleOut q = field_wave<TEX, ATT, true>(P, k.scene_range, lane, ox + dx * tc, oy + dy * tc, oz + dz * tc, valid,
-                                                 nullptr, nullptr, &slab.srt[0][0], PROF ? pc : nullptr);
+        SampleOut q = field_wave<TEX, ATT, true, RES>(P, k.scene_range, lane, ox + dx * tc, oy + dy * tc, oz + dz * tc,
+                                                      valid, nullptr, nullptr, &slab.srt[0][0], PROF ? pc : nullptr, &RW);
         c.t = tc; c.sigma = q.sigma; c.r = q.r; c.g = q.g; c.b = q.b;
       }
       int n = S;
@@ -1018,8 +1021,8 @@ __global__ __launch_bounds__(256, OCC) void render_fwd_kernel(RenderKernelParams
         MergeIn f;
         if (PROF) { asm volatile("" :: "v"(tf)); t3 = __builtin_readcyclecounter(); }
         {
-          SampleOut q = field_wave<TEX, ATT, true>(P, k.scene_range, lane, ox + dx * tf, oy + dy * tf, oz + dz * tf, valid,
-                                                   nullptr, nullptr, &slab.srt[0][0], PROF ? pc : nullptr);
+          SampleOut q = field_wave<TEX, ATT, true, RES>(P, k.scene_range, lane, ox + dx * tf, oy + dy * tf, oz + dz * tf,
+                                                        valid, nullptr, nullptr, &slab.srt[0][0], PROF ? pc : nullptr, &RW);
           f.t = tf; f.sigma = q.sigma; f.r = q.r; f.g = q.g; f.b = q.b;
         }
         if constexpr (TAPS) {
