@@ -340,8 +340,9 @@ typedef struct nfi_render_args {
   /* optional hipEvent_t pair recorded on the stream immediately before / after the render kernel
    * (excludes the ray set-up launch): live per-launch kernel timing for bench.py.  NULL = off. */
   void* event_start; void* event_stop;
-  /* tuning knob, 0 = default: bits 0-1 select the register/occupancy variant of the render kernel
-   * (1: 2, 2 or 0: 3, 3: 4 waves per SIMD).  Results do not depend on it. */
+  /* tuning knob, 0 = default.  bit 2: hand rays out in scanline order instead of 8x8 pixel tiles
+   * (results identical).  bit 3: evaluate the decoder MLP with exact-fp32 MFMA instead of the
+   * split-fp16 (hi+lo, 22 significand bits) MFMA; both meet the 1e-4 parity budget. */
   int tuning;
   /* optional uint64[12] device array: per-phase shader-cycle sums over all waves (profiling build of
    * the kernel; NULL = off): field tile {issue, wait+interp, mlp, count}, ray set-up, coarse field,

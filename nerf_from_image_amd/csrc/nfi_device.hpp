@@ -18,6 +18,7 @@ namespace nfi {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 constexpr int kWave = 64;
 constexpr int kC = 32;        // plane channels
@@ -35,8 +36,18 @@ constexpr int kW1F = 0;
 constexpr int kW2F = kW1F + 8 * 64 * 4;
 constexpr int kB1F = kW2F + 4 * 64 * 4;
 constexpr int kB2F = kB1F + 64;
-constexpr int kImageFloats = kB2F + 16;                 // 3152
-constexpr int kVF = kImageFloats;                       // per-scene attention values [4 groups][4 regs][4] appended in LDS
+// fp16 hi/lo split of the same operands for the renderer's split-precision MLP (dwords = half pairs):
+// W1H [4 n-tiles][hi,lo][64 lanes][4 dwords]   A operand of v_mfma_f32_16x16x32_f16, K = 32 channels
+// W2H [2 k-instr][hi,lo][64 lanes][4 dwords]   K = 32 of the 64 hidden units per instruction
+constexpr int kW1H = kB2F + 16;                         // 3152
+constexpr int kW2H = kW1H + 4 * 2 * 64 * 4;             // 5200
+constexpr int kImageFloats = kW2H + 2 * 2 * 64 * 4;     // 6224
+// LDS copy of the image: a kernel stages EITHER the fp32 fragments (W1F, W2F) OR the fp16 ones, which
+// then overlay the fp32 fragment area; the biases keep their place.  kLdsImageFloats floats + VF.
+constexpr int kW1H_lds = 0;                             // fp16 W1 fragments overlay W1F
+constexpr int kW2H_lds = 4 * 2 * 64 * 4;                // fp16 W2 fragments overlay W2F
+constexpr int kLdsImageFloats = kW1H;                   // 3152
+constexpr int kVF = kLdsImageFloats;                    // per-scene attention values [16 rows][4] appended in LDS
 constexpr int kFieldLdsFloats = kVF + 64;               // 3216
 
 // ---- small wave helpers ---------------------------------------------------------------------
@@ -388,128 +399,199 @@ __device__ __forceinline__ void tile_bilinear(const TileTex<TEX>& T, float fx, f
   }
 }
 
-// Returns (in every lane of the four groups) the decoder outputs for point j.
-//   outside: 1.0f if the point is outside the scene cube.
-//   sem: if non-null, softmax probabilities are written to sem[A] (global) for this point.
-// Decoder operands of one lane, held in registers across the tiles of a pass when the register
-// budget allows (2 waves/SIMD variant): removes 17 ds_read_b128 + their waits from every tile.
-struct ResidentWeights {
-  f32x4 w1[8], w2[4], b1[4], b2;
-};
-__device__ __forceinline__ void load_resident(const FieldParams& P, int lane, ResidentWeights& R) {
-  const f32x4* ldsv = reinterpret_cast<const f32x4*>(P.lds);
-  const int g = lane >> 4;
+// Decoder MLP + density / colour epilogue for N tiles at once (N = 2 in the renderer: the two tiles'
+// MFMA chains, softplus blocks and cross-lane reductions are independent, so a wave has twice the
+// instruction-level parallelism against the dependent latencies that dominate this phase, and the
+// operand fragments are read from LDS once for both).
+// Returns (in every lane of the four groups) the decoder outputs for point j of each tile.
+//   outside[n]: 1.0f if the point is outside the scene cube.
+//   sem[n]: if non-null, softmax probabilities are written to sem[n][A] (global) for this point.
+// x[0..7] -> hi = fp16(x) (round toward zero), lo = fp16(x - hi): hi + lo carries 22 significand bits
+// (fp16 subnormals are preserved by the MFMA in the default kernel mode, so small values lose nothing)
+__device__ __forceinline__ void split_f16x8(const float (&x)[8], f16x8& hi, f16x8& lo) {
 #pragma unroll
-  for (int s = 0; s < 8; ++s) R.w1[s] = ldsv[(kW1F >> 2) + s * 64 + lane];
-#pragma unroll
-  for (int nt = 0; nt < 4; ++nt) { R.w2[nt] = ldsv[(kW2F >> 2) + nt * 64 + lane]; R.b1[nt] = ldsv[(kB1F >> 2) + g * 4 + nt]; }
-  R.b2 = ldsv[(kB2F >> 2) + g];
+  for (int i = 0; i < 4; ++i) {
+    auto h = __builtin_amdgcn_cvt_pkrtz(x[2 * i], x[2 * i + 1]);
+    auto l = __builtin_amdgcn_cvt_pkrtz(x[2 * i] - (float)h[0], x[2 * i + 1] - (float)h[1]);
+    hi[2 * i] = h[0]; hi[2 * i + 1] = h[1];
+    lo[2 * i] = l[0]; lo[2 * i + 1] = l[1];
+  }
 }
 
-template <bool ATT, bool RES = false>
-__device__ __forceinline__ TileOut tile_mlp(const FieldParams& P, int lane, const float (&feat)[8], float outside,
-                                            float* sem, const ResidentWeights* RW = nullptr) {
+// PREC 0: exact fp32 MFMA (v_mfma_f32_16x16x4_f32, 48 per tile).
+// PREC 1: split fp16 (v_mfma_f32_16x16x32_f16, 18 per tile): every operand is hi + lo in fp16 and the
+//         products hi*hi + hi*lo + lo*hi are accumulated in fp32 - 2^-21 relative per product instead of
+//         fp32's 2^-24, an order of magnitude below the 1e-4 parity budget, at 1/5 of the matrix-pipe time.
+//         On gfx950 the f32-input MFMA runs at the f32 VECTOR rate and does not overlap with VALU work of
+//         other waves (tools/probes/mfma_valu_overlap.hip), so this time comes straight off the kernel.
+template <bool ATT, int N, int PREC>
+__device__ __forceinline__ void tile_mlp(const FieldParams& P, int lane, const float (&feat)[N][8],
+                                         const float (&outside)[N], float* const (&sem)[N], TileOut (&res)[N]) {
   const int g = lane >> 4;
-  // ---- layer 1: H^T[64 x 16] = W1'[64 x 32] * F^T[32 x 16], bias pre-loaded, log2 domain ----
   const f32x4* ldsv = reinterpret_cast<const f32x4*>(P.lds);
-  f32x4 o;
-  {
-    f32x4 acc1[4];
+  f32x4 o[N];
+  if constexpr (PREC == 1) {
+    const u32x4* ldsu = reinterpret_cast<const u32x4*>(P.lds);
+    f16x8 fh[N], fl[N];
 #pragma unroll
-    for (int nt = 0; nt < 4; ++nt) acc1[nt] = RES ? RW->b1[nt] : ldsv[(kB1F >> 2) + g * 4 + nt];
+    for (int n = 0; n < N; ++n) split_f16x8(feat[n], fh[n], fl[n]);
+    f32x4 acc1[N][4];
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+      const f32x4 b = ldsv[(kB1F >> 2) + g * 4 + nt];
+      const f16x8 wh = __builtin_bit_cast(f16x8, ldsu[(kW1H_lds >> 2) + (nt * 2 + 0) * 64 + lane]);
+      const f16x8 wl = __builtin_bit_cast(f16x8, ldsu[(kW1H_lds >> 2) + (nt * 2 + 1) * 64 + lane]);
+#pragma unroll
+      for (int n = 0; n < N; ++n) acc1[n][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, fh[n], b, 0, 0, 0);
+#pragma unroll
+      for (int n = 0; n < N; ++n) acc1[n][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, fl[n], acc1[n][nt], 0, 0, 0);
+#pragma unroll
+      for (int n = 0; n < N; ++n) acc1[n][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl, fh[n], acc1[n][nt], 0, 0, 0);
+    }
+#pragma unroll
+    for (int n = 0; n < N; ++n)
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float h = acc1[n][nt][r];
+          float e = __builtin_amdgcn_exp2f(h);
+          float sp = __builtin_amdgcn_logf(1.0f + e);
+          acc1[n][nt][r] = (h > kSoftplusThr2) ? h : sp;
+        }
+    const f32x4 b2 = ldsv[(kB2F >> 2) + g];
+#pragma unroll
+    for (int n = 0; n < N; ++n) o[n] = b2;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      const f16x8 wh = __builtin_bit_cast(f16x8, ldsu[(kW2H_lds >> 2) + (kk * 2 + 0) * 64 + lane]);
+      const f16x8 wl = __builtin_bit_cast(f16x8, ldsu[(kW2H_lds >> 2) + (kk * 2 + 1) * 64 + lane]);
+      f16x8 sh[N], sl[N];
+#pragma unroll
+      for (int n = 0; n < N; ++n) {
+        const float x[8] = {acc1[n][2 * kk][0], acc1[n][2 * kk][1], acc1[n][2 * kk][2], acc1[n][2 * kk][3],
+                            acc1[n][2 * kk + 1][0], acc1[n][2 * kk + 1][1], acc1[n][2 * kk + 1][2], acc1[n][2 * kk + 1][3]};
+        split_f16x8(x, sh[n], sl[n]);
+      }
+#pragma unroll
+      for (int n = 0; n < N; ++n) o[n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, sh[n], o[n], 0, 0, 0);
+#pragma unroll
+      for (int n = 0; n < N; ++n) o[n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, sl[n], o[n], 0, 0, 0);
+#pragma unroll
+      for (int n = 0; n < N; ++n) o[n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl, sh[n], o[n], 0, 0, 0);
+    }
+  } else {
+    // ---- layer 1: H^T[64 x 16] = W1'[64 x 32] * F^T[32 x 16], bias pre-loaded, log2 domain ----
+    f32x4 acc1[N][4];
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+      const f32x4 b = ldsv[(kB1F >> 2) + g * 4 + nt];
+#pragma unroll
+      for (int n = 0; n < N; ++n) acc1[n][nt] = b;
+    }
 #pragma unroll
     for (int s = 0; s < 8; ++s) {
-      f32x4 w = RES ? RW->w1[s] : ldsv[(kW1F >> 2) + s * 64 + lane];
-      acc1[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(w.x, feat[s], acc1[0], 0, 0, 0);
-      acc1[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(w.y, feat[s], acc1[1], 0, 0, 0);
-      acc1[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(w.z, feat[s], acc1[2], 0, 0, 0);
-      acc1[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(w.w, feat[s], acc1[3], 0, 0, 0);
+      const f32x4 w = ldsv[(kW1F >> 2) + s * 64 + lane];
+#pragma unroll
+      for (int n = 0; n < N; ++n) {
+        acc1[n][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(w.x, feat[n][s], acc1[n][0], 0, 0, 0);
+        acc1[n][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(w.y, feat[n][s], acc1[n][1], 0, 0, 0);
+        acc1[n][2] = __builtin_amdgcn_mfma_f32_16x16x4f32(w.z, feat[n][s], acc1[n][2], 0, 0, 0);
+        acc1[n][3] = __builtin_amdgcn_mfma_f32_16x16x4f32(w.w, feat[n][s], acc1[n][3], 0, 0, 0);
+      }
     }
     // softplus in base 2: sp2 = log2(1 + 2^h2)  (= softplus(h)/ln2; ln2 is folded into W2')
 #pragma unroll
-    for (int nt = 0; nt < 4; ++nt) {
+    for (int n = 0; n < N; ++n)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        float h = acc1[nt][r];
-        float e = __builtin_amdgcn_exp2f(h);
-        float sp = __builtin_amdgcn_logf(1.0f + e);
-        acc1[nt][r] = (h > kSoftplusThr2) ? h : sp;
+      for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float h = acc1[n][nt][r];
+          float e = __builtin_amdgcn_exp2f(h);
+          float sp = __builtin_amdgcn_logf(1.0f + e);
+          acc1[n][nt][r] = (h > kSoftplusThr2) ? h : sp;
+        }
+    // ---- layer 2: O^T[16 x 16] = W2'[16 x 64] * SP^T[64 x 16]; two accumulators per tile ----
+    f32x4 o0[N], o1[N];
+    const f32x4 b2 = ldsv[(kB2F >> 2) + g];
+#pragma unroll
+    for (int n = 0; n < N; ++n) { o0[n] = b2; o1[n] = f32x4{0.0f, 0.0f, 0.0f, 0.0f}; }
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+      const f32x4 w = ldsv[(kW2F >> 2) + nt * 64 + lane];
+#pragma unroll
+      for (int n = 0; n < N; ++n) {
+        o0[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(w.x, acc1[n][nt][0], o0[n], 0, 0, 0);
+        o1[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(w.y, acc1[n][nt][1], o1[n], 0, 0, 0);
+        o0[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(w.z, acc1[n][nt][2], o0[n], 0, 0, 0);
+        o1[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(w.w, acc1[n][nt][3], o1[n], 0, 0, 0);
       }
     }
-    // ---- layer 2: O^T[16 x 16] = W2'[16 x 64] * SP^T[64 x 16]; two accumulators hide latency ----
-    f32x4 o0 = RES ? RW->b2 : ldsv[(kB2F >> 2) + g];
-    f32x4 o1 = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
-    for (int nt = 0; nt < 4; ++nt) {
-      f32x4 w = RES ? RW->w2[nt] : ldsv[(kW2F >> 2) + nt * 64 + lane];
-      o0 = __builtin_amdgcn_mfma_f32_16x16x4f32(w.x, acc1[nt][0], o0, 0, 0, 0);
-      o1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w.y, acc1[nt][1], o1, 0, 0, 0);
-      o0 = __builtin_amdgcn_mfma_f32_16x16x4f32(w.z, acc1[nt][2], o0, 0, 0, 0);
-      o1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w.w, acc1[nt][3], o1, 0, 0, 0);
-    }
-    o = o0 + o1;  // lane (j,g): outputs 4g..4g+3 of point j; output 0 = sdf/density, 1.. = features*log2e
+    for (int n = 0; n < N; ++n) o[n] = o0[n] + o1[n];   // lane (j,g): outputs 4g..4g+3 of point j; row 0 = sdf/density
   }
 
-  TileOut res;
-  const int j = lane & 15;
-  float sdf = bcast_row0(o.x);     // group 0's output row 0 -> all four channel groups
-  res.sdf = sdf;
-  if (P.use_sdf) {
-    // sigma = (1/alpha) * (0.5 + 0.5*sign(-d)*(1 - exp(-|d|/beta))) * (1 - outside)
-    float e = __builtin_amdgcn_exp2f(fabsf(sdf) * P.neg_log2e_over_beta);
-    float sgn = (sdf < 0.0f) ? 0.5f : ((sdf > 0.0f) ? -0.5f : 0.0f);
-    float cdf = 0.5f + sgn * (1.0f - e);
-    res.sigma = P.inv_alpha * (cdf * (1.0f - outside));
-  } else {
-    float d = sdf - 1.0f;
-    float sp = (d > 20.0f) ? d : log1pf(__expf(d));
-    res.sigma = sp * (1.0f - outside);
-  }
-  if constexpr (ATT) {
-    // softmax over features 1..A spread over (group, reg); rows are pre-scaled by log2e
-    const int A = P.n_attention;
-    float m = -INFINITY;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      int row = 4 * g + r;
-      bool valid = (row >= 1) && (row <= A);
-      m = valid ? fmaxf(m, o[r]) : m;
+  for (int n = 0; n < N; ++n) {
+    const float sdf = bcast_row0(o[n].x);     // group 0's output row 0 -> all four channel groups
+    res[n].sdf = sdf;
+    if (P.use_sdf) {
+      // sigma = (1/alpha) * (0.5 + 0.5*sign(-d)*(1 - exp(-|d|/beta))) * (1 - outside)
+      float e = __builtin_amdgcn_exp2f(fabsf(sdf) * P.neg_log2e_over_beta);
+      float sgn = (sdf < 0.0f) ? 0.5f : ((sdf > 0.0f) ? -0.5f : 0.0f);
+      float cdf = 0.5f + sgn * (1.0f - e);
+      res[n].sigma = P.inv_alpha * (cdf * (1.0f - outside[n]));
+    } else {
+      float d = sdf - 1.0f;
+      float sp = (d > 20.0f) ? d : log1pf(__expf(d));
+      res[n].sigma = sp * (1.0f - outside[n]);
     }
-    m = max_xor32(max_xor16(m));
-    const f32x4* vf = reinterpret_cast<const f32x4*>(P.vf) + g * 4;
-    float se = 0.0f, sr = 0.0f, sg = 0.0f, sb = 0.0f;
-    float e4[4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      int row = 4 * g + r;
-      bool valid = (row >= 1) && (row <= A);
-      float e = valid ? __builtin_amdgcn_exp2f(o[r] - m) : 0.0f;
-      e4[r] = e;
-      f32x4 v = vf[r];
-      se += e;
-      sr = fmaf(e, v.x, sr);
-      sg = fmaf(e, v.y, sg);
-      sb = fmaf(e, v.z, sb);
-    }
-    se = sum_xor32(sum_xor16(se)); sr = sum_xor32(sum_xor16(sr)); sg = sum_xor32(sum_xor16(sg)); sb = sum_xor32(sum_xor16(sb));
-    float inv = __builtin_amdgcn_rcpf(se);
-    inv = inv * (2.0f - se * inv);      // one Newton step: the quotient is then within 1 ulp
-    res.r = sr * inv; res.g = sg * inv; res.b = sb * inv;
-    if (sem) {
+    if constexpr (ATT) {
+      // softmax over features 1..A spread over (group, reg); rows are pre-scaled by log2e
+      const int A = P.n_attention;
+      float m = -INFINITY;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         int row = 4 * g + r;
-        if (row >= 1 && row <= A) sem[row - 1] = e4[r] * inv;
+        bool valid = (row >= 1) && (row <= A);
+        m = valid ? fmaxf(m, o[n][r]) : m;
       }
+      m = max_xor32(max_xor16(m));
+      const f32x4* vf = reinterpret_cast<const f32x4*>(P.vf) + g * 4;
+      float se = 0.0f, sr = 0.0f, sg = 0.0f, sb = 0.0f;
+      float e4[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        int row = 4 * g + r;
+        bool valid = (row >= 1) && (row <= A);
+        float e = valid ? __builtin_amdgcn_exp2f(o[n][r] - m) : 0.0f;
+        e4[r] = e;
+        f32x4 v = vf[r];
+        se += e;
+        sr = fmaf(e, v.x, sr);
+        sg = fmaf(e, v.y, sg);
+        sb = fmaf(e, v.z, sb);
+      }
+      se = sum_xor32(sum_xor16(se)); sr = sum_xor32(sum_xor16(sr)); sg = sum_xor32(sum_xor16(sg)); sb = sum_xor32(sum_xor16(sb));
+      float inv = __builtin_amdgcn_rcpf(se);
+      inv = inv * (2.0f - se * inv);      // one Newton step: the quotient is then within 1 ulp
+      res[n].r = sr * inv; res[n].g = sg * inv; res[n].b = sb * inv;
+      if (sem[n]) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          int row = 4 * g + r;
+          if (row >= 1 && row <= A) sem[n][row - 1] = e4[r] * inv;
+        }
+      }
+    } else {
+      // rgb = sigmoid(f)*2.004 - 1.002, features (rows 1..3 of group 0) pre-scaled by log2e
+      float r1 = bcast_row0(o[n].y), r2 = bcast_row0(o[n].z), r3 = bcast_row0(o[n].w);
+      res[n].r = (1.0f / (1.0f + __builtin_amdgcn_exp2f(-r1))) * 2.004f - 1.002f;
+      res[n].g = (1.0f / (1.0f + __builtin_amdgcn_exp2f(-r2))) * 2.004f - 1.002f;
+      res[n].b = (1.0f / (1.0f + __builtin_amdgcn_exp2f(-r3))) * 2.004f - 1.002f;
     }
-  } else {
-    // rgb = sigmoid(f)*2.004 - 1.002, features (rows 1..3 of group 0) pre-scaled by log2e
-    float r1 = bcast_row0(o.y), r2 = bcast_row0(o.z), r3 = bcast_row0(o.w);
-    res.r = (1.0f / (1.0f + __builtin_amdgcn_exp2f(-r1))) * 2.004f - 1.002f;
-    res.g = (1.0f / (1.0f + __builtin_amdgcn_exp2f(-r2))) * 2.004f - 1.002f;
-    res.b = (1.0f / (1.0f + __builtin_amdgcn_exp2f(-r3))) * 2.004f - 1.002f;
   }
-  return res;
 }
 
 struct SampleOut {
@@ -525,11 +607,10 @@ struct SampleOut {
 // stage: 16 x 36 floats of LDS owned by this wave (feature-tile transpose).
 // prof: null, or 4 cycle accumulators {tile set-up + load issue, load wait + interpolation,
 // transpose + MLP + epilogue, tiles} filled with s_memtime deltas (profiling builds only)
-template <int TEX, bool ATT, bool SKIP, bool RES = false>
+template <int TEX, bool ATT, bool SKIP, int PREC = 0>
 __device__ __forceinline__ SampleOut field_wave(const FieldParams& P, float scene_range, int lane, float px, float py,
                                                 float pz, bool valid, float* sem_base, bool* outside_flag,
-                                                float* stage, unsigned long long* prof = nullptr,
-                                                const ResidentWeights* RW = nullptr) {
+                                                float* stage, unsigned long long* prof = nullptr) {
   // reference: x / scene_range, mask = any(|x| > 1)   (true division, generator.py:604-607)
   float qx = px / scene_range, qy = py / scene_range, qz = pz / scene_range;
   bool out = (fabsf(qx) > 1.0f) || (fabsf(qy) > 1.0f) || (fabsf(qz) > 1.0f);
@@ -564,43 +645,60 @@ __device__ __forceinline__ SampleOut field_wave(const FieldParams& P, float scen
   // chunk q of L and channel group g of M hold the same channels, so the W1 operand image is
   // independent of this choice.
   const int lp = lane >> 2, lq = lane & 3;        // L layout
-#pragma unroll 1
-  for (int t = 0; t < 4; ++t) {
-    if (!((tm >> t) & 1u)) continue;              // wave-uniform
-    unsigned long long c0 = prof ? __builtin_readcyclecounter() : 0;
+  // gather + interpolation + L->M transpose of one tile; returns the tile's flags for this lane's point
+  auto gather_tile = [&](int t, float (&feat)[8]) -> int {
     const int srcL = 16 * t + lp, srcM = 16 * t + j;
     const float cfx = __shfl(fx, srcL, 64), cfy = __shfl(fy, srcL, 64), cfz = __shfl(fz, srcL, 64);
     const uint32_t cxi = (uint32_t)__shfl(xi, srcL, 64);
     const int fcur = __shfl(flags, srcM, 64);
     TileTex<TEX> T;
     tile_issue<TEX>(P, lq, cxi, T);
-    unsigned long long c1 = prof ? __builtin_readcyclecounter() : 0;
-    float featL[8], feat[8];
+    float featL[8];
     tile_bilinear<TEX>(T, cfx, cfy, cfz, featL);
-    if (prof) { asm volatile("" :: "v"(featL[0]), "v"(featL[7])); }
-    unsigned long long c2 = prof ? __builtin_readcyclecounter() : 0;
-    // L -> M transpose of the 16 x 32 feature tile through the wave's LDS staging rows (pitch 36
-    // floats: conflict-free for both the 16-byte writes and the 16-byte reads)
+    // pitch 36 floats: conflict-free for both the 16-byte writes and the 16-byte reads
     __builtin_amdgcn_sched_barrier(0);
-    {
-      f32x4* wr = reinterpret_cast<f32x4*>(stage + lp * 36 + lq * 4);
-      wr[0] = f32x4{featL[0], featL[1], featL[2], featL[3]};
-      wr[4] = f32x4{featL[4], featL[5], featL[6], featL[7]};
-      wave_lds_fence();
-      const f32x4* rd = reinterpret_cast<const f32x4*>(stage + j * 36 + g * 4);
-      const f32x4 lo = rd[0], hi = rd[4];
-      feat[0] = lo.x; feat[1] = lo.y; feat[2] = lo.z; feat[3] = lo.w;
-      feat[4] = hi.x; feat[5] = hi.y; feat[6] = hi.z; feat[7] = hi.w;
-      wave_lds_fence();
+    f32x4* wr = reinterpret_cast<f32x4*>(stage + lp * 36 + lq * 4);
+    wr[0] = f32x4{featL[0], featL[1], featL[2], featL[3]};
+    wr[4] = f32x4{featL[4], featL[5], featL[6], featL[7]};
+    wave_lds_fence();
+    const f32x4* rd = reinterpret_cast<const f32x4*>(stage + j * 36 + g * 4);
+    const f32x4 lo = rd[0], hi = rd[4];
+    feat[0] = lo.x; feat[1] = lo.y; feat[2] = lo.z; feat[3] = lo.w;
+    feat[4] = hi.x; feat[5] = hi.y; feat[6] = hi.z; feat[7] = hi.w;
+    wave_lds_fence();
+    __builtin_amdgcn_sched_barrier(0);
+    return fcur;
+  };
+#pragma unroll 1
+  while (tm != 0) {
+    unsigned long long c0 = prof ? __builtin_readcyclecounter() : 0;
+    const int ta = __builtin_ctz(tm);
+    tm &= tm - 1;
+    const bool pair = tm != 0;                    // wave-uniform
+    const int tb = pair ? __builtin_ctz(tm) : ta;
+    tm &= tm - 1;                                 // (no-op when tm is already 0)
+    float feat[2][8];
+    const int fa = gather_tile(ta, feat[0]);
+    int fb = fa;
+    if (pair) {
+      fb = gather_tile(tb, feat[1]);
+    } else {
+#pragma unroll
+      for (int s8 = 0; s8 < 8; ++s8) feat[1][s8] = feat[0][s8];
     }
-    __builtin_amdgcn_sched_barrier(0);
-    float* sem = (sem_base && (fcur & 2)) ? sem_base + (size_t)srcM * P.n_attention : nullptr;
-    TileOut to = tile_mlp<ATT, RES>(P, lane, feat, (fcur & 1) ? 1.0f : 0.0f, sem, RW);
-    if (g == t) { so.sdf = to.sdf; so.sigma = to.sigma; so.r = to.r; so.g = to.g; so.b = to.b; }
+    unsigned long long c2 = prof ? __builtin_readcyclecounter() : 0;
+    const float outs[2] = {(fa & 1) ? 1.0f : 0.0f, (fb & 1) ? 1.0f : 0.0f};
+    float* const sems[2] = {
+        (sem_base && (fa & 2)) ? sem_base + (size_t)(16 * ta + j) * P.n_attention : nullptr,
+        (sem_base && pair && (fb & 2)) ? sem_base + (size_t)(16 * tb + j) * P.n_attention : nullptr};
+    TileOut to[2];
+    tile_mlp<ATT, 2, PREC>(P, lane, feat, outs, sems, to);
+    if (g == ta) { so.sdf = to[0].sdf; so.sigma = to[0].sigma; so.r = to[0].r; so.g = to[0].g; so.b = to[0].b; }
+    if (pair && g == tb) { so.sdf = to[1].sdf; so.sigma = to[1].sigma; so.r = to[1].r; so.g = to[1].g; so.b = to[1].b; }
     if (prof) {
       asm volatile("" :: "v"(so.sigma), "v"(so.r));
       unsigned long long c3 = __builtin_readcyclecounter();
-      prof[0] += c1 - c0; prof[1] += c2 - c1; prof[2] += c3 - c2; prof[3] += 1;
+      prof[1] += c2 - c0; prof[2] += c3 - c2; prof[3] += pair ? 2 : 1;
     }
   }
   return so;

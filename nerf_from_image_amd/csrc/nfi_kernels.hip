@@ -159,10 +159,43 @@ __global__ __launch_bounds__(256) void decoder_pack_kernel(const float* __restri
       int k = i - kB1F;
       int r = k & 3, nt = (k >> 2) & 3, g = k >> 4;
       v = b1[16 * nt + 4 * g + r] * kLog2e;
-    } else {
+    } else if (i < kW1H) {
       int k = i - kB2F;
       int row = k;  // 4g + r
       if (row < n_out) v = (row == 0) ? b2[0] : b2[row] * kLog2e;
+    } else {
+      // fp16 hi/lo operand images: one dword = two consecutive k-elements of one lane
+      float w2v[2];
+      int hl;
+      if (i < kW2H) {
+        int k = i - kW1H;
+        int d = k & 3, lane = (k >> 2) & 63;
+        hl = (k >> 8) & 1;
+        int nt = k >> 9;
+        int row = 16 * nt + (lane & 15);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          int ch = feat_channel(tex, 2 * d + h, lane >> 4);
+          w2v[h] = (w1[row * kC + ch] * gain1) * (kLog2e / 3.0f);
+        }
+      } else {
+        int k = i - kW2H;
+        int d = k & 3, lane = (k >> 2) & 63;
+        hl = (k >> 8) & 1;
+        int kk = k >> 9;
+        int row = lane & 15;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          int e = 2 * d + h;
+          int hid = 16 * (2 * kk + (e >> 2)) + 4 * (lane >> 4) + (e & 3);
+          float w = 0.0f;
+          if (row < n_out) { w = w2[row * kHidden + hid] * gain2; if (row == 0) w *= kLn2; }
+          w2v[h] = w;
+        }
+      }
+      auto hi = __builtin_amdgcn_cvt_pkrtz(w2v[0], w2v[1]);
+      auto lo = __builtin_amdgcn_cvt_pkrtz(w2v[0] - (float)hi[0], w2v[1] - (float)hi[1]);
+      v = bits2f(hl == 0 ? __builtin_bit_cast(uint32_t, hi) : __builtin_bit_cast(uint32_t, lo));
     }
     image[i] = v;
   }
@@ -375,7 +408,7 @@ struct FieldKernelParams {
 
 // stage the decoder image (+ this scene's attention values in accumulator layout) into LDS
 __device__ __forceinline__ void stage_field_lds(float* lds, const float* image, const float* att_scene, int A) {
-  for (int i = threadIdx.x; i < kImageFloats; i += blockDim.x) lds[i] = image[i];
+  for (int i = threadIdx.x; i < kLdsImageFloats; i += blockDim.x) lds[i] = image[i];
   for (int i = threadIdx.x; i < 64; i += blockDim.x) {
     int c = i & 3, row = i >> 2;  // row = 4g + r; value for feature row-1
     float v = 0.0f;
@@ -896,6 +929,8 @@ struct RenderKernelParams {
   const float* ro; const float* rd; const float* near_raw; const float* far_raw; const uint8_t* hit;
   const uint32_t* reduce;
   uint32_t* counter;   // work counter (zeroed with reduce[])
+  int width;           // image width (tile order of the work queue)
+  int tile_order;      // 1: hand rays out in 8x8 pixel tiles instead of scanlines
   // field
   const void* texels; int res;
   const float* image; int A; const float* att;
@@ -922,12 +957,18 @@ struct RayInputs {
   uint32_t hit;
 };
 
-template <int TEX, bool ATT, int OCC, bool TAPS, bool PROF = false>
+template <int TEX, bool ATT, int OCC, bool TAPS, int PREC, bool PROF = false>
 __global__ __launch_bounds__(256, OCC) void render_fwd_kernel(RenderKernelParams k) {
-  __shared__ __attribute__((aligned(16))) float lds[kImageFloats];
+  __shared__ __attribute__((aligned(16))) float lds[kLdsImageFloats];
   __shared__ __attribute__((aligned(16))) float vfs[4][64];
   __shared__ WaveSlab slabs[4];
-  for (int i = threadIdx.x; i < kImageFloats; i += blockDim.x) lds[i] = k.image[i];
+  if (PREC == 1) {
+    // fp16 fragments overlay the fp32 fragment area; biases stay where they are
+    for (int i = threadIdx.x; i < kB1F; i += blockDim.x) lds[i] = k.image[kW1H + i];
+    for (int i = kB1F + threadIdx.x; i < kLdsImageFloats; i += blockDim.x) lds[i] = k.image[i];
+  } else {
+    for (int i = threadIdx.x; i < kLdsImageFloats; i += blockDim.x) lds[i] = k.image[i];
+  }
   __syncthreads();
   const int lane = lane_id();
   const int wave = threadIdx.x >> 6;
@@ -940,13 +981,21 @@ __global__ __launch_bounds__(256, OCC) void render_fwd_kernel(RenderKernelParams
   const size_t tb = TEX == 0 ? 128 : 64;
   const uint32_t n_rays = (uint32_t)k.n_scenes * (uint32_t)k.hw;
   uint32_t* counter = k.counter;
+  // queue position -> ray id.  Tile order: consecutive positions walk 8x8 pixel tiles, so the few
+  // thousand rays in flight at any time cover a compact image region (a compact part of the three
+  // planes) instead of a band of scanlines - better L2/Infinity-Cache reuse of the gather stream.
+  const uint32_t tiles_x = (uint32_t)k.width >> 3;
+  auto ray_of = [&](uint32_t pos) -> uint32_t {
+    if (!k.tile_order) return pos;
+    const uint32_t scene = pos / (uint32_t)k.hw, p = pos - scene * (uint32_t)k.hw;
+    const uint32_t tile = p >> 6, in = p & 63u;
+    const uint32_t ty = tile / tiles_x, tx = tile - ty * tiles_x;
+    return scene * (uint32_t)k.hw + ((ty << 3) + (in >> 3)) * (uint32_t)k.width + (tx << 3) + (in & 7u);
+  };
 
   FieldParams P = make_field_params(k.texels, k.res, TEX, k.A, k.use_sdf, k.beta, k.alpha, lds);
   P.vf = vf;
   int cur_scene = -1;
-  constexpr bool RES = (OCC == 2) && !TAPS && !PROF;     // decoder operands resident in registers
-  ResidentWeights RW;
-  if (RES) load_resident(P, lane, RW);
 
   auto load_inputs = [&](uint32_t ray, RayInputs& in) {
     const size_t r3 = (size_t)ray * 3;
@@ -968,11 +1017,11 @@ __global__ __launch_bounds__(256, OCC) void render_fwd_kernel(RenderKernelParams
   // [6] resample, [7] fine field, [8] merge, [9] composite + store, [10] rays, [11] total
   unsigned long long pc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   unsigned long long tk0 = PROF ? __builtin_readcyclecounter() : 0;
-  if (cur < n_rays) load_inputs(cur, in);
+  if (cur < n_rays) load_inputs(ray_of(cur), in);
   while (cur < n_rays) {
     if (lane == 0) fly = atomicAdd(counter, 1u);
-    if (nxt < n_rays) load_inputs(nxt, pre);
-    const uint32_t ray = cur;
+    if (nxt < n_rays) load_inputs(ray_of(nxt), pre);
+    const uint32_t ray = ray_of(cur);
     const uint32_t hitb = in.hit;
     if (k.skip_missed && !(hitb & 2)) {
       // the ray's line stays outside the (inflated) scene cube: every sample has sigma == 0
@@ -1008,8 +1057,8 @@ __global__ __launch_bounds__(256, OCC) void render_fwd_kernel(RenderKernelParams
       MergeIn c;
       unsigned long long t1 = PROF ? __builtin_readcyclecounter() : 0;
       {
-        SampleOut q = field_wave<TEX, ATT, true, RES>(P, k.scene_range, lane, ox + dx * tc, oy + dy * tc, oz + dz * tc,
-                                                      valid, nullptr, nullptr, &slab.srt[0][0], PROF ? pc : nullptr, &RW);
+        SampleOut q = field_wave<TEX, ATT, true, PREC>(P, k.scene_range, lane, ox + dx * tc, oy + dy * tc, oz + dz * tc, valid,
+                                                 nullptr, nullptr, &slab.srt[0][0], PROF ? pc : nullptr);
         c.t = tc; c.sigma = q.sigma; c.r = q.r; c.g = q.g; c.b = q.b;
       }
       int n = S;
@@ -1021,8 +1070,8 @@ __global__ __launch_bounds__(256, OCC) void render_fwd_kernel(RenderKernelParams
         MergeIn f;
         if (PROF) { asm volatile("" :: "v"(tf)); t3 = __builtin_readcyclecounter(); }
         {
-          SampleOut q = field_wave<TEX, ATT, true, RES>(P, k.scene_range, lane, ox + dx * tf, oy + dy * tf, oz + dz * tf,
-                                                        valid, nullptr, nullptr, &slab.srt[0][0], PROF ? pc : nullptr, &RW);
+          SampleOut q = field_wave<TEX, ATT, true, PREC>(P, k.scene_range, lane, ox + dx * tf, oy + dy * tf, oz + dz * tf, valid,
+                                                   nullptr, nullptr, &slab.srt[0][0], PROF ? pc : nullptr);
           f.t = tf; f.sigma = q.sigma; f.r = q.r; f.g = q.g; f.b = q.b;
         }
         if constexpr (TAPS) {
@@ -1135,23 +1184,24 @@ extern "C" int nfi_render_fwd(const nfi_render_args* a, nfi_stream_t stream) {
   k.skip_missed = (a->skip_missed_rays && !any_tap) ? 1 : 0;
 
   k.counter = reduce + 3;
+  k.width = a->width;
+  k.tile_order = (((a->tuning >> 2) & 1) == 0 && (a->width % 8 == 0) && (a->height % 8 == 0)) ? 1 : 0;
   k.prof = (unsigned long long*)a->profile_cycles;
   // persistent 1-D grid: OCC blocks of 4 waves per CU, never more blocks than rays need
-  int occ = a->tuning & 3;               // 0 = default
-  if (occ == 0) occ = 3;
-  if (occ == 1) occ = 2;
+  const int occ = 3;
   int64_t blocks = (int64_t)256 * occ;
   if (blocks > (n + 3) / 4) blocks = (n + 3) / 4;
   dim3 grid((unsigned)blocks);
   bool att = a->n_attention > 0;
   if (a->event_start) (void)hipEventRecord((hipEvent_t)a->event_start, s);
-#define NFI_LAUNCH_RENDER(TEX, ATT)                                                                        \
-  do {                                                                                                     \
-    if (k.prof) hipLaunchKernelGGL((render_fwd_kernel<TEX, ATT, 3, false, true>), grid, dim3(256), 0, s, k);     \
-    else if (any_tap) hipLaunchKernelGGL((render_fwd_kernel<TEX, ATT, 2, true>), grid, dim3(256), 0, s, k);     \
-    else if (occ == 2) hipLaunchKernelGGL((render_fwd_kernel<TEX, ATT, 2, false>), grid, dim3(256), 0, s, k);   \
-    else if (occ == 3) hipLaunchKernelGGL((render_fwd_kernel<TEX, ATT, 3, false>), grid, dim3(256), 0, s, k);   \
-    else hipLaunchKernelGGL((render_fwd_kernel<TEX, ATT, 4, false>), grid, dim3(256), 0, s, k);                 \
+  const bool strict = ((a->tuning >> 3) & 1) != 0;   // exact-fp32 MLP instead of the split-fp16 one
+#define NFI_LAUNCH_RENDER(TEX, ATT)                                                                                   \
+  do {                                                                                                                \
+    if (k.prof) hipLaunchKernelGGL((render_fwd_kernel<TEX, ATT, 3, false, 1, true>), grid, dim3(256), 0, s, k);         \
+    else if (any_tap && strict) hipLaunchKernelGGL((render_fwd_kernel<TEX, ATT, 2, true, 0>), grid, dim3(256), 0, s, k); \
+    else if (any_tap) hipLaunchKernelGGL((render_fwd_kernel<TEX, ATT, 2, true, 1>), grid, dim3(256), 0, s, k);          \
+    else if (strict) hipLaunchKernelGGL((render_fwd_kernel<TEX, ATT, 3, false, 0>), grid, dim3(256), 0, s, k);          \
+    else hipLaunchKernelGGL((render_fwd_kernel<TEX, ATT, 3, false, 1>), grid, dim3(256), 0, s, k);                      \
   } while (0)
   if (a->texel_dtype == NFI_TEXEL_F32) {
     if (att) NFI_LAUNCH_RENDER(0, true); else NFI_LAUNCH_RENDER(0, false);

@@ -82,3 +82,46 @@ def gather_metrics(t):
     bufs = [torch.zeros_like(pad) for _ in range(w)]
     dist.all_gather(bufs, pad)
     return torch.cat([b[:int(s.item())] for b, s in zip(bufs, sizes)])
+
+
+class ParallelModel(torch.nn.Module):
+    """One-process-per-GPU counterpart of run.py's ``ParallelModel`` (560-617): same constructor
+    arguments and the same ``forward`` signature/dispatch, with ``render`` being the HIP drop-in and
+    ``depth_samples_per_ray`` passed in instead of read from a script global (run.py:512-514).
+
+    Each rank builds ONE instance around its persistent replicas; callers shard the batch with
+    :func:`shard_batch` instead of relying on DataParallel's scatter."""
+
+    def __init__(self, resolution, model=None, model_ema=None, lpips_net=None, render=None,
+                 depth_samples_per_ray=64):
+        super().__init__()
+        self.resolution = resolution
+        self.model = model
+        self.model_ema = model_ema
+        self.lpips_net = lpips_net
+        self._render = render
+        self.depth_samples_per_ray = depth_samples_per_ray
+
+    def forward(self, tform_cam2world, focal, center, bbox, c, use_ema=False, ray_multiplier=1, res_multiplier=1,
+                pretrain_sdf=False, compute_normals=False, compute_semantics=False, compute_coords=False,
+                encoder_output=False, closure=None, closure_params=None, extra_model_outputs=[],
+                extra_model_inputs={}, force_no_cam_grad=False):
+        model_to_use = self.model_ema if use_ema else self.model
+        if pretrain_sdf:
+            return model_to_use(None, c, request_model_outputs=['sdf_distance_loss', 'sdf_eikonal_loss'])
+        if encoder_output:
+            return model_to_use.emb(c)
+        render = self._render
+        if render is None:
+            from . import render as nfi_render
+            render = nfi_render.render
+        res = int(self.resolution * res_multiplier)
+        output = render(model_to_use, res, res, tform_cam2world, focal, center, bbox, c,
+                        self.depth_samples_per_ray * ray_multiplier, compute_normals=compute_normals,
+                        compute_semantics=compute_semantics, compute_coords=compute_coords,
+                        extra_model_outputs=extra_model_outputs, extra_model_inputs=extra_model_inputs,
+                        force_no_cam_grad=force_no_cam_grad)
+        if closure is not None:
+            # RGB, alpha, semantics, extra outputs - as run.py:612-615
+            return closure(self, output[0], output[2], output[4], output[-1], **closure_params)
+        return output

@@ -33,7 +33,7 @@ def test_library_exports_every_declared_symbol(lib):
     for name in _lib.FUNCTIONS:
         assert hasattr(lib, name), name
     assert lib.nfi_version() >= 100
-    assert lib.nfi_decoder_image_floats() == 3152
+    assert lib.nfi_decoder_image_floats() == 6224
     # 8 floats + 1 byte per ray + reduce words
     assert lib.nfi_render_workspace_bytes(16384) >= 16384 * 33
 

@@ -109,3 +109,35 @@ def test_all_rays_hit_geometry(gpu_device):
     o = oracle(d, gpu_device)
     for k in ('rgb', 'depth', 'mask'):
         assert err(r[k], o[k])['max'] <= 1e-4, k
+
+
+def test_mlp_precision_modes(gpu_device):
+    """The decoder MLP runs on split-fp16 MFMA (hi+lo operands, fp32 accumulation) by default and on
+    exact-fp32 MFMA with tuning bit 3; both must sit inside the 1e-4 budget against the oracle and
+    agree with each other to ~1e-5; ray order (tuning bit 2) must not change a single bit."""
+    d = make_inputs(2, gpu_device, radius=1.6, seed=5)
+    o = oracle(d, gpu_device)
+    texels = ops.planes_to_texels(d['planes'])
+    image = ops.decoder_pack(d['w1'], d['b1'], d['w2'], d['b2'], A)
+
+    def run(tuning):
+        return ops.render_fwd(d['cam'], d['focal'], R, R, S, texels, image, 0.55, A, d['att'], True, d['beta'], d['alpha'],
+                              noise_coarse=d['noise_c'], noise_fine=d['noise_f'], tuning=tuning)
+    split, strict, scan = run(0), run(8), run(4)
+    for k in ('rgb', 'depth', 'mask'):
+        assert err(split[k], o[k])['max'] <= 1e-4, ('split-fp16', k, err(split[k], o[k]))
+        assert err(strict[k], o[k])['max'] <= 1e-4, ('fp32', k, err(strict[k], o[k]))
+        assert err(split[k], strict[k])['max'] <= 3e-5, ('modes', k, err(split[k], strict[k]))
+        assert torch.equal(split[k], scan[k]), 'ray order changed ' + k
+    # tiny and huge-ish magnitudes: fp16 subnormal operands and values far above 1 must survive the split
+    for scale in (1e-3, 40.0):
+        d2 = dict(d)
+        d2['planes'] = d['planes'] * scale
+        d2['w1'] = d['w1'] / scale
+        o2 = oracle(d2, gpu_device)
+        t2 = ops.planes_to_texels(d2['planes'])
+        i2 = ops.decoder_pack(d2['w1'], d2['b1'], d2['w2'], d2['b2'], A)
+        r2 = ops.render_fwd(d2['cam'], d2['focal'], R, R, S, t2, i2, 0.55, A, d2['att'], True, d2['beta'], d2['alpha'],
+                            noise_coarse=d2['noise_c'], noise_fine=d2['noise_f'])
+        for k in ('rgb', 'mask'):
+            assert err(r2[k], o2[k])['max'] <= 1e-4, (scale, k, err(r2[k], o2[k]))

@@ -211,3 +211,22 @@ def test_normals_sampler_and_render(setup):
     n_sorted = n_all.gather(-2, o['perm'].unsqueeze(-1).expand(-1, -1, -1, -1, 3))
     ref_map = (o['weights'][..., None] * n_sorted).sum(dim=-2) + (1. - o['mask'][..., None])
     close(normal_map, ref_map, 3e-3, 'normal map')
+
+
+def test_parallel_model_dispatch(setup):
+    """ParallelModel.forward (run.py:569-617): EMA selection, resolution multiplier, closure hand-off."""
+    from nerf_from_image_amd.parallel import ParallelModel
+    model, cam, focal, z = setup
+    cfg = types.SimpleNamespace(use_viewdir=False, use_sdf=True, attention_values=10, fine_sampling=True)
+    render = nfi_render.make_render(cfg, {'scene_range': 0.55, 'white_background': True})
+    pm = ParallelModel(8, model=None, model_ema=model, render=render, depth_samples_per_ray=16)
+    with torch.no_grad():
+        out = pm(cam, focal, None, None, z, use_ema=True, res_multiplier=2)
+        assert out[0].shape == (2, 16, 16, 3) and out[2].shape == (2, 16, 16)
+        seen = {}
+
+        def closure(self_, rgb, alpha, sem, extra, weight):
+            seen['args'] = (self_ is pm, tuple(rgb.shape), tuple(alpha.shape), sem, extra, weight)
+            return rgb.mean() * weight
+        loss = pm(cam, focal, None, None, z, use_ema=True, closure=closure, closure_params={'weight': 2.0})
+    assert seen['args'] == (True, (2, 8, 8, 3), (2, 8, 8), None, {}, 2.0) and loss.dim() == 0
