@@ -206,11 +206,52 @@ def hip_forward(self, viewdir, c, request_model_outputs=['sampler'], model_input
     return model_outputs
 
 
+def wrapped_forward(self, viewdir, c, request_model_outputs=['sampler'], model_inputs={}):
+    """Forward for a module that HAS the reference's own Generator.forward (models/generator.py:407-686):
+    the original forward runs unchanged for everything that is not the hot path - latent handling,
+    mapping / synthesis / texture networks, path-length and the SDF regulariser branch (505-585, plain
+    PyTorch incl. its double backward) - while a forward hook captures the planes it produced; only the
+    returned ``sampler`` closure is replaced by the HIP one.  The plane producer therefore runs once."""
+    if self.use_viewdir:
+        raise NotImplementedError('use_viewdir (ViewDirectionMapper, carla only) is not implemented on the HIP path')
+    want_sampler = 'sampler' in request_model_outputs
+    req = list(request_model_outputs)
+    added_att = False
+    if want_sampler and self.attention_values > 0 and 'attention_values' not in req:
+        req.append('attention_values')           # the original forward returns the (possibly overridden) table
+        added_att = True
+    captured = {}
+    hook = self.synthesis_network.register_forward_hook(lambda mod, inp, out: captured.__setitem__('planes', out))
+    try:
+        model_outputs = self._nfi_original_forward(viewdir, c, req, model_inputs)
+    finally:
+        hook.remove()
+    if want_sampler:
+        planes = captured['planes']
+        planes = planes.view(planes.shape[0], 3, 32, planes.shape[-2], planes.shape[-1])
+        att = model_outputs.get('attention_values') if self.attention_values > 0 else None
+        model_outputs['sampler'] = make_sampler(
+            planes, self.decoder, self.scene_range, self.attention_values, att, self.use_sdf,
+            self.beta if self.use_sdf else None, self.alpha if self.use_sdf else None,
+            texel_dtype=getattr(self, 'nfi_texel_dtype', ops.TEXEL_F32), request_model_outputs=request_model_outputs)
+    if added_att:
+        del model_outputs['attention_values']
+    return model_outputs
+
+
 def attach(model, texel_dtype=ops.TEXEL_F32):
-    """Gives a reference-style Generator the HIP forward.  Returns the same module."""
+    """Gives a reference-style Generator the HIP sampler.  Returns the same module.
+
+    A module whose class implements ``forward`` itself (the reference ``Generator``) keeps that
+    forward for the non-hot-path outputs and only gets its sampler swapped (``wrapped_forward``);
+    a bare container of the required sub-modules gets the restated ``hip_forward``."""
     missing = [a for a in REQUIRED_ATTRS if not hasattr(model, a)]
     if missing:
         raise AttributeError('attach(): module lacks %s' % missing)
     model.nfi_texel_dtype = texel_dtype
-    model.forward = types.MethodType(hip_forward, model)
+    if type(model).forward is not torch.nn.Module.forward and not hasattr(model, '_nfi_original_forward'):
+        model._nfi_original_forward = model.forward          # bound method of the reference class
+        model.forward = types.MethodType(wrapped_forward, model)
+    elif not hasattr(model, '_nfi_original_forward'):
+        model.forward = types.MethodType(hip_forward, model)
     return model
