@@ -189,8 +189,12 @@ def main():
         os.environ.setdefault('MASTER_PORT', '29533')
         dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
 
+    # the library is prebuilt in-tree; if it ever has to be (re)built, exactly one rank does it
     import __graft_entry__ as entry
-    entry.build()
+    if local_rank == 0:
+        entry.build()
+    if use_dist:
+        dist.barrier()
     from nerf_from_image_amd import ops
 
     B = args.images_per_gpu
