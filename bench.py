@@ -120,7 +120,7 @@ def extras(dev, ops, d):
     >= 10x denominator)."""
     from oracle import nfi_oracle as orc
 
-    def time_render(n_img, radius, texel_dtype, iters=20):
+    def time_render(n_img, radius, texel_dtype, iters=20, R=R, S=S):
         dd = synthetic_inputs(n_img, 4321, dev)
         g = torch.Generator().manual_seed(77)
         dd['cam'] = cameras(n_img, radius, g).to(dev)
@@ -143,7 +143,10 @@ def extras(dev, ops, d):
         'b1_chairs_fp32': time_render(1, RADIUS, ops.TEXEL_F32),
         'b8_chairs_fp32': time_render(8, RADIUS, ops.TEXEL_F32),
         'b8_all_rays_hit_fp32': time_render(8, 1.3, ops.TEXEL_F32),
-        'b8_chairs_bf16_texels': time_render(8, RADIUS, ops.TEXEL_BF16)}}
+        'b8_chairs_bf16_texels': time_render(8, RADIUS, ops.TEXEL_BF16),
+        # BASELINE config 5 geometry on one GPU: 256x256 rays, 128 + 128 samples per ray
+        'b2_cfg5_256px_128+128_fp32': time_render(2, RADIUS, ops.TEXEL_F32, iters=10, R=256, S=128),
+        'b2_cfg5_256px_128+128_bf16_texels': time_render(2, RADIUS, ops.TEXEL_BF16, iters=10, R=256, S=128)}}
     # reference numerics on PyTorch-ROCm: the oracle with GPU ATen ops, 2 images, planes precomputed
     dd = synthetic_inputs(2, 4321, dev)
     nc = torch.rand((2, R, R, S), device=dev)

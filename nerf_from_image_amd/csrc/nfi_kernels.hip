@@ -508,18 +508,21 @@ extern "C" int nfi_field_query_fwd(const nfi_field_args* a, nfi_stream_t stream)
 // ------------------------------------------------------------------------------------------------
 // per-wave LDS slab used by the sampling / compositing stages
 // ------------------------------------------------------------------------------------------------
-struct __attribute__((aligned(16))) WaveSlab {
-  float cdf[128];
-  float bins[128];
-  uint32_t key[128];
-  float srt[5][128];   // depth, sigma, r, g, b in merged order
+template <int N>
+struct __attribute__((aligned(16))) WaveSlabT {
+  float cdf[N];
+  float bins[N];
+  uint32_t key[N];
+  float srt[5][N];   // depth, sigma, r, g, b in merged order
 };
+using WaveSlab = WaveSlabT<128>;       // up to 64 + 64 samples per ray
+using WaveSlabWide = WaveSlabT<256>;   // up to 128 + 128
 
 // ---- inverse CDF on a ray held one element per (slot, lane) -----------------------------------
 // bins[e] e<M, weights[e] e<M-1 (already padded with 0 past M-1).  Writes cdf/bins to the slab and
 // returns, for each of this lane's u values, the sample and the searchsorted index.
-template <int SPL>
-__device__ __forceinline__ void build_cdf(WaveSlab& slab, const float (&bins)[SPL], const float (&wts)[SPL], int M,
+template <int SPL, class Slab>
+__device__ __forceinline__ void build_cdf(Slab& slab, const float (&bins)[SPL], const float (&wts)[SPL], int M,
                                           int lane) {
   float q[SPL];
   float tot = 0.0f;
@@ -545,7 +548,8 @@ __device__ __forceinline__ void build_cdf(WaveSlab& slab, const float (&bins)[SP
   wave_lds_fence();
 }
 
-__device__ __forceinline__ float invert_cdf(const WaveSlab& slab, int M, float u, int& ind) {
+template <class Slab>
+__device__ __forceinline__ float invert_cdf(const Slab& slab, int M, float u, int& ind) {
   ind = upper_bound_lds(slab.cdf, M, u);
   int lo = ind - 1 < 0 ? 0 : ind - 1;
   int hi = ind > M - 1 ? M - 1 : ind;
@@ -585,22 +589,59 @@ __device__ __forceinline__ float resample_ray(WaveSlab& slab, float sigma, float
   return z;
 }
 
+// The same for 64 < S <= 128 (two elements per lane, element e = slot*64 + lane).
+template <int SP>
+__device__ __forceinline__ void smooth_weights_wide(const float (&w)[SP], int S, int lane, float (&sm)[SP]) {
+#pragma unroll
+  for (int j = 0; j < SP; ++j) {
+    const float prev_edge = j > 0 ? bits2f((uint32_t)__builtin_amdgcn_readlane((int)f2bits(w[j > 0 ? j - 1 : 0]), 63)) : -INFINITY;
+    const float next_edge = j + 1 < SP ? bits2f((uint32_t)__builtin_amdgcn_readlane((int)f2bits(w[j + 1 < SP ? j + 1 : j]), 0)) : -INFINITY;
+    const float wp = lane_prev(w[j], prev_edge);
+    float wn = lane_next(w[j], next_edge);
+    if (j * 64 + lane >= S - 1) wn = -INFINITY;
+    const float m0 = fmaxf(wp, w[j]), m1 = fmaxf(w[j], wn);
+    sm[j] = (m0 + m1) / 2.0f + 0.01f;
+  }
+}
+
+template <int SP, class Slab>
+__device__ __forceinline__ void resample_ray_wide(Slab& slab, const float (&sigma)[SP], const float (&t)[SP], int S, float dnorm,
+                                                  const float (&u)[SP], int lane, float (&z)[SP], float (&w)[SP],
+                                                  float (&sm)[SP], int (&ind)[SP]) {
+  float sg[SP];
+#pragma unroll
+  for (int j = 0; j < SP; ++j) sg[j] = (j * 64 + lane < S) ? sigma[j] : 0.0f;
+  ray_weights<SP>(sg, t, S, dnorm, lane, w);
+  smooth_weights_wide<SP>(w, S, lane, sm);
+  float tn[SP], mid[SP], wts[SP];
+  next_elem<SP>(t, tn, lane);
+  next_elem<SP>(sm, wts, lane);                               // weights e = 0..S-3  <- smooth[e+1]
+#pragma unroll
+  for (int j = 0; j < SP; ++j) mid[j] = 0.5f * (tn[j] + t[j]);  // bins e = 0..S-2
+  build_cdf<SP>(slab, mid, wts, S - 1, lane);
+#pragma unroll
+  for (int j = 0; j < SP; ++j) z[j] = invert_cdf(slab, S - 1, u[j], ind[j]);
+}
+
 // ---- merge + composite ---------------------------------------------------------------------------
 // Every lane owns up to 2 input samples (element e = slot*64+lane of cat(a,b)); computes the
 // stable ascending rank of each key among the n keys, scatters (depth, sigma, rgb) to the slab in
 // merged order.  rank_out: merged position of each of this lane's elements.
-__device__ __forceinline__ void merge_scatter(WaveSlab& slab, const float (&dep)[2], const float (&sig)[2],
-                                              const float (&cr)[2], const float (&cg)[2], const float (&cb)[2], int n,
-                                              int lane, int (&rank_out)[2]) {
-  uint32_t key[2];
+template <int NS, class Slab>
+__device__ __forceinline__ void merge_scatter(Slab& slab, const float (&dep)[NS], const float (&sig)[NS],
+                                              const float (&cr)[NS], const float (&cg)[NS], const float (&cb)[NS],
+                                              const int (&eidx)[NS], int n, int (&rank_out)[NS]) {
+  // eidx[j]: index of this lane's j-th element in cat(a, b) (>= n: no element)
+  uint32_t key[NS];
 #pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    int e = j * 64 + lane;
+  for (int j = 0; j < NS; ++j) {
     key[j] = ordered_key(dep[j]);
-    if (e < n) slab.key[e] = key[j];
+    if (eidx[j] < n) slab.key[eidx[j]] = key[j];
   }
   wave_lds_fence();
-  int rank[2] = {0, 0};
+  int rank[NS];
+#pragma unroll
+  for (int j = 0; j < NS; ++j) rank[j] = 0;
   const uint4* kv = reinterpret_cast<const uint4*>(slab.key);
   const int n4 = (n + 3) >> 2;
   for (int i = 0; i < n4; ++i) {
@@ -611,19 +652,17 @@ __device__ __forceinline__ void merge_scatter(WaveSlab& slab, const float (&dep)
       int idx = 4 * i + c;
       bool in = idx < n;
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        int e = j * 64 + lane;
-        bool before = (qq[c] < key[j]) || (qq[c] == key[j] && idx < e);
+      for (int j = 0; j < NS; ++j) {
+        bool before = (qq[c] < key[j]) || (qq[c] == key[j] && idx < eidx[j]);
         rank[j] += (in && before) ? 1 : 0;
       }
     }
   }
   wave_lds_fence();
 #pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    int e = j * 64 + lane;
+  for (int j = 0; j < NS; ++j) {
     rank_out[j] = rank[j];
-    if (e < n) {
+    if (eidx[j] < n) {
       int r = rank[j];
       slab.srt[0][r] = dep[j]; slab.srt[1][r] = sig[j];
       slab.srt[2][r] = cr[j]; slab.srt[3][r] = cg[j]; slab.srt[4][r] = cb[j];
@@ -699,19 +738,20 @@ __device__ __forceinline__ void merge_pair_scatter(WaveSlab& slab, const MergeIn
 struct CompositeOut { float r, g, b, depth, mask; };
 
 // composite the n samples sitting in merged order in the slab (lib/nerf_utils.py:123-161)
-__device__ __forceinline__ CompositeOut composite_slab(const WaveSlab& slab, int n, float dnorm, int white, int lane,
-                                                       float (&w_out)[2]) {
-  float dep[2], sig[2], w[2];
+template <int NS, class Slab>
+__device__ __forceinline__ CompositeOut composite_slab(const Slab& slab, int n, float dnorm, int white, int lane,
+                                                       float (&w_out)[NS]) {
+  float dep[NS], sig[NS], w[NS];
 #pragma unroll
-  for (int j = 0; j < 2; ++j) {
+  for (int j = 0; j < NS; ++j) {
     int e = j * 64 + lane;
     dep[j] = (e < n) ? slab.srt[0][e] : 0.0f;
     sig[j] = (e < n) ? slab.srt[1][e] : 0.0f;
   }
-  ray_weights<2>(sig, dep, n, dnorm, lane, w);
+  ray_weights<NS>(sig, dep, n, dnorm, lane, w);
   float r = 0.0f, g = 0.0f, b = 0.0f, d = 0.0f, m = 0.0f;
 #pragma unroll
-  for (int j = 0; j < 2; ++j) {
+  for (int j = 0; j < NS; ++j) {
     int e = j * 64 + lane;
     if (e < n) {
       r += w[j] * slab.srt[2][e]; g += w[j] * slab.srt[3][e]; b += w[j] * slab.srt[4][e];
@@ -817,26 +857,63 @@ __global__ __launch_bounds__(256) void resample_kernel(nfi_resample_args a) {
   if (a.cdf && lane < S - 1) a.cdf[ray * (S - 1) + lane] = slab.cdf[lane];
 }
 
-extern "C" int nfi_resample(const nfi_resample_args* a, nfi_stream_t stream) {
-  REQUIRE(a && a->sigma && a->ray_directions && a->depth && a->u && a->fine_depth, "resample: null pointer");
-  REQUIRE(a->n_rays > 0 && a->n_samples >= 4 && a->n_samples <= 64, "resample: n_samples must be in [4,64]");
-  hipLaunchKernelGGL(resample_kernel, dim3((unsigned)((a->n_rays + 3) / 4)), dim3(256), 0, (hipStream_t)stream, *a);
-  return check_launch("resample");
-}
-
-__global__ __launch_bounds__(256) void composite_kernel(nfi_composite_args a) {
+__global__ __launch_bounds__(256) void resample_wide_kernel(nfi_resample_args a) {
   __shared__ WaveSlab slabs[4];
   const int lane = lane_id();
   const int wave = threadIdx.x >> 6;
   const int64_t ray = (int64_t)blockIdx.x * 4 + wave;
   if (ray >= a.n_rays) return;
   WaveSlab& slab = slabs[wave];
-  const int na = a.n_a, nb = a.n_b, n = na + nb;
-  float dep[2], sig[2], cr[2], cg[2], cb[2];
+  const int S = a.n_samples;
+  float sigma[2], t[2], u[2], z[2], w[2], sm[2];
+  int ind[2];
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
+    const int e = j * 64 + lane;
+    sigma[j] = e < S ? a.sigma[ray * S + e] : 0.0f;
+    t[j] = e < S ? a.depth[ray * S + e] : 0.0f;
+    u[j] = e < S ? a.u[ray * a.u_row_stride + e] : 0.0f;
+  }
+  float dn = norm3(a.ray_directions[ray * 3], a.ray_directions[ray * 3 + 1], a.ray_directions[ray * 3 + 2]);
+  resample_ray_wide<2>(slab, sigma, t, S, dn, u, lane, z, w, sm, ind);
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int e = j * 64 + lane;
+    if (e < S) {
+      a.fine_depth[ray * S + e] = z[j];
+      if (a.weights) a.weights[ray * S + e] = w[j];
+      if (a.smooth) a.smooth[ray * S + e] = sm[j];
+      if (a.inds) a.inds[ray * S + e] = ind[j];
+    }
+    if (a.cdf && e < S - 1) a.cdf[ray * (S - 1) + e] = slab.cdf[e];
+  }
+}
+
+extern "C" int nfi_resample(const nfi_resample_args* a, nfi_stream_t stream) {
+  REQUIRE(a && a->sigma && a->ray_directions && a->depth && a->u && a->fine_depth, "resample: null pointer");
+  REQUIRE(a->n_rays > 0 && a->n_samples >= 4 && a->n_samples <= NFI_MAX_SAMPLES, "resample: n_samples must be in [4,128]");
+  const dim3 grid((unsigned)((a->n_rays + 3) / 4));
+  if (a->n_samples <= 64) hipLaunchKernelGGL(resample_kernel, grid, dim3(256), 0, (hipStream_t)stream, *a);
+  else hipLaunchKernelGGL(resample_wide_kernel, grid, dim3(256), 0, (hipStream_t)stream, *a);
+  return check_launch("resample");
+}
+
+template <int NS>
+__global__ __launch_bounds__(256) void composite_kernel(nfi_composite_args a) {
+  __shared__ WaveSlabT<64 * NS> slabs[4];
+  const int lane = lane_id();
+  const int wave = threadIdx.x >> 6;
+  const int64_t ray = (int64_t)blockIdx.x * 4 + wave;
+  if (ray >= a.n_rays) return;
+  auto& slab = slabs[wave];
+  const int na = a.n_a, nb = a.n_b, n = na + nb;
+  float dep[NS], sig[NS], cr[NS], cg[NS], cb[NS];
+  int eidx[NS];
+#pragma unroll
+  for (int j = 0; j < NS; ++j) {
     int e = j * 64 + lane;
     dep[j] = sig[j] = cr[j] = cg[j] = cb[j] = 0.0f;
+    eidx[j] = e;
     if (e < na) {
       size_t i = (size_t)ray * na + e;
       dep[j] = a.depth_a[i]; sig[j] = a.sigma_a[i];
@@ -847,13 +924,13 @@ __global__ __launch_bounds__(256) void composite_kernel(nfi_composite_args a) {
       cr[j] = a.rgb_b[i * 3]; cg[j] = a.rgb_b[i * 3 + 1]; cb[j] = a.rgb_b[i * 3 + 2];
     }
   }
-  int rank[2];
+  int rank[NS];
   if (nb > 0) {
-    merge_scatter(slab, dep, sig, cr, cg, cb, n, lane, rank);
+    merge_scatter<NS>(slab, dep, sig, cr, cg, cb, eidx, n, rank);
   } else {
     // list a is composited in the order given (render_volume_density does not sort)
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
+    for (int j = 0; j < NS; ++j) {
       int e = j * 64 + lane;
       rank[j] = e;
       if (e < n) { slab.srt[0][e] = dep[j]; slab.srt[1][e] = sig[j]; slab.srt[2][e] = cr[j]; slab.srt[3][e] = cg[j]; slab.srt[4][e] = cb[j]; }
@@ -861,15 +938,15 @@ __global__ __launch_bounds__(256) void composite_kernel(nfi_composite_args a) {
     wave_lds_fence();
   }
   float dn = norm3(a.ray_directions[ray * 3], a.ray_directions[ray * 3 + 1], a.ray_directions[ray * 3 + 2]);
-  float w[2];
-  CompositeOut o = composite_slab(slab, n, dn, a.white_background, lane, w);
+  float w[NS];
+  CompositeOut o = composite_slab<NS>(slab, n, dn, a.white_background, lane, w);
   if (lane == 0) {
     a.rgb_map[ray * 3] = o.r; a.rgb_map[ray * 3 + 1] = o.g; a.rgb_map[ray * 3 + 2] = o.b;
     a.depth_map[ray] = o.depth;
     a.mask[ray] = o.mask;
   }
 #pragma unroll
-  for (int j = 0; j < 2; ++j) {
+  for (int j = 0; j < NS; ++j) {
     int e = j * 64 + lane;
     if (e < n) {
       if (a.weights) a.weights[(size_t)ray * n + e] = w[j];
@@ -882,18 +959,18 @@ __global__ __launch_bounds__(256) void composite_kernel(nfi_composite_args a) {
     wave_lds_fence();
     // park the merged-order weights in the slab, then every lane accumulates its own elements
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
+    for (int j = 0; j < NS; ++j) {
       int e = j * 64 + lane;
       if (e < n) slab.cdf[e] = w[j];
     }
     wave_lds_fence();
-    float we[2];
+    float we[NS];
 #pragma unroll
-    for (int j = 0; j < 2; ++j) { int e = j * 64 + lane; we[j] = e < n ? slab.cdf[rank[j]] : 0.0f; }
+    for (int j = 0; j < NS; ++j) { int e = j * 64 + lane; we[j] = e < n ? slab.cdf[rank[j]] : 0.0f; }
     for (int c = 0; c < a.n_extra; ++c) {
       float acc = 0.0f;
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
+      for (int j = 0; j < NS; ++j) {
         int e = j * 64 + lane;
         if (e < na) acc += we[j] * a.extra_a[((size_t)ray * na + e) * a.n_extra + c];
         else if (e < n) acc += we[j] * a.extra_b[((size_t)ray * nb + (e - na)) * a.n_extra + c];
@@ -907,11 +984,13 @@ __global__ __launch_bounds__(256) void composite_kernel(nfi_composite_args a) {
 extern "C" int nfi_composite_fwd(const nfi_composite_args* a, nfi_stream_t stream) {
   REQUIRE(a && a->ray_directions && a->depth_a && a->sigma_a && a->rgb_a && a->rgb_map && a->depth_map && a->mask,
           "composite: null pointer");
-  REQUIRE(a->n_rays > 0 && a->n_a > 0 && a->n_b >= 0 && a->n_a + a->n_b <= NFI_MAX_SAMPLES,
-          "composite: need 1 <= n_a + n_b <= 128");
+  REQUIRE(a->n_rays > 0 && a->n_a > 0 && a->n_b >= 0 && a->n_a + a->n_b <= 2 * NFI_MAX_SAMPLES,
+          "composite: need 1 <= n_a + n_b <= 256");
   REQUIRE(a->n_b == 0 || (a->depth_b && a->sigma_b && a->rgb_b), "composite: list b missing");
   REQUIRE(a->n_extra == 0 || (a->extra_a && (a->n_b == 0 || a->extra_b)), "composite: extra attribute missing");
-  hipLaunchKernelGGL(composite_kernel, dim3((unsigned)((a->n_rays + 3) / 4)), dim3(256), 0, (hipStream_t)stream, *a);
+  const dim3 grid((unsigned)((a->n_rays + 3) / 4));
+  if (a->n_a + a->n_b <= 128) hipLaunchKernelGGL(composite_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, *a);
+  else hipLaunchKernelGGL(composite_kernel<4>, grid, dim3(256), 0, (hipStream_t)stream, *a);
   return check_launch("composite_fwd");
 }
 
@@ -1090,7 +1169,7 @@ __global__ __launch_bounds__(256, OCC) void render_fwd_kernel(RenderKernelParams
         wave_lds_fence();
       }
       float w[2];
-      CompositeOut o = composite_slab(slab, n, dnorm, k.white, lane, w);
+      CompositeOut o = composite_slab<2>(slab, n, dnorm, k.white, lane, w);
       if (lane == 0) {
         k.rgb[(size_t)ray * 3] = o.r; k.rgb[(size_t)ray * 3 + 1] = o.g; k.rgb[(size_t)ray * 3 + 2] = o.b;
         k.depth[ray] = o.depth; k.mask[ray] = o.mask;
@@ -1134,6 +1213,175 @@ __global__ __launch_bounds__(256, OCC) void render_fwd_kernel(RenderKernelParams
   }
 }
 
+// The same pipeline for 64 < S <= 128 samples per pass (BASELINE cfg5, ray_multiplier=2): every lane
+// owns two coarse and two fine samples (element e = slot*64 + lane), the field is marched 64 points
+// at a time, and the merge ranks all 2S keys against each other.
+template <int TEX, bool ATT, bool TAPS, int PREC>
+__global__ __launch_bounds__(256, 2) void render_fwd_wide_kernel(RenderKernelParams k) {
+  __shared__ __attribute__((aligned(16))) float lds[kLdsImageFloats];
+  __shared__ __attribute__((aligned(16))) float vfs[4][64];
+  __shared__ WaveSlabWide slabs[4];
+  if (PREC == 1) {
+    for (int i = threadIdx.x; i < kB1F; i += blockDim.x) lds[i] = k.image[kW1H + i];
+    for (int i = kB1F + threadIdx.x; i < kLdsImageFloats; i += blockDim.x) lds[i] = k.image[i];
+  } else {
+    for (int i = threadIdx.x; i < kLdsImageFloats; i += blockDim.x) lds[i] = k.image[i];
+  }
+  __syncthreads();
+  const int lane = lane_id();
+  const int wave = threadIdx.x >> 6;
+  WaveSlabWide& slab = slabs[wave];
+  float* vf = vfs[wave];
+  const int S = k.S;
+  const float fill_near = ordered_key_inv(~k.reduce[0]), fill_far = ordered_key_inv(k.reduce[1]);
+  const float bg = k.white ? 1.0f : 0.0f;
+  const size_t tb = TEX == 0 ? 128 : 64;
+  const uint32_t n_rays = (uint32_t)k.n_scenes * (uint32_t)k.hw;
+  const uint32_t tiles_x = (uint32_t)k.width >> 3;
+  auto ray_of = [&](uint32_t pos) -> uint32_t {
+    if (!k.tile_order) return pos;
+    const uint32_t scene = pos / (uint32_t)k.hw, p = pos - scene * (uint32_t)k.hw;
+    const uint32_t tile = p >> 6, in = p & 63u;
+    const uint32_t ty = tile / tiles_x, tx = tile - ty * tiles_x;
+    return scene * (uint32_t)k.hw + ((ty << 3) + (in >> 3)) * (uint32_t)k.width + (tx << 3) + (in & 7u);
+  };
+  FieldParams P = make_field_params(k.texels, k.res, TEX, k.A, k.use_sdf, k.beta, k.alpha, lds);
+  P.vf = vf;
+  int cur_scene = -1;
+  uint32_t cur = 0, nxt = 0;
+  if (lane == 0) cur = atomicAdd(k.counter, 1u);
+  cur = (uint32_t)__builtin_amdgcn_readfirstlane((int)cur);
+  while (cur < n_rays) {
+    if (lane == 0) nxt = atomicAdd(k.counter, 1u);
+    const uint32_t ray = ray_of(cur);
+    const uint32_t hitb = k.hit[ray];
+    if (k.skip_missed && !(hitb & 2)) {
+      if (lane == 0) {
+        k.rgb[(size_t)ray * 3] = bg; k.rgb[(size_t)ray * 3 + 1] = bg; k.rgb[(size_t)ray * 3 + 2] = bg;
+        k.depth[ray] = 0.0f; k.mask[ray] = 0.0f;
+      }
+    } else {
+      const int scene = (int)(ray / (uint32_t)k.hw);
+      if (scene != cur_scene) {
+        cur_scene = scene;
+        const char* tex_scene = reinterpret_cast<const char*>(k.texels) + (size_t)scene * 3 * k.res * k.res * tb;
+        P.rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(tex_scene), 0, (int)(3u * P.plane_bytes), 0x00020000);
+        wave_lds_fence();
+        {
+          int c = lane & 3, row = lane >> 2;
+          float v = 0.0f;
+          if (k.att && c < 3 && row >= 1 && row <= k.A) v = k.att[((size_t)scene * k.A + (row - 1)) * 3 + c];
+          vf[lane] = v;
+        }
+        wave_lds_fence();
+      }
+      const size_t r3 = (size_t)ray * 3;
+      const float ox = k.ro[r3], oy = k.ro[r3 + 1], oz = k.ro[r3 + 2];
+      const float dx = k.rd[r3], dy = k.rd[r3 + 1], dz = k.rd[r3 + 2];
+      float near = k.near_raw[ray], far = k.far_raw[ray];
+      finish_planes((hitb & 1) != 0, fill_near, fill_far, near, far);
+      const float dnorm = norm3(dx, dy, dz);
+      const size_t rs = (size_t)ray * S;
+      float* stage = &slab.srt[0][0];
+
+      // ---- coarse pass ----
+      float tc[2], sc[2], rc[2], gc[2], bc[2];
+      bool val[2];
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int e = j * 64 + lane;
+        val[j] = e < S;
+        const float nz = (k.noise_c && val[j]) ? k.noise_c[rs + e] : 0.0f;
+        tc[j] = val[j] ? stratified_depth(near, far, e, S, nz, k.noise_c != nullptr) : 0.0f;
+        SampleOut q = field_wave<TEX, ATT, true, PREC>(P, k.scene_range, lane, ox + dx * tc[j], oy + dy * tc[j], oz + dz * tc[j],
+                                                       val[j], nullptr, nullptr, stage, nullptr);
+        sc[j] = q.sigma; rc[j] = q.r; gc[j] = q.g; bc[j] = q.b;
+      }
+      int n = S;
+      float dep[4], sig[4], cr[4], cg[4], cb[4];
+      int eidx[4], rank[4];
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        dep[j] = tc[j]; sig[j] = sc[j]; cr[j] = rc[j]; cg[j] = gc[j]; cb[j] = bc[j];
+        eidx[j] = val[j] ? j * 64 + lane : 0x7fffffff;
+        dep[2 + j] = sig[2 + j] = cr[2 + j] = cg[2 + j] = cb[2 + j] = 0.0f;
+        eidx[2 + j] = 0x7fffffff;
+        rank[j] = j * 64 + lane; rank[2 + j] = 0;
+      }
+      if (k.fine) {
+        // ---- hierarchical resampling + fine pass ----
+        float u[2], tf[2], wtap[2], smtap[2];
+        int ind[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) u[j] = val[j] ? k.noise_f[(size_t)ray * k.noise_f_stride + j * 64 + lane] : 0.0f;
+        wave_lds_fence();
+        resample_ray_wide<2>(slab, sc, tc, S, dnorm, u, lane, tf, wtap, smtap, ind);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          SampleOut q = field_wave<TEX, ATT, true, PREC>(P, k.scene_range, lane, ox + dx * tf[j], oy + dy * tf[j], oz + dz * tf[j],
+                                                         val[j], nullptr, nullptr, stage, nullptr);
+          dep[2 + j] = tf[j]; sig[2 + j] = q.sigma; cr[2 + j] = q.r; cg[2 + j] = q.g; cb[2 + j] = q.b;
+          eidx[2 + j] = val[j] ? S + j * 64 + lane : 0x7fffffff;
+          if constexpr (TAPS) {
+            if (val[j]) {
+              const size_t i = rs + j * 64 + lane;
+              if (k.t_fine) k.t_fine[i] = tf[j];
+              if (k.sigma_fine) k.sigma_fine[i] = q.sigma;
+              if (k.rgb_fine) { float* o3 = k.rgb_fine + i * 3; o3[0] = q.r; o3[1] = q.g; o3[2] = q.b; }
+            }
+          }
+        }
+        n = 2 * S;
+        wave_lds_fence();
+        merge_scatter<4>(slab, dep, sig, cr, cg, cb, eidx, n, rank);
+      } else {
+        wave_lds_fence();
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const int e = j * 64 + lane;
+          if (val[j]) { slab.srt[0][e] = tc[j]; slab.srt[1][e] = sc[j]; slab.srt[2][e] = rc[j]; slab.srt[3][e] = gc[j]; slab.srt[4][e] = bc[j]; }
+        }
+        wave_lds_fence();
+      }
+      float w[4];
+      CompositeOut o = composite_slab<4>(slab, n, dnorm, k.white, lane, w);
+      if (lane == 0) {
+        k.rgb[(size_t)ray * 3] = o.r; k.rgb[(size_t)ray * 3 + 1] = o.g; k.rgb[(size_t)ray * 3 + 2] = o.b;
+        k.depth[ray] = o.depth; k.mask[ray] = o.mask;
+      }
+      if constexpr (TAPS) {
+        if (lane == 0) {
+          if (k.near_plane) k.near_plane[ray] = near;
+          if (k.far_plane) k.far_plane[ray] = far;
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          if (val[j]) {
+            const size_t i = rs + j * 64 + lane;
+            if (k.t_coarse) k.t_coarse[i] = tc[j];
+            if (k.sigma_coarse) k.sigma_coarse[i] = sc[j];
+            if (k.rgb_coarse) { float* o3 = k.rgb_coarse + i * 3; o3[0] = rc[j]; o3[1] = gc[j]; o3[2] = bc[j]; }
+            if (k.perm) {
+              k.perm[(size_t)ray * n + rank[j]] = j * 64 + lane;
+              if (k.fine) k.perm[(size_t)ray * n + rank[2 + j]] = S + j * 64 + lane;
+            }
+          }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          int e = j * 64 + lane;
+          if (e < n) {
+            if (k.weights) k.weights[(size_t)ray * n + e] = w[j];
+            if (k.t_sorted) k.t_sorted[(size_t)ray * n + e] = slab.srt[0][e];
+          }
+        }
+      }
+      wave_lds_fence();  // slab is reused by the next ray
+    }
+    cur = (uint32_t)__builtin_amdgcn_readfirstlane((int)nxt);
+  }
+}
+
 extern "C" size_t nfi_render_workspace_bytes(int64_t n_rays) {
   // ro, rd, near_raw, far_raw (fp32) + hit (u8, padded) + reduce[4]
   size_t n = (size_t)n_rays;
@@ -1143,7 +1391,8 @@ extern "C" size_t nfi_render_workspace_bytes(int64_t n_rays) {
 extern "C" int nfi_render_fwd(const nfi_render_args* a, nfi_stream_t stream) {
   REQUIRE(a && a->cam2world && a->rgb && a->depth && a->mask && a->workspace, "render: null pointer");
   REQUIRE(a->n_scenes > 0 && a->height > 0 && a->width > 0, "render: bad image shape");
-  REQUIRE(a->n_samples >= 4 && a->n_samples <= 64, "render: n_samples must be in [4,64] per pass");
+  REQUIRE(a->n_samples >= 4 && a->n_samples <= NFI_MAX_SAMPLES, "render: n_samples must be in [4,128] per pass");
+  REQUIRE(a->n_samples <= 64 || !a->profile_cycles, "render: the cycle profile exists for n_samples <= 64 only");
   REQUIRE(!a->fine_sampling || a->noise_fine, "render: fine sampling needs u (noise_fine)");
   REQUIRE(!a->semantics, "render: composited semantics are produced by nfi_composite_fwd, not the fused kernel");
   int rc = check_field_common(a->texels, a->plane_res, a->texel_dtype, a->decoder_image, a->n_attention,
@@ -1203,11 +1452,25 @@ extern "C" int nfi_render_fwd(const nfi_render_args* a, nfi_stream_t stream) {
     else if (strict) hipLaunchKernelGGL((render_fwd_kernel<TEX, ATT, 3, false, 0>), grid, dim3(256), 0, s, k);          \
     else hipLaunchKernelGGL((render_fwd_kernel<TEX, ATT, 3, false, 1>), grid, dim3(256), 0, s, k);                      \
   } while (0)
-  if (a->texel_dtype == NFI_TEXEL_F32) {
+#define NFI_LAUNCH_RENDER_WIDE(TEX, ATT)                                                                             \
+  do {                                                                                                                \
+    if (any_tap && strict) hipLaunchKernelGGL((render_fwd_wide_kernel<TEX, ATT, true, 0>), grid, dim3(256), 0, s, k);   \
+    else if (any_tap) hipLaunchKernelGGL((render_fwd_wide_kernel<TEX, ATT, true, 1>), grid, dim3(256), 0, s, k);        \
+    else if (strict) hipLaunchKernelGGL((render_fwd_wide_kernel<TEX, ATT, false, 0>), grid, dim3(256), 0, s, k);        \
+    else hipLaunchKernelGGL((render_fwd_wide_kernel<TEX, ATT, false, 1>), grid, dim3(256), 0, s, k);                    \
+  } while (0)
+  if (a->n_samples > 64) {
+    if (a->texel_dtype == NFI_TEXEL_F32) {
+      if (att) NFI_LAUNCH_RENDER_WIDE(0, true); else NFI_LAUNCH_RENDER_WIDE(0, false);
+    } else {
+      if (att) NFI_LAUNCH_RENDER_WIDE(1, true); else NFI_LAUNCH_RENDER_WIDE(1, false);
+    }
+  } else if (a->texel_dtype == NFI_TEXEL_F32) {
     if (att) NFI_LAUNCH_RENDER(0, true); else NFI_LAUNCH_RENDER(0, false);
   } else {
     if (att) NFI_LAUNCH_RENDER(1, true); else NFI_LAUNCH_RENDER(1, false);
   }
+#undef NFI_LAUNCH_RENDER_WIDE
 #undef NFI_LAUNCH_RENDER
   if (a->event_stop) (void)hipEventRecord((hipEvent_t)a->event_stop, s);
   return check_launch("render_fwd");

@@ -55,8 +55,8 @@ def _render(cfg, dcfg, target_model, height, width, tform_cam2world, focal_lengt
             depth_samples_per_ray, randomize=True, compute_normals=False, compute_semantics=False,
             compute_coords=False, extra_model_outputs=[], extra_model_inputs={}, force_no_cam_grad=False):
     S = depth_samples_per_ray
-    if S > 64:
-        raise NotImplementedError('depth_samples_per_ray > 64 per pass is not supported by the HIP kernels yet')
+    if S > 128:
+        raise NotImplementedError('depth_samples_per_ray > 128 per pass is not supported by the HIP kernels')
     scene_range = dcfg['scene_range']
     white = dcfg['white_background']
     if cfg.use_viewdir:

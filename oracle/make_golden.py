@@ -140,6 +140,13 @@ CASES = {
     'persp_s64_fine_rand': dict(B=1, H=8, W=8, S=64, scene_range=0.55, radius=1.3, focal=1.0254,
                                 white=True, fine=True, randomize=True, sdf=True, A=10, alpha=0.02,
                                 beta=0.1, bbox=False, ortho=False),
+    # BASELINE cfg5 (ray_multiplier=2): 128 + 128 samples per ray, and a ragged 96 + 96
+    'persp_s128_fine_rand': dict(B=1, H=6, W=6, S=128, scene_range=0.55, radius=1.3, focal=1.0254,
+                                 white=True, fine=True, randomize=True, sdf=True, A=10, alpha=0.02,
+                                 beta=0.1, bbox=False, ortho=False),
+    'persp_s96_black_fine_det': dict(B=1, H=6, W=6, S=96, scene_range=0.55, radius=1.3, focal=1.0254,
+                                     white=False, fine=True, randomize=False, sdf=True, A=10, alpha=0.02,
+                                     beta=0.1, bbox=False, ortho=False),
 }
 
 PLANE_RES = 32

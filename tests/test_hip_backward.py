@@ -35,7 +35,8 @@ def oracle_merge_composite(rd, t_a, s_a, c_a, t_b, s_b, c_b, e_a, e_b, white):
 
 
 @pytest.mark.parametrize('two_lists,white,n_a,n_b,extras', [(True, True, 64, 64, 0), (True, False, 16, 16, 5),
-                                                            (False, True, 32, 0, 3), (True, True, 40, 24, 0)])
+                                                            (False, True, 32, 0, 3), (True, True, 40, 24, 0),
+                                                            (True, False, 128, 128, 2), (True, True, 96, 70, 0)])
 def test_composite_backward(gpu_device, two_lists, white, n_a, n_b, extras):
     g = torch.Generator().manual_seed(17 + n_a + extras)
     N = (3, 5, 7)

@@ -18,7 +18,7 @@ pytestmark = pytest.mark.gpu
 R, S, A, PR = 128, 64, 10, 256
 
 
-def make_inputs(B, dev, radius=2.0, seed=1234):
+def make_inputs(B, dev, radius=2.0, seed=1234, R=R, S=S):
     g = torch.Generator().manual_seed(seed)
     low = torch.randn(B * 3, 32, 16, 16, generator=g)
     planes = torch.nn.functional.interpolate(low, size=(PR, PR), mode='bilinear', align_corners=True)
@@ -38,7 +38,7 @@ def make_inputs(B, dev, radius=2.0, seed=1234):
 
 
 def hip(d, white=True, skip=True, att=None, sl=slice(None), taps=()):
-    B = d['cam'][sl].shape[0]
+    R, S = d['noise_c'].shape[1], d['noise_c'].shape[3]
     texels = ops.planes_to_texels(d['planes'][sl].contiguous())
     image = ops.decoder_pack(d['w1'], d['b1'], d['w2'], d['b2'], A)
     nf = d['noise_f'].view(-1, R * R, S)[sl].reshape(-1, S)
@@ -49,6 +49,7 @@ def hip(d, white=True, skip=True, att=None, sl=slice(None), taps=()):
 
 
 def oracle(d, dev, white=True):
+    R, S = d['noise_c'].shape[1], d['noise_c'].shape[3]
     c = {k: v.to(dev) for k, v in d.items()}
     with torch.no_grad():
         return orc.render(c['planes'], c['w1'], c['b1'], c['w2'], c['b2'], c['cam'], c['focal'], R, R, S, 0.55,
@@ -71,6 +72,25 @@ def test_cfg2_single_image_against_oracle(gpu_device):
     flips = (r['perm'].cpu().long() != o_cpu['perm']).float().mean().item()
     assert flips <= 1e-3, flips
     assert err(r['t_fine'], o_cpu['t_fine'])['max'] <= 1e-4
+
+
+def test_cfg5_single_image_against_oracle(gpu_device):
+    """BASELINE cfg5 geometry: 256x256 rays, 128 + 128 samples per ray (res_multiplier = ray_multiplier = 2)."""
+    d = make_inputs(1, gpu_device, radius=1.6, R=256, S=128)
+    r = hip(d, taps=('perm', 't_fine'))
+    o_gpu = oracle(d, gpu_device)
+    for k in ('rgb', 'depth', 'mask'):
+        e_gpu = err(r[k], o_gpu[k])
+        assert e_gpu['max'] <= 1e-4 and e_gpu['nonfinite'] == 0, (k, 'vs PyTorch-ROCm reference numerics', e_gpu)
+    assert o_gpu['mask'].mean() > 0.2, 'scene should not be empty'
+    flips = (r['perm'].long() != o_gpu['perm']).float().mean().item()
+    assert flips <= 2e-3, flips
+    assert err(r['t_fine'], o_gpu['t_fine'])['max'] <= 1e-4
+    # the skip of missed rays stays exact, and the no-tap kernel gives the same image as the tap kernel
+    r2 = hip(d)
+    r3 = hip(d, skip=False)
+    for k in ('rgb', 'depth', 'mask'):
+        assert torch.equal(r2[k], r[k]) and torch.equal(r3[k], r[k]), k
 
 
 def test_cfg2_batch_properties(gpu_device):
