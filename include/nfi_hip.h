@@ -44,7 +44,7 @@ typedef enum nfi_status {
 enum { NFI_PLANE_CHANNELS = 32, NFI_HIDDEN = 64, NFI_MAX_ATTENTION = 14, NFI_MAX_SAMPLES = 128 };
 
 /* texel storage type of the channel-last plane image */
-enum { NFI_TEXEL_F32 = 0, NFI_TEXEL_BF16 = 1 };
+enum { NFI_TEXEL_F32 = 0, NFI_TEXEL_BF16 = 1, NFI_TEXEL_F16 = 2 };
 
 const char* nfi_last_error(void);
 int nfi_version(void);

@@ -346,6 +346,20 @@ __device__ __forceinline__ void load_texel8<1>(const FieldParams& P, uint32_t vo
   t[6] = bits2f(a.w << 16); t[7] = bits2f(a.w & 0xFFFF0000u);
 }
 
+template <>
+__device__ __forceinline__ void load_texel8<2>(const FieldParams& P, uint32_t voff, uint32_t soff, int imm,
+                                               float (&t)[8]) {
+  // fp16 texel = 64 B; same channel ownership as bf16
+  typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+  u32x4 a = __builtin_amdgcn_raw_buffer_load_b128(P.rsrc, voff + imm, soff, 0);
+  const uint32_t w[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const f16x2 h = __builtin_bit_cast(f16x2, w[i]);
+    t[2 * i] = (float)h.x; t[2 * i + 1] = (float)h.y;
+  }
+}
+
 struct TileOut {
   float sdf, sigma, r, g, b;
 };

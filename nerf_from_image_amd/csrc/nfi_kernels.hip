@@ -60,6 +60,16 @@ __global__ __launch_bounds__(256) void planes_to_texels_kernel(const float* __re
       float4* dst = reinterpret_cast<float4*>(reinterpret_cast<float*>(texels) + ((size_t)img * hw + px0 + p) * kC + q * 8);
       dst[0] = make_float4(v[0], v[1], v[2], v[3]);
       dst[1] = make_float4(v[4], v[5], v[6], v[7]);
+    } else if (TEX == 2) {
+      typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+      uint32_t w[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        f16x2 h = {(_Float16)v[2 * k], (_Float16)v[2 * k + 1]};   // round-to-nearest-even fp32 -> fp16
+        w[k] = __builtin_bit_cast(uint32_t, h);
+      }
+      uint4* dst = reinterpret_cast<uint4*>(reinterpret_cast<uint16_t*>(texels) + ((size_t)img * hw + px0 + p) * kC + q * 8);
+      dst[0] = make_uint4(w[0], w[1], w[2], w[3]);
     } else {
       uint32_t w[4];
 #pragma unroll
@@ -102,13 +112,15 @@ extern "C" int nfi_planes_to_texels(const float* planes, void* texels, int n_sce
                                     nfi_stream_t stream) {
   REQUIRE(planes && texels, "planes_to_texels: null pointer");
   REQUIRE(n_scenes > 0 && plane_res >= 2 && plane_res <= 1024, "planes_to_texels: plane_res must be in [2,1024]");
-  REQUIRE(texel_dtype == NFI_TEXEL_F32 || texel_dtype == NFI_TEXEL_BF16, "planes_to_texels: bad texel dtype");
+  REQUIRE(texel_dtype >= NFI_TEXEL_F32 && texel_dtype <= NFI_TEXEL_F16, "planes_to_texels: bad texel dtype");
   int hw = plane_res * plane_res;
   dim3 grid((hw + 63) / 64, n_scenes * 3);
   if (texel_dtype == NFI_TEXEL_F32)
     hipLaunchKernelGGL(planes_to_texels_kernel<0>, grid, dim3(256), 0, (hipStream_t)stream, planes, texels, hw);
-  else
+  else if (texel_dtype == NFI_TEXEL_BF16)
     hipLaunchKernelGGL(planes_to_texels_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, planes, texels, hw);
+  else
+    hipLaunchKernelGGL(planes_to_texels_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, planes, texels, hw);
   return check_launch("planes_to_texels");
 }
 
@@ -207,7 +219,7 @@ extern "C" int nfi_decoder_pack(const float* w1, const float* b1, const float* w
                                 int texel_dtype, float* image, nfi_stream_t stream) {
   REQUIRE(w1 && b1 && w2 && b2 && image, "decoder_pack: null pointer");
   REQUIRE(n_attention >= 0 && n_attention <= NFI_MAX_ATTENTION, "decoder_pack: attention_values must be in [0,14]");
-  REQUIRE(texel_dtype == NFI_TEXEL_F32 || texel_dtype == NFI_TEXEL_BF16, "decoder_pack: bad texel dtype");
+  REQUIRE(texel_dtype >= NFI_TEXEL_F32 && texel_dtype <= NFI_TEXEL_F16, "decoder_pack: bad texel dtype");
   int n_out = n_attention > 0 ? 1 + n_attention : 4;
   hipLaunchKernelGGL(decoder_pack_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, w1, b1, w2, b2, n_out, texel_dtype,
                      image);
@@ -471,7 +483,7 @@ static int check_field_common(const void* texels, int plane_res, int texel_dtype
                               const float* att, int use_sdf, const float* beta, const float* alpha) {
   REQUIRE(texels && image, "field: null texels / decoder image");
   REQUIRE(plane_res >= 2 && plane_res <= 1024, "field: plane_res must be in [2,1024]");
-  REQUIRE(texel_dtype == NFI_TEXEL_F32 || texel_dtype == NFI_TEXEL_BF16, "field: bad texel dtype");
+  REQUIRE(texel_dtype >= NFI_TEXEL_F32 && texel_dtype <= NFI_TEXEL_F16, "field: bad texel dtype");
   REQUIRE(A >= 0 && A <= NFI_MAX_ATTENTION, "field: attention_values must be in [0,14]");
   REQUIRE(A == 0 || att, "field: attention_values tensor missing");
   REQUIRE(!use_sdf || (beta && alpha), "field: use_sdf needs beta and alpha");
@@ -498,9 +510,12 @@ extern "C" int nfi_field_query_fwd(const nfi_field_args* a, nfi_stream_t stream)
   if (a->texel_dtype == NFI_TEXEL_F32) {
     if (att) hipLaunchKernelGGL((field_query_kernel<0, true>), grid, dim3(256), 0, s, k);
     else hipLaunchKernelGGL((field_query_kernel<0, false>), grid, dim3(256), 0, s, k);
-  } else {
+  } else if (a->texel_dtype == NFI_TEXEL_BF16) {
     if (att) hipLaunchKernelGGL((field_query_kernel<1, true>), grid, dim3(256), 0, s, k);
     else hipLaunchKernelGGL((field_query_kernel<1, false>), grid, dim3(256), 0, s, k);
+  } else {
+    if (att) hipLaunchKernelGGL((field_query_kernel<2, true>), grid, dim3(256), 0, s, k);
+    else hipLaunchKernelGGL((field_query_kernel<2, false>), grid, dim3(256), 0, s, k);
   }
   return check_launch("field_query_fwd");
 }
@@ -1462,13 +1477,17 @@ extern "C" int nfi_render_fwd(const nfi_render_args* a, nfi_stream_t stream) {
   if (a->n_samples > 64) {
     if (a->texel_dtype == NFI_TEXEL_F32) {
       if (att) NFI_LAUNCH_RENDER_WIDE(0, true); else NFI_LAUNCH_RENDER_WIDE(0, false);
-    } else {
+    } else if (a->texel_dtype == NFI_TEXEL_BF16) {
       if (att) NFI_LAUNCH_RENDER_WIDE(1, true); else NFI_LAUNCH_RENDER_WIDE(1, false);
+    } else {
+      if (att) NFI_LAUNCH_RENDER_WIDE(2, true); else NFI_LAUNCH_RENDER_WIDE(2, false);
     }
   } else if (a->texel_dtype == NFI_TEXEL_F32) {
     if (att) NFI_LAUNCH_RENDER(0, true); else NFI_LAUNCH_RENDER(0, false);
-  } else {
+  } else if (a->texel_dtype == NFI_TEXEL_BF16) {
     if (att) NFI_LAUNCH_RENDER(1, true); else NFI_LAUNCH_RENDER(1, false);
+  } else {
+    if (att) NFI_LAUNCH_RENDER(2, true); else NFI_LAUNCH_RENDER(2, false);
   }
 #undef NFI_LAUNCH_RENDER_WIDE
 #undef NFI_LAUNCH_RENDER

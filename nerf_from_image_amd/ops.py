@@ -11,6 +11,15 @@ from . import _lib
 
 TEXEL_F32 = 0
 TEXEL_BF16 = 1
+TEXEL_F16 = 2
+_TEXEL_TORCH = {TEXEL_F32: torch.float32, TEXEL_BF16: torch.bfloat16, TEXEL_F16: torch.float16}
+
+
+def texel_dtype_of(texels):
+    for k, v in _TEXEL_TORCH.items():
+        if texels.dtype == v:
+            return k
+    raise TypeError('texels must be float32, bfloat16 or float16, got %s' % texels.dtype)
 
 
 def _stream(t):
@@ -34,7 +43,7 @@ def planes_to_texels(planes, texel_dtype=TEXEL_F32):
     B, three, C, R, R2 = planes.shape
     if three != 3 or C != 32 or R != R2:
         raise ValueError('planes must be [B,3,32,R,R], got %s' % (tuple(planes.shape),))
-    dt = torch.float32 if texel_dtype == TEXEL_F32 else torch.bfloat16
+    dt = _TEXEL_TORCH[texel_dtype]
     texels = torch.empty((B, 3, R, R, 32), dtype=dt, device=planes.device)
     lib = _lib.load()
     with torch.cuda.device(planes.device):
@@ -141,7 +150,7 @@ def field_query(points, texels, decoder_image, scene_range, n_attention, attenti
     points = _f32c(points, 'points')
     B, P = points.shape[0], points.shape[1]
     dev = points.device
-    tdt = TEXEL_F32 if texels.dtype == torch.float32 else TEXEL_BF16
+    tdt = texel_dtype_of(texels)
     att = _f32c(attention_values, 'attention_values') if n_attention > 0 else None
     out = {'sigma': torch.empty((B, P), dtype=torch.float32, device=dev),
            'rgb': torch.empty((B, P, 3), dtype=torch.float32, device=dev)}
@@ -267,7 +276,7 @@ def render_fwd(cam2world, focal, height, width, num_samples, texels, decoder_ima
     n = B * height * width
     S = num_samples
     lib = _lib.load()
-    tdt = TEXEL_F32 if texels.dtype == torch.float32 else TEXEL_BF16
+    tdt = texel_dtype_of(texels)
     out = {'rgb': torch.empty((B, height, width, 3), dtype=torch.float32, device=dev),
            'depth': torch.empty((B, height, width), dtype=torch.float32, device=dev),
            'mask': torch.empty((B, height, width), dtype=torch.float32, device=dev)}

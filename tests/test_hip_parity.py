@@ -50,6 +50,8 @@ def test_texel_layout_roundtrip(gpu_device):
     exact(ops.texels_to_planes(tex), planes, 'roundtrip')
     tb = ops.planes_to_texels(planes, ops.TEXEL_BF16)
     exact(tb, planes.permute(0, 1, 3, 4, 2).contiguous().to(torch.bfloat16), 'bf16 texels')
+    th = ops.planes_to_texels(planes, ops.TEXEL_F16)
+    exact(th, planes.permute(0, 1, 3, 4, 2).contiguous().to(torch.float16), 'fp16 texels')
 
 
 def test_rays_and_planes(case):
@@ -205,3 +207,18 @@ def test_fused_render_bf16_texels(case):
     close(r['mask'], o['mask'], 0.08, 'bf16 mask')
     close(r['rgb'], o['rgb'], 0.08, 'bf16 rgb')
     assert err(r['rgb'], o['rgb'])['mean'] < 5e-3
+
+
+@pytest.mark.parametrize('dtype,torch_dtype', [(ops.TEXEL_BF16, torch.bfloat16), (ops.TEXEL_F16, torch.float16)])
+def test_fused_render_half_texels_against_rounded_planes(case, dtype, torch_dtype):
+    """16-bit plane storage (BASELINE cfg2 bf16 / cfg5 fp16): the kernel must equal the fp32 reference
+    evaluated on the SAME rounded planes at the fp32 tolerance, i.e. the storage rounding of the
+    planes is the only deviation (arithmetic stays fp32)."""
+    name, meta, t, o, dev = case
+    r = hip_render(meta, t, dev, texel_dtype=dtype)
+    t2 = dict(t)
+    t2['planes'] = t['planes'].to(torch_dtype).to(torch.float32)
+    o2 = oracle_render(meta, t2)
+    tol = 2e-4
+    close(r['mask'], o2['mask'], tol, 'mask')
+    close(r['rgb'], o2['rgb'], tol, 'rgb')
