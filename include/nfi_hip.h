@@ -74,6 +74,17 @@ size_t nfi_decoder_image_floats(void);
 int nfi_decoder_pack(const float* w1, const float* b1, const float* w2, const float* b2,
                      int n_attention, int texel_dtype, float* image, nfi_stream_t stream);
 
+/* View-direction variant (--use_viewdir; ViewDirectionMapper, models/generator.py:189-253; decoder output
+ * widened to 32 features, 376-377; closure applied per sample, 243-251 / 662-663):
+ *   w2 [33,64] b2 [33] (row 0 = distance, rows 1..32 = features);  w3 [n3,32] b3 [n3] = the mapper's
+ *   `output` EqualizedLinear (raw parameters), n3 = A, or 3 if A == 0.
+ * The per-ray output of ViewDirectionMapper.fc6 is handed to the field / render entry points as
+ * ray_features [rays, NFI_RAY_FEATURE_PITCH] = [0, x_0 .. x_31, 0 x 15] (padded by the caller). */
+enum { NFI_RAY_FEATURE_PITCH = 48 };
+size_t nfi_decoder_image_floats_viewdir(void);
+int nfi_decoder_pack_viewdir(const float* w1, const float* b1, const float* w2, const float* b2, const float* w3,
+                             const float* b3, int n_attention, int texel_dtype, float* image, nfi_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------
  * Camera rays + scene-box intersection.
  * Replaces nerf_utils.get_ray_bundle (lib/nerf_utils.py:28-91), F.normalize (run.py:196)
@@ -153,6 +164,10 @@ typedef struct nfi_field_args {
   float* sdf;                    /* [B,P] out or NULL */
   float* semantics;              /* [B,P,A] out or NULL */
   uint8_t* outside;              /* [B,P] out or NULL */
+  /* view-direction decoder: NULL, or [B, P/samples_per_ray, NFI_RAY_FEATURE_PITCH]; decoder_image must then
+   * come from nfi_decoder_pack_viewdir and point p belongs to ray p / samples_per_ray (x_in [B,H,W,S,3]) */
+  const float* ray_features;
+  int samples_per_ray;
 } nfi_field_args;
 int nfi_field_query_fwd(const nfi_field_args* a, nfi_stream_t stream);
 
@@ -308,7 +323,7 @@ int nfi_field_query_bwd(const nfi_field_bwd_args* a, nfi_stream_t stream);
  * ------------------------------------------------------------------------------------------ */
 typedef struct nfi_render_args {
   int n_scenes, height, width;
-  int n_samples;                 /* S per pass, <= 64 */
+  int n_samples;                 /* S per pass, <= NFI_MAX_SAMPLES */
   int fine_sampling;             /* args.fine_sampling (run.py:259) */
   int white_background;          /* dataset_config['white_background'] (run.py:348) */
   float scene_range;             /* dataset_config['scene_range'] (run.py:200) */
@@ -348,6 +363,9 @@ typedef struct nfi_render_args {
    * the kernel; NULL = off): field tile {issue, wait+interp, mlp, count}, ray set-up, coarse field,
    * resample, fine field, merge, composite, rays marched, wave lifetime */
   void* profile_cycles;
+  /* view-direction decoder: NULL, or [N, NFI_RAY_FEATURE_PITCH] (decoder_image from nfi_decoder_pack_viewdir;
+   * the MLP then runs in exact fp32) */
+  const float* ray_features;
 } nfi_render_args;
 size_t nfi_render_workspace_bytes(int64_t n_rays);
 int nfi_render_fwd(const nfi_render_args* a, nfi_stream_t stream);

@@ -50,6 +50,24 @@ constexpr int kLdsImageFloats = kW1H;                   // 3152
 constexpr int kVF = kLdsImageFloats;                    // per-scene attention values [16 rows][4] appended in LDS
 constexpr int kFieldLdsFloats = kVF + 64;               // 3216
 
+// ---- view-direction variant (--use_viewdir, models/generator.py:189-253, 376-377, 662-663) ----------
+// decoder = Linear(32,64) -> Softplus -> Linear(64, 1+32); per sample  y = leaky_relu(x_ray + f, 0.2),
+// colour logits = Linear(32, A or 3)(y).  Image built by nfi_decoder_pack_viewdir (exact-fp32 MFMA only):
+// W1F/B1F as above; W2V [3 row tiles][4 n-tiles][64 lanes][4 regs] (rows 0..32 of the 33 outputs, row 0 =
+// distance); B2V [3][4 groups][4 regs]; W3V [3 row tiles][64 lanes][4 regs] = A operand of the third
+// layer over K = the 48 (padded) second-layer rows, with W3V[row 0][k 0] = 1 passing the distance
+// through; B3V [4 groups][4 regs].
+constexpr int kVdW1F = 0;
+constexpr int kVdB1F = kVdW1F + 8 * 64 * 4;            // 2048
+constexpr int kVdW2 = kVdB1F + 64;                     // 2112
+constexpr int kVdB2 = kVdW2 + 3 * 4 * 64 * 4;          // 5184
+constexpr int kVdW3 = kVdB2 + 48;                      // 5232
+constexpr int kVdB3 = kVdW3 + 3 * 64 * 4;              // 6000
+constexpr int kVdImageFloats = kVdB3 + 16;             // 6016
+constexpr int kVdVF = kVdImageFloats;
+constexpr int kVdFieldLdsFloats = kVdVF + 64;          // 6080
+constexpr int kRayFeatPad = 48;                        // per-ray feature row: [0, x_0..x_31, 0 x 15]
+
 // ---- small wave helpers ---------------------------------------------------------------------
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
 __device__ __forceinline__ void wave_lds_fence() {
@@ -413,6 +431,74 @@ __device__ __forceinline__ void tile_bilinear(const TileTex<TEX>& T, float fx, f
   }
 }
 
+// density / colour epilogue on the decoder outputs o (lane (g,j): rows 4g..4g+3 of point j; row 0 =
+// distance/density, rows 1.. = colour logits pre-scaled by log2e)
+template <bool ATT, int N>
+__device__ __forceinline__ void tile_epilogue(const FieldParams& P, int lane, const f32x4 (&o)[N], const float (&outside)[N],
+                                              float* const (&sem)[N], TileOut (&res)[N]) {
+  const int g = lane >> 4;
+#pragma unroll
+  for (int n = 0; n < N; ++n) {
+    const float sdf = bcast_row0(o[n].x);     // group 0's output row 0 -> all four channel groups
+    res[n].sdf = sdf;
+    if (P.use_sdf) {
+      // sigma = (1/alpha) * (0.5 + 0.5*sign(-d)*(1 - exp(-|d|/beta))) * (1 - outside)
+      float e = __builtin_amdgcn_exp2f(fabsf(sdf) * P.neg_log2e_over_beta);
+      float sgn = (sdf < 0.0f) ? 0.5f : ((sdf > 0.0f) ? -0.5f : 0.0f);
+      float cdf = 0.5f + sgn * (1.0f - e);
+      res[n].sigma = P.inv_alpha * (cdf * (1.0f - outside[n]));
+    } else {
+      float d = sdf - 1.0f;
+      float sp = (d > 20.0f) ? d : log1pf(__expf(d));
+      res[n].sigma = sp * (1.0f - outside[n]);
+    }
+    if constexpr (ATT) {
+      // softmax over features 1..A spread over (group, reg); rows are pre-scaled by log2e
+      const int A = P.n_attention;
+      float m = -INFINITY;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        int row = 4 * g + r;
+        bool valid = (row >= 1) && (row <= A);
+        m = valid ? fmaxf(m, o[n][r]) : m;
+      }
+      m = max_xor32(max_xor16(m));
+      const f32x4* vf = reinterpret_cast<const f32x4*>(P.vf) + g * 4;
+      float se = 0.0f, sr = 0.0f, sg = 0.0f, sb = 0.0f;
+      float e4[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        int row = 4 * g + r;
+        bool valid = (row >= 1) && (row <= A);
+        float e = valid ? __builtin_amdgcn_exp2f(o[n][r] - m) : 0.0f;
+        e4[r] = e;
+        f32x4 v = vf[r];
+        se += e;
+        sr = fmaf(e, v.x, sr);
+        sg = fmaf(e, v.y, sg);
+        sb = fmaf(e, v.z, sb);
+      }
+      se = sum_xor32(sum_xor16(se)); sr = sum_xor32(sum_xor16(sr)); sg = sum_xor32(sum_xor16(sg)); sb = sum_xor32(sum_xor16(sb));
+      float inv = __builtin_amdgcn_rcpf(se);
+      inv = inv * (2.0f - se * inv);      // one Newton step: the quotient is then within 1 ulp
+      res[n].r = sr * inv; res[n].g = sg * inv; res[n].b = sb * inv;
+      if (sem[n]) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          int row = 4 * g + r;
+          if (row >= 1 && row <= A) sem[n][row - 1] = e4[r] * inv;
+        }
+      }
+    } else {
+      // rgb = sigmoid(f)*2.004 - 1.002, features (rows 1..3 of group 0) pre-scaled by log2e
+      float r1 = bcast_row0(o[n].y), r2 = bcast_row0(o[n].z), r3 = bcast_row0(o[n].w);
+      res[n].r = (1.0f / (1.0f + __builtin_amdgcn_exp2f(-r1))) * 2.004f - 1.002f;
+      res[n].g = (1.0f / (1.0f + __builtin_amdgcn_exp2f(-r2))) * 2.004f - 1.002f;
+      res[n].b = (1.0f / (1.0f + __builtin_amdgcn_exp2f(-r3))) * 2.004f - 1.002f;
+    }
+  }
+}
+
 // Decoder MLP + density / colour epilogue for N tiles at once (N = 2 in the renderer: the two tiles'
 // MFMA chains, softplus blocks and cross-lane reductions are independent, so a wave has twice the
 // instruction-level parallelism against the dependent latencies that dominate this phase, and the
@@ -546,66 +632,94 @@ __device__ __forceinline__ void tile_mlp(const FieldParams& P, int lane, const f
     for (int n = 0; n < N; ++n) o[n] = o0[n] + o1[n];   // lane (j,g): outputs 4g..4g+3 of point j; row 0 = sdf/density
   }
 
+  tile_epilogue<ATT, N>(P, lane, o, outside, sem, res);
+}
+
+// View-direction variant of the decoder (exact fp32 MFMA): layer 1 as above, layer 2 with 33 outputs
+// in three 16-row tiles, y = leaky_relu(x_ray + f, 0.2) on the 32 feature rows (row 0 = distance goes
+// through), layer 3 over K = those 48 accumulator rows - the accumulator layout of one layer is the B
+// operand of the next, as between layers 1 and 2.  xr[n][t]: rows 16t+4g..+3 of the padded ray feature
+// of tile n's point j.  P.lds holds the nfi_decoder_pack_viewdir image.
+template <bool ATT, int N>
+__device__ __forceinline__ void tile_mlp_vd(const FieldParams& P, int lane, const float (&feat)[N][8],
+                                            const f32x4 (&xr)[N][3], const float (&outside)[N], float* const (&sem)[N],
+                                            TileOut (&res)[N]) {
+  const int g = lane >> 4;
+  const f32x4* ldsv = reinterpret_cast<const f32x4*>(P.lds);
+  f32x4 acc1[N][4];
 #pragma unroll
-  for (int n = 0; n < N; ++n) {
-    const float sdf = bcast_row0(o[n].x);     // group 0's output row 0 -> all four channel groups
-    res[n].sdf = sdf;
-    if (P.use_sdf) {
-      // sigma = (1/alpha) * (0.5 + 0.5*sign(-d)*(1 - exp(-|d|/beta))) * (1 - outside)
-      float e = __builtin_amdgcn_exp2f(fabsf(sdf) * P.neg_log2e_over_beta);
-      float sgn = (sdf < 0.0f) ? 0.5f : ((sdf > 0.0f) ? -0.5f : 0.0f);
-      float cdf = 0.5f + sgn * (1.0f - e);
-      res[n].sigma = P.inv_alpha * (cdf * (1.0f - outside[n]));
-    } else {
-      float d = sdf - 1.0f;
-      float sp = (d > 20.0f) ? d : log1pf(__expf(d));
-      res[n].sigma = sp * (1.0f - outside[n]);
-    }
-    if constexpr (ATT) {
-      // softmax over features 1..A spread over (group, reg); rows are pre-scaled by log2e
-      const int A = P.n_attention;
-      float m = -INFINITY;
+  for (int nt = 0; nt < 4; ++nt) {
+    const f32x4 b = ldsv[(kVdB1F >> 2) + g * 4 + nt];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        int row = 4 * g + r;
-        bool valid = (row >= 1) && (row <= A);
-        m = valid ? fmaxf(m, o[n][r]) : m;
-      }
-      m = max_xor32(max_xor16(m));
-      const f32x4* vf = reinterpret_cast<const f32x4*>(P.vf) + g * 4;
-      float se = 0.0f, sr = 0.0f, sg = 0.0f, sb = 0.0f;
-      float e4[4];
+    for (int n = 0; n < N; ++n) acc1[n][nt] = b;
+  }
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        int row = 4 * g + r;
-        bool valid = (row >= 1) && (row <= A);
-        float e = valid ? __builtin_amdgcn_exp2f(o[n][r] - m) : 0.0f;
-        e4[r] = e;
-        f32x4 v = vf[r];
-        se += e;
-        sr = fmaf(e, v.x, sr);
-        sg = fmaf(e, v.y, sg);
-        sb = fmaf(e, v.z, sb);
-      }
-      se = sum_xor32(sum_xor16(se)); sr = sum_xor32(sum_xor16(sr)); sg = sum_xor32(sum_xor16(sg)); sb = sum_xor32(sum_xor16(sb));
-      float inv = __builtin_amdgcn_rcpf(se);
-      inv = inv * (2.0f - se * inv);      // one Newton step: the quotient is then within 1 ulp
-      res[n].r = sr * inv; res[n].g = sg * inv; res[n].b = sb * inv;
-      if (sem[n]) {
+  for (int s = 0; s < 8; ++s) {
+    const f32x4 w = ldsv[(kVdW1F >> 2) + s * 64 + lane];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          int row = 4 * g + r;
-          if (row >= 1 && row <= A) sem[n][row - 1] = e4[r] * inv;
-        }
-      }
-    } else {
-      // rgb = sigmoid(f)*2.004 - 1.002, features (rows 1..3 of group 0) pre-scaled by log2e
-      float r1 = bcast_row0(o[n].y), r2 = bcast_row0(o[n].z), r3 = bcast_row0(o[n].w);
-      res[n].r = (1.0f / (1.0f + __builtin_amdgcn_exp2f(-r1))) * 2.004f - 1.002f;
-      res[n].g = (1.0f / (1.0f + __builtin_amdgcn_exp2f(-r2))) * 2.004f - 1.002f;
-      res[n].b = (1.0f / (1.0f + __builtin_amdgcn_exp2f(-r3))) * 2.004f - 1.002f;
+    for (int n = 0; n < N; ++n) {
+      acc1[n][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(w.x, feat[n][s], acc1[n][0], 0, 0, 0);
+      acc1[n][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(w.y, feat[n][s], acc1[n][1], 0, 0, 0);
+      acc1[n][2] = __builtin_amdgcn_mfma_f32_16x16x4f32(w.z, feat[n][s], acc1[n][2], 0, 0, 0);
+      acc1[n][3] = __builtin_amdgcn_mfma_f32_16x16x4f32(w.w, feat[n][s], acc1[n][3], 0, 0, 0);
     }
   }
+#pragma unroll
+  for (int n = 0; n < N; ++n)
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float h = acc1[n][nt][r];
+        float e = __builtin_amdgcn_exp2f(h);
+        float sp = __builtin_amdgcn_logf(1.0f + e);
+        acc1[n][nt][r] = (h > kSoftplusThr2) ? h : sp;
+      }
+  f32x4 o2[N][3];
+#pragma unroll
+  for (int t = 0; t < 3; ++t) {
+    const f32x4 b = ldsv[(kVdB2 >> 2) + t * 4 + g];
+#pragma unroll
+    for (int n = 0; n < N; ++n) o2[n][t] = b;
+  }
+#pragma unroll
+  for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+      const f32x4 w = ldsv[(kVdW2 >> 2) + (t * 4 + nt) * 64 + lane];
+#pragma unroll
+      for (int n = 0; n < N; ++n) {
+        o2[n][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(w.x, acc1[n][nt][0], o2[n][t], 0, 0, 0);
+        o2[n][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(w.y, acc1[n][nt][1], o2[n][t], 0, 0, 0);
+        o2[n][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(w.z, acc1[n][nt][2], o2[n][t], 0, 0, 0);
+        o2[n][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(w.w, acc1[n][nt][3], o2[n][t], 0, 0, 0);
+      }
+    }
+  f32x4 o[N], oB[N];
+  const f32x4 b3 = ldsv[(kVdB3 >> 2) + g];
+#pragma unroll
+  for (int n = 0; n < N; ++n) { o[n] = b3; oB[n] = f32x4{0.0f, 0.0f, 0.0f, 0.0f}; }
+#pragma unroll
+  for (int t = 0; t < 3; ++t) {
+    const f32x4 w = ldsv[(kVdW3 >> 2) + t * 64 + lane];
+#pragma unroll
+    for (int n = 0; n < N; ++n) {
+      f32x4 y;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float v = o2[n][t][r] + xr[n][t][r];
+        y[r] = (v >= 0.0f) ? v : v * 0.2f;                       // F.leaky_relu(x + f, 0.2)
+      }
+      if (t == 0 && g == 0) y[0] = o2[n][0][0];                   // row 0: the distance passes through
+      o[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(w.x, y[0], o[n], 0, 0, 0);
+      oB[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(w.y, y[1], oB[n], 0, 0, 0);
+      o[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(w.z, y[2], o[n], 0, 0, 0);
+      oB[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(w.w, y[3], oB[n], 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int n = 0; n < N; ++n) o[n] = o[n] + oB[n];
+  tile_epilogue<ATT, N>(P, lane, o, outside, sem, res);
 }
 
 struct SampleOut {
@@ -621,10 +735,12 @@ struct SampleOut {
 // stage: 16 x 36 floats of LDS owned by this wave (feature-tile transpose).
 // prof: null, or 4 cycle accumulators {tile set-up + load issue, load wait + interpolation,
 // transpose + MLP + epilogue, tiles} filled with s_memtime deltas (profiling builds only)
-template <int TEX, bool ATT, bool SKIP, int PREC = 0>
+// VD: view-direction decoder; xray = padded per-ray features [rays][kRayFeatPad], ray_idx = this lane's ray.
+template <int TEX, bool ATT, bool SKIP, int PREC = 0, bool VD = false>
 __device__ __forceinline__ SampleOut field_wave(const FieldParams& P, float scene_range, int lane, float px, float py,
                                                 float pz, bool valid, float* sem_base, bool* outside_flag,
-                                                float* stage, unsigned long long* prof = nullptr) {
+                                                float* stage, unsigned long long* prof = nullptr,
+                                                const float* xray = nullptr, int ray_idx = 0) {
   // reference: x / scene_range, mask = any(|x| > 1)   (true division, generator.py:604-607)
   float qx = px / scene_range, qy = py / scene_range, qz = pz / scene_range;
   bool out = (fabsf(qx) > 1.0f) || (fabsf(qy) > 1.0f) || (fabsf(qz) > 1.0f);
@@ -706,7 +822,19 @@ __device__ __forceinline__ SampleOut field_wave(const FieldParams& P, float scen
         (sem_base && (fa & 2)) ? sem_base + (size_t)(16 * ta + j) * P.n_attention : nullptr,
         (sem_base && pair && (fb & 2)) ? sem_base + (size_t)(16 * tb + j) * P.n_attention : nullptr};
     TileOut to[2];
-    tile_mlp<ATT, 2, PREC>(P, lane, feat, outs, sems, to);
+    if constexpr (VD) {
+      static_assert(PREC == 0, "the view-direction decoder exists in exact fp32 only");
+      const int ra = __shfl(ray_idx, 16 * ta + j, 64), rb = __shfl(ray_idx, 16 * tb + j, 64);
+      f32x4 xr[2][3];
+#pragma unroll
+      for (int t = 0; t < 3; ++t) {
+        xr[0][t] = *reinterpret_cast<const f32x4*>(xray + (size_t)ra * kRayFeatPad + 16 * t + 4 * g);
+        xr[1][t] = *reinterpret_cast<const f32x4*>(xray + (size_t)rb * kRayFeatPad + 16 * t + 4 * g);
+      }
+      tile_mlp_vd<ATT, 2>(P, lane, feat, xr, outs, sems, to);
+    } else {
+      tile_mlp<ATT, 2, PREC>(P, lane, feat, outs, sems, to);
+    }
     if (g == ta) { so.sdf = to[0].sdf; so.sigma = to[0].sigma; so.r = to[0].r; so.g = to[0].g; so.b = to[0].b; }
     if (pair && g == tb) { so.sdf = to[1].sdf; so.sigma = to[1].sigma; so.r = to[1].r; so.g = to[1].g; so.b = to[1].b; }
     if (prof) {

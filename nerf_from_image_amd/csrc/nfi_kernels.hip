@@ -226,6 +226,64 @@ extern "C" int nfi_decoder_pack(const float* w1, const float* b1, const float* w
   return check_launch("decoder_pack");
 }
 
+__global__ __launch_bounds__(256) void decoder_pack_vd_kernel(const float* __restrict__ w1, const float* __restrict__ b1,
+                                                              const float* __restrict__ w2, const float* __restrict__ b2,
+                                                              const float* __restrict__ w3, const float* __restrict__ b3,
+                                                              int n3, int tex, float* __restrict__ image) {
+  const float gain1 = 0.17677669529663687f;  // 1/sqrt(32)
+  const float gain2 = 0.125f;                // 1/sqrt(64)
+  const float gain3 = 0.17677669529663687f;  // 1/sqrt(32)
+  for (int i = threadIdx.x; i < kVdImageFloats; i += blockDim.x) {
+    float v = 0.0f;
+    if (i < kVdB1F) {
+      int k = i - kVdW1F;
+      int nt = k & 3, lane = (k >> 2) & 63, s = k >> 8;
+      int row = 16 * nt + (lane & 15);
+      int ch = feat_channel(tex, s, lane >> 4);
+      v = (w1[row * kC + ch] * gain1) * (kLog2e / 3.0f);
+    } else if (i < kVdW2) {
+      int k = i - kVdB1F;
+      int r = k & 3, nt = (k >> 2) & 3, g = k >> 4;
+      v = b1[16 * nt + 4 * g + r] * kLog2e;
+    } else if (i < kVdB2) {
+      int k = i - kVdW2;
+      int r = k & 3, lane = (k >> 2) & 63, nt = (k >> 8) & 3, t = k >> 10;
+      int row = 16 * t + (lane & 15);
+      int hid = 16 * nt + 4 * (lane >> 4) + r;
+      if (row < 33) v = (w2[row * kHidden + hid] * gain2) * kLn2;   // every row stays in natural units
+    } else if (i < kVdW3) {
+      int row = i - kVdB2;                                           // 16t + 4g + r
+      if (row < 33) v = b2[row];
+    } else if (i < kVdB3) {
+      int k = i - kVdW3;
+      int r = k & 3, lane = (k >> 2) & 63, t = k >> 8;
+      int out = lane & 15;
+      int kk = 16 * t + 4 * (lane >> 4) + r;                          // second-layer row feeding this K slot
+      if (out == 0) v = (kk == 0) ? 1.0f : 0.0f;                      // the distance passes through
+      else if (out <= n3 && kk >= 1 && kk <= 32) v = (w3[(out - 1) * 32 + (kk - 1)] * gain3) * kLog2e;
+    } else {
+      int out = i - kVdB3;
+      if (out >= 1 && out <= n3) v = b3[out - 1] * kLog2e;
+    }
+    image[i] = v;
+  }
+}
+
+extern "C" size_t nfi_decoder_image_floats_viewdir(void) { return (size_t)kVdImageFloats; }
+
+extern "C" int nfi_decoder_pack_viewdir(const float* w1, const float* b1, const float* w2, const float* b2, const float* w3,
+                                        const float* b3, int n_attention, int texel_dtype, float* image,
+                                        nfi_stream_t stream) {
+  REQUIRE(w1 && b1 && w2 && b2 && w3 && b3 && image, "decoder_pack_viewdir: null pointer");
+  REQUIRE(n_attention >= 0 && n_attention <= NFI_MAX_ATTENTION, "decoder_pack_viewdir: attention_values must be in [0,14]");
+  REQUIRE(texel_dtype >= NFI_TEXEL_F32 && texel_dtype <= NFI_TEXEL_F16, "decoder_pack_viewdir: bad texel dtype");
+  static_assert(NFI_RAY_FEATURE_PITCH == kRayFeatPad, "ray feature pitch");
+  int n3 = n_attention > 0 ? n_attention : 3;
+  hipLaunchKernelGGL(decoder_pack_vd_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, w1, b1, w2, b2, w3, b3, n3,
+                     texel_dtype, image);
+  return check_launch("decoder_pack_viewdir");
+}
+
 // ------------------------------------------------------------------------------------------------
 // rays + scene-cube planes
 // ------------------------------------------------------------------------------------------------
@@ -416,21 +474,24 @@ struct FieldKernelParams {
   const float* image; int A; const float* att;
   int use_sdf; const float* beta; const float* alpha; float scene_range;
   float* sigma; float* rgb; float* sdf; float* sem; uint8_t* outside;
+  const float* xray; int spr;
 };
 
 // stage the decoder image (+ this scene's attention values in accumulator layout) into LDS
-__device__ __forceinline__ void stage_field_lds(float* lds, const float* image, const float* att_scene, int A) {
-  for (int i = threadIdx.x; i < kLdsImageFloats; i += blockDim.x) lds[i] = image[i];
+__device__ __forceinline__ void stage_field_lds(float* lds, const float* image, const float* att_scene, int A,
+                                                int n_image = kLdsImageFloats) {
+  for (int i = threadIdx.x; i < n_image; i += blockDim.x) lds[i] = image[i];
   for (int i = threadIdx.x; i < 64; i += blockDim.x) {
     int c = i & 3, row = i >> 2;  // row = 4g + r; value for feature row-1
     float v = 0.0f;
     if (att_scene && c < 3 && row >= 1 && row <= A) v = att_scene[(row - 1) * 3 + c];
-    lds[kVF + i] = v;
+    lds[n_image + i] = v;
   }
 }
 
 __device__ __forceinline__ FieldParams make_field_params(const void* texels_scene, int res, int tex, int A, int use_sdf,
-                                                         const float* beta, const float* alpha, const float* lds) {
+                                                         const float* beta, const float* alpha, const float* lds,
+                                                         int n_image = kLdsImageFloats) {
   FieldParams P;
   uint32_t tb = tex == 0 ? 128u : 64u;
   P.plane_bytes = (uint32_t)res * (uint32_t)res * tb;
@@ -444,23 +505,25 @@ __device__ __forceinline__ FieldParams make_field_params(const void* texels_scen
   P.beta = use_sdf ? beta[0] : 1.0f;
   P.neg_log2e_over_beta = -kLog2e / P.beta;
   P.lds = lds;
-  P.vf = lds + kVF;
+  P.vf = lds + n_image;
   return P;
 }
 
-template <int TEX, bool ATT>
+template <int TEX, bool ATT, bool VD = false>
 __global__ __launch_bounds__(256) void field_query_kernel(FieldKernelParams k) {
-  __shared__ __attribute__((aligned(16))) float lds[kFieldLdsFloats];
+  constexpr int kImg = VD ? kVdImageFloats : kLdsImageFloats;
+  __shared__ __attribute__((aligned(16))) float lds[kImg + 64];
   __shared__ __attribute__((aligned(16))) float stages[4][16 * 36];
   const int scene = blockIdx.y;
-  stage_field_lds(lds, k.image, k.att ? k.att + (size_t)scene * k.A * 3 : nullptr, k.A);
+  stage_field_lds(lds, k.image, k.att ? k.att + (size_t)scene * k.A * 3 : nullptr, k.A, kImg);
   __syncthreads();
   const size_t tb = TEX == 0 ? 128 : 64;
   const char* tex_scene = reinterpret_cast<const char*>(k.texels) + (size_t)scene * 3 * k.res * k.res * tb;
-  FieldParams P = make_field_params(tex_scene, k.res, TEX, k.A, k.use_sdf, k.beta, k.alpha, lds);
+  FieldParams P = make_field_params(tex_scene, k.res, TEX, k.A, k.use_sdf, k.beta, k.alpha, lds, kImg);
   const int lane = lane_id();
   const int wave = threadIdx.x >> 6;
   const int64_t n_chunks = (k.P + 63) / 64;
+  const float* xray_scene = VD ? k.xray + (size_t)scene * (size_t)(k.P / k.spr) * kRayFeatPad : nullptr;
   for (int64_t chunk = (int64_t)blockIdx.x * 4 + wave; chunk < n_chunks; chunk += (int64_t)gridDim.x * 4) {
     int64_t p = chunk * 64 + lane;
     bool valid = p < k.P;
@@ -469,7 +532,8 @@ __global__ __launch_bounds__(256) void field_query_kernel(FieldKernelParams k) {
     if (valid) { px = k.points[gi * 3]; py = k.points[gi * 3 + 1]; pz = k.points[gi * 3 + 2]; }
     bool out;
     float* sem = k.sem ? k.sem + ((size_t)scene * k.P + chunk * 64) * k.A : nullptr;
-    SampleOut so = field_wave<TEX, ATT, false>(P, k.scene_range, lane, px, py, pz, valid, sem, &out, stages[wave]);
+    SampleOut so = field_wave<TEX, ATT, false, 0, VD>(P, k.scene_range, lane, px, py, pz, valid, sem, &out, stages[wave],
+                                                      nullptr, xray_scene, VD && valid ? (int)(p / k.spr) : 0);
     if (valid) {
       k.sigma[gi] = so.sigma;
       k.rgb[gi * 3] = so.r; k.rgb[gi * 3 + 1] = so.g; k.rgb[gi * 3 + 2] = so.b;
@@ -500,23 +564,29 @@ extern "C" int nfi_field_query_fwd(const nfi_field_args* a, nfi_stream_t stream)
   // unskipped tiles of invalid lanes may write semantics rows past P in the last chunk: forbid unless P%64==0
   FieldKernelParams k{a->points, a->points_per_scene, a->texels, a->plane_res, a->texel_dtype, a->decoder_image,
                       a->n_attention, a->attention_values, a->use_sdf, a->beta, a->alpha, a->scene_range,
-                      a->sigma, a->rgb, a->sdf, a->semantics, a->outside};
+                      a->sigma, a->rgb, a->sdf, a->semantics, a->outside, a->ray_features, a->samples_per_ray};
+  REQUIRE(!a->ray_features || (a->samples_per_ray > 0 && a->points_per_scene % a->samples_per_ray == 0),
+          "field_query: with ray_features, points_per_scene must be a multiple of samples_per_ray");
   int64_t chunks = (a->points_per_scene + 63) / 64;
   int64_t blocks = (chunks + 3) / 4;
   if (blocks > 2048) blocks = 2048;
   dim3 grid((unsigned)blocks, (unsigned)a->n_scenes);
   hipStream_t s = (hipStream_t)stream;
   bool att = a->n_attention > 0;
-  if (a->texel_dtype == NFI_TEXEL_F32) {
-    if (att) hipLaunchKernelGGL((field_query_kernel<0, true>), grid, dim3(256), 0, s, k);
-    else hipLaunchKernelGGL((field_query_kernel<0, false>), grid, dim3(256), 0, s, k);
-  } else if (a->texel_dtype == NFI_TEXEL_BF16) {
-    if (att) hipLaunchKernelGGL((field_query_kernel<1, true>), grid, dim3(256), 0, s, k);
-    else hipLaunchKernelGGL((field_query_kernel<1, false>), grid, dim3(256), 0, s, k);
-  } else {
-    if (att) hipLaunchKernelGGL((field_query_kernel<2, true>), grid, dim3(256), 0, s, k);
-    else hipLaunchKernelGGL((field_query_kernel<2, false>), grid, dim3(256), 0, s, k);
-  }
+#define NFI_LAUNCH_FIELD(TEX)                                                                          \
+  do {                                                                                                \
+    if (a->ray_features) {                                                                            \
+      if (att) hipLaunchKernelGGL((field_query_kernel<TEX, true, true>), grid, dim3(256), 0, s, k);   \
+      else hipLaunchKernelGGL((field_query_kernel<TEX, false, true>), grid, dim3(256), 0, s, k);      \
+    } else {                                                                                          \
+      if (att) hipLaunchKernelGGL((field_query_kernel<TEX, true>), grid, dim3(256), 0, s, k);         \
+      else hipLaunchKernelGGL((field_query_kernel<TEX, false>), grid, dim3(256), 0, s, k);            \
+    }                                                                                                 \
+  } while (0)
+  if (a->texel_dtype == NFI_TEXEL_F32) NFI_LAUNCH_FIELD(0);
+  else if (a->texel_dtype == NFI_TEXEL_BF16) NFI_LAUNCH_FIELD(1);
+  else NFI_LAUNCH_FIELD(2);
+#undef NFI_LAUNCH_FIELD
   return check_launch("field_query_fwd");
 }
 
@@ -1040,6 +1110,7 @@ struct RenderKernelParams {
   float* t_sorted; float* weights; int32_t* perm;
   int skip_missed;
   unsigned long long* prof;
+  const float* xray;   // view-direction decoder: padded per-ray features [N][kRayFeatPad], or null
 };
 
 // Persistent kernel: one wave per ray, rays handed out by one device-scope counter (scene-major,
@@ -1051,9 +1122,10 @@ struct RayInputs {
   uint32_t hit;
 };
 
-template <int TEX, bool ATT, int OCC, bool TAPS, int PREC, bool PROF = false>
+template <int TEX, bool ATT, int OCC, bool TAPS, int PREC, bool PROF = false, bool VD = false>
 __global__ __launch_bounds__(256, OCC) void render_fwd_kernel(RenderKernelParams k) {
-  __shared__ __attribute__((aligned(16))) float lds[kLdsImageFloats];
+  constexpr int kImg = VD ? kVdImageFloats : kLdsImageFloats;
+  __shared__ __attribute__((aligned(16))) float lds[kImg];
   __shared__ __attribute__((aligned(16))) float vfs[4][64];
   __shared__ WaveSlab slabs[4];
   if (PREC == 1) {
@@ -1061,7 +1133,7 @@ __global__ __launch_bounds__(256, OCC) void render_fwd_kernel(RenderKernelParams
     for (int i = threadIdx.x; i < kB1F; i += blockDim.x) lds[i] = k.image[kW1H + i];
     for (int i = kB1F + threadIdx.x; i < kLdsImageFloats; i += blockDim.x) lds[i] = k.image[i];
   } else {
-    for (int i = threadIdx.x; i < kLdsImageFloats; i += blockDim.x) lds[i] = k.image[i];
+    for (int i = threadIdx.x; i < kImg; i += blockDim.x) lds[i] = k.image[i];
   }
   __syncthreads();
   const int lane = lane_id();
@@ -1087,7 +1159,7 @@ __global__ __launch_bounds__(256, OCC) void render_fwd_kernel(RenderKernelParams
     return scene * (uint32_t)k.hw + ((ty << 3) + (in >> 3)) * (uint32_t)k.width + (tx << 3) + (in & 7u);
   };
 
-  FieldParams P = make_field_params(k.texels, k.res, TEX, k.A, k.use_sdf, k.beta, k.alpha, lds);
+  FieldParams P = make_field_params(k.texels, k.res, TEX, k.A, k.use_sdf, k.beta, k.alpha, lds, kImg);
   P.vf = vf;
   int cur_scene = -1;
 
@@ -1151,8 +1223,8 @@ __global__ __launch_bounds__(256, OCC) void render_fwd_kernel(RenderKernelParams
       MergeIn c;
       unsigned long long t1 = PROF ? __builtin_readcyclecounter() : 0;
       {
-        SampleOut q = field_wave<TEX, ATT, true, PREC>(P, k.scene_range, lane, ox + dx * tc, oy + dy * tc, oz + dz * tc, valid,
-                                                 nullptr, nullptr, &slab.srt[0][0], PROF ? pc : nullptr);
+        SampleOut q = field_wave<TEX, ATT, true, PREC, VD>(P, k.scene_range, lane, ox + dx * tc, oy + dy * tc, oz + dz * tc, valid,
+                                                     nullptr, nullptr, &slab.srt[0][0], PROF ? pc : nullptr, k.xray, (int)ray);
         c.t = tc; c.sigma = q.sigma; c.r = q.r; c.g = q.g; c.b = q.b;
       }
       int n = S;
@@ -1164,8 +1236,8 @@ __global__ __launch_bounds__(256, OCC) void render_fwd_kernel(RenderKernelParams
         MergeIn f;
         if (PROF) { asm volatile("" :: "v"(tf)); t3 = __builtin_readcyclecounter(); }
         {
-          SampleOut q = field_wave<TEX, ATT, true, PREC>(P, k.scene_range, lane, ox + dx * tf, oy + dy * tf, oz + dz * tf, valid,
-                                                   nullptr, nullptr, &slab.srt[0][0], PROF ? pc : nullptr);
+          SampleOut q = field_wave<TEX, ATT, true, PREC, VD>(P, k.scene_range, lane, ox + dx * tf, oy + dy * tf, oz + dz * tf, valid,
+                                                       nullptr, nullptr, &slab.srt[0][0], PROF ? pc : nullptr, k.xray, (int)ray);
           f.t = tf; f.sigma = q.sigma; f.r = q.r; f.g = q.g; f.b = q.b;
         }
         if constexpr (TAPS) {
@@ -1231,16 +1303,17 @@ __global__ __launch_bounds__(256, OCC) void render_fwd_kernel(RenderKernelParams
 // The same pipeline for 64 < S <= 128 samples per pass (BASELINE cfg5, ray_multiplier=2): every lane
 // owns two coarse and two fine samples (element e = slot*64 + lane), the field is marched 64 points
 // at a time, and the merge ranks all 2S keys against each other.
-template <int TEX, bool ATT, bool TAPS, int PREC>
+template <int TEX, bool ATT, bool TAPS, int PREC, bool VD = false>
 __global__ __launch_bounds__(256, 2) void render_fwd_wide_kernel(RenderKernelParams k) {
-  __shared__ __attribute__((aligned(16))) float lds[kLdsImageFloats];
+  constexpr int kImg = VD ? kVdImageFloats : kLdsImageFloats;
+  __shared__ __attribute__((aligned(16))) float lds[kImg];
   __shared__ __attribute__((aligned(16))) float vfs[4][64];
   __shared__ WaveSlabWide slabs[4];
   if (PREC == 1) {
     for (int i = threadIdx.x; i < kB1F; i += blockDim.x) lds[i] = k.image[kW1H + i];
     for (int i = kB1F + threadIdx.x; i < kLdsImageFloats; i += blockDim.x) lds[i] = k.image[i];
   } else {
-    for (int i = threadIdx.x; i < kLdsImageFloats; i += blockDim.x) lds[i] = k.image[i];
+    for (int i = threadIdx.x; i < kImg; i += blockDim.x) lds[i] = k.image[i];
   }
   __syncthreads();
   const int lane = lane_id();
@@ -1260,7 +1333,7 @@ __global__ __launch_bounds__(256, 2) void render_fwd_wide_kernel(RenderKernelPar
     const uint32_t ty = tile / tiles_x, tx = tile - ty * tiles_x;
     return scene * (uint32_t)k.hw + ((ty << 3) + (in >> 3)) * (uint32_t)k.width + (tx << 3) + (in & 7u);
   };
-  FieldParams P = make_field_params(k.texels, k.res, TEX, k.A, k.use_sdf, k.beta, k.alpha, lds);
+  FieldParams P = make_field_params(k.texels, k.res, TEX, k.A, k.use_sdf, k.beta, k.alpha, lds, kImg);
   P.vf = vf;
   int cur_scene = -1;
   uint32_t cur = 0, nxt = 0;
@@ -1308,8 +1381,8 @@ __global__ __launch_bounds__(256, 2) void render_fwd_wide_kernel(RenderKernelPar
         val[j] = e < S;
         const float nz = (k.noise_c && val[j]) ? k.noise_c[rs + e] : 0.0f;
         tc[j] = val[j] ? stratified_depth(near, far, e, S, nz, k.noise_c != nullptr) : 0.0f;
-        SampleOut q = field_wave<TEX, ATT, true, PREC>(P, k.scene_range, lane, ox + dx * tc[j], oy + dy * tc[j], oz + dz * tc[j],
-                                                       val[j], nullptr, nullptr, stage, nullptr);
+        SampleOut q = field_wave<TEX, ATT, true, PREC, VD>(P, k.scene_range, lane, ox + dx * tc[j], oy + dy * tc[j], oz + dz * tc[j],
+                                                           val[j], nullptr, nullptr, stage, nullptr, k.xray, (int)ray);
         sc[j] = q.sigma; rc[j] = q.r; gc[j] = q.g; bc[j] = q.b;
       }
       int n = S;
@@ -1333,8 +1406,8 @@ __global__ __launch_bounds__(256, 2) void render_fwd_wide_kernel(RenderKernelPar
         resample_ray_wide<2>(slab, sc, tc, S, dnorm, u, lane, tf, wtap, smtap, ind);
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-          SampleOut q = field_wave<TEX, ATT, true, PREC>(P, k.scene_range, lane, ox + dx * tf[j], oy + dy * tf[j], oz + dz * tf[j],
-                                                         val[j], nullptr, nullptr, stage, nullptr);
+          SampleOut q = field_wave<TEX, ATT, true, PREC, VD>(P, k.scene_range, lane, ox + dx * tf[j], oy + dy * tf[j], oz + dz * tf[j],
+                                                             val[j], nullptr, nullptr, stage, nullptr, k.xray, (int)ray);
           dep[2 + j] = tf[j]; sig[2 + j] = q.sigma; cr[2 + j] = q.r; cg[2 + j] = q.g; cb[2 + j] = q.b;
           eidx[2 + j] = val[j] ? S + j * 64 + lane : 0x7fffffff;
           if constexpr (TAPS) {
@@ -1451,6 +1524,8 @@ extern "C" int nfi_render_fwd(const nfi_render_args* a, nfi_stream_t stream) {
   k.width = a->width;
   k.tile_order = (((a->tuning >> 2) & 1) == 0 && (a->width % 8 == 0) && (a->height % 8 == 0)) ? 1 : 0;
   k.prof = (unsigned long long*)a->profile_cycles;
+  k.xray = a->ray_features;
+  REQUIRE(!(a->ray_features && a->profile_cycles), "render: no cycle profile with the view-direction decoder");
   // persistent 1-D grid: OCC blocks of 4 waves per CU, never more blocks than rays need
   const int occ = 3;
   int64_t blocks = (int64_t)256 * occ;
@@ -1474,7 +1549,20 @@ extern "C" int nfi_render_fwd(const nfi_render_args* a, nfi_stream_t stream) {
     else if (strict) hipLaunchKernelGGL((render_fwd_wide_kernel<TEX, ATT, false, 0>), grid, dim3(256), 0, s, k);        \
     else hipLaunchKernelGGL((render_fwd_wide_kernel<TEX, ATT, false, 1>), grid, dim3(256), 0, s, k);                    \
   } while (0)
-  if (a->n_samples > 64) {
+#define NFI_LAUNCH_RENDER_VD(TEX, ATT)                                                                                        \
+  do {                                                                                                                      \
+    if (a->n_samples > 64) hipLaunchKernelGGL((render_fwd_wide_kernel<TEX, ATT, true, 0, true>), grid, dim3(256), 0, s, k);   \
+    else hipLaunchKernelGGL((render_fwd_kernel<TEX, ATT, 2, true, 0, false, true>), grid, dim3(256), 0, s, k);                \
+  } while (0)
+  if (a->ray_features) {
+    if (a->texel_dtype == NFI_TEXEL_F32) {
+      if (att) NFI_LAUNCH_RENDER_VD(0, true); else NFI_LAUNCH_RENDER_VD(0, false);
+    } else if (a->texel_dtype == NFI_TEXEL_BF16) {
+      if (att) NFI_LAUNCH_RENDER_VD(1, true); else NFI_LAUNCH_RENDER_VD(1, false);
+    } else {
+      if (att) NFI_LAUNCH_RENDER_VD(2, true); else NFI_LAUNCH_RENDER_VD(2, false);
+    }
+  } else if (a->n_samples > 64) {
     if (a->texel_dtype == NFI_TEXEL_F32) {
       if (att) NFI_LAUNCH_RENDER_WIDE(0, true); else NFI_LAUNCH_RENDER_WIDE(0, false);
     } else if (a->texel_dtype == NFI_TEXEL_BF16) {
@@ -1489,6 +1577,7 @@ extern "C" int nfi_render_fwd(const nfi_render_args* a, nfi_stream_t stream) {
   } else {
     if (att) NFI_LAUNCH_RENDER(2, true); else NFI_LAUNCH_RENDER(2, false);
   }
+#undef NFI_LAUNCH_RENDER_VD
 #undef NFI_LAUNCH_RENDER_WIDE
 #undef NFI_LAUNCH_RENDER
   if (a->event_stop) (void)hipEventRecord((hipEvent_t)a->event_stop, s);

@@ -80,6 +80,32 @@ def decoder_pack(w1, b1, w2, b2, n_attention, texel_dtype=TEXEL_F32):
     return image
 
 
+RAY_FEATURE_PITCH = 48
+
+
+def decoder_pack_viewdir(w1, b1, w2, b2, w3, b3, n_attention, texel_dtype=TEXEL_F32):
+    """--use_viewdir decoder (33 outputs) + ViewDirectionMapper.output (w3, b3) -> operand image (fp32 [6016])."""
+    ts = [_f32c(t, n) for t, n in ((w1, 'w1'), (b1, 'b1'), (w2, 'w2'), (b2, 'b2'), (w3, 'w3'), (b3, 'b3'))]
+    n3 = n_attention if n_attention > 0 else 3
+    want = [(64, 32), (64,), (33, 64), (33,), (n3, 32), (n3,)]
+    if [tuple(t.shape) for t in ts] != want:
+        raise ValueError('view-direction decoder shapes must be %s; got %s' % (want, [tuple(t.shape) for t in ts]))
+    lib = _lib.load()
+    image = torch.empty((lib.nfi_decoder_image_floats_viewdir(),), dtype=torch.float32, device=ts[0].device)
+    with torch.cuda.device(ts[0].device):
+        _lib.check(lib.nfi_decoder_pack_viewdir(*[_lib.ptr(t) for t in ts], n_attention, texel_dtype, _lib.ptr(image),
+                                                _stream(ts[0])), 'nfi_decoder_pack_viewdir')
+    return image
+
+
+def pad_ray_features(x):
+    """ViewDirectionMapper.fc6 output [..., 32] -> [..., 48] rows [0, x, 0 x 15] (the kernels' accumulator-row order)."""
+    x = _f32c(x, 'ray_features')
+    if x.shape[-1] != 32:
+        raise ValueError('ray features must have 32 channels, got %s' % (tuple(x.shape),))
+    return torch.nn.functional.pad(x, (1, RAY_FEATURE_PITCH - 33)).contiguous()
+
+
 # --------------------------------------------------------------------------- #
 def raygen(height, width, focal, cam2world, bbox=None, center=None, normalize=False):
     cam2world = _f32c(cam2world, 'tform_cam2world')
@@ -145,10 +171,18 @@ def points_on_rays(ray_origins, ray_directions, depth):
 
 # --------------------------------------------------------------------------- #
 def field_query(points, texels, decoder_image, scene_range, n_attention, attention_values=None, use_sdf=True,
-                beta=None, alpha=None, want_sdf=False, want_semantics=False, want_outside=False):
-    """points [B,P,3] -> dict(sigma [B,P], rgb [B,P,3], sdf?, semantics?, outside?)."""
+                beta=None, alpha=None, want_sdf=False, want_semantics=False, want_outside=False,
+                ray_features=None, samples_per_ray=0):
+    """points [B,P,3] -> dict(sigma [B,P], rgb [B,P,3], sdf?, semantics?, outside?).
+    ray_features: padded [B, P/samples_per_ray, 48] (pad_ray_features) with a decoder_pack_viewdir image."""
     points = _f32c(points, 'points')
     B, P = points.shape[0], points.shape[1]
+    if ray_features is not None:
+        ray_features = _f32c(ray_features, 'ray_features')
+        if samples_per_ray <= 0 or P % samples_per_ray or \
+                tuple(ray_features.shape) != (B, P // samples_per_ray, RAY_FEATURE_PITCH):
+            raise ValueError('ray_features must be [B, P/samples_per_ray, 48]; got %s for P=%d, S=%d' % (
+                tuple(ray_features.shape), P, samples_per_ray))
     dev = points.device
     tdt = texel_dtype_of(texels)
     att = _f32c(attention_values, 'attention_values') if n_attention > 0 else None
@@ -167,7 +201,7 @@ def field_query(points, texels, decoder_image, scene_range, n_attention, attenti
                          use_sdf=int(use_sdf), beta=_f32c(beta, 'beta') if use_sdf else None,
                          alpha=_f32c(alpha, 'alpha') if use_sdf else None, scene_range=float(scene_range),
                          sigma=out['sigma'], rgb=out['rgb'], sdf=out.get('sdf'), semantics=out.get('semantics'),
-                         outside=out.get('outside'))
+                         outside=out.get('outside'), ray_features=ray_features, samples_per_ray=int(samples_per_ray))
     return out
 
 
@@ -268,8 +302,9 @@ TAP_NAMES = ('ray_origins', 'ray_directions', 'near_plane', 'far_plane', 'hit', 
 def render_fwd(cam2world, focal, height, width, num_samples, texels, decoder_image, scene_range, n_attention,
                attention_values=None, use_sdf=True, beta=None, alpha=None, bbox=None, center=None,
                noise_coarse=None, noise_fine=None, fine_sampling=True, white_background=True, taps=(),
-               skip_missed_rays=True, workspace=None, events=None, tuning=0, profile_cycles=None):
-    """Fused forward render.  Returns dict(rgb [B,H,W,3], depth, mask [B,H,W], + requested taps)."""
+               skip_missed_rays=True, workspace=None, events=None, tuning=0, profile_cycles=None, ray_features=None):
+    """Fused forward render.  Returns dict(rgb [B,H,W,3], depth, mask [B,H,W], + requested taps).
+    ray_features: padded [B,H,W,48] per-ray view-direction features (decoder_pack_viewdir image)."""
     cam2world = _f32c(cam2world, 'tform_cam2world')
     B = cam2world.shape[0]
     dev = cam2world.device
@@ -307,6 +342,10 @@ def render_fwd(cam2world, focal, height, width, num_samples, texels, decoder_ima
         u, ustride = _u_and_stride(noise_fine if noise_fine.dim() == 2 else noise_fine.reshape(-1, S), n, S)
     else:
         u, ustride = None, 0
+    if ray_features is not None:
+        ray_features = _f32c(ray_features, 'ray_features')
+        if ray_features.numel() != n * RAY_FEATURE_PITCH:
+            raise ValueError('ray_features must be [B,H,W,48], got %s' % (tuple(ray_features.shape),))
     with torch.cuda.device(dev):
         _lib.call_struct(
             'nfi_render_fwd', 'nfi_render_args', _stream(cam2world), n_scenes=B, height=height, width=width,
@@ -320,7 +359,7 @@ def render_fwd(cam2world, focal, height, width, num_samples, texels, decoder_ima
             noise_fine=u, noise_fine_row_stride=ustride, rgb=out['rgb'], depth=out['depth'], mask=out['mask'],
             workspace=workspace, workspace_bytes=workspace.numel(), skip_missed_rays=int(skip_missed_rays),
             event_start=None if events is None else events[0], event_stop=None if events is None else events[1],
-            tuning=int(tuning), profile_cycles=profile_cycles, **tap_t)
+            tuning=int(tuning), profile_cycles=profile_cycles, ray_features=ray_features, **tap_t)
     out.update(tap_t)
     out['_workspace'] = workspace
     return out

@@ -144,6 +144,13 @@ CASES = {
     'persp_s128_fine_rand': dict(B=1, H=6, W=6, S=128, scene_range=0.55, radius=1.3, focal=1.0254,
                                  white=True, fine=True, randomize=True, sdf=True, A=10, alpha=0.02,
                                  beta=0.1, bbox=False, ortho=False),
+    # --use_viewdir (carla): per-ray ViewDirectionMapper feature added to a 32-wide decoder output
+    'persp_viewdir_fine_rand': dict(B=2, H=8, W=8, S=16, scene_range=0.55, radius=1.6, focal=1.0254,
+                                    white=True, fine=True, randomize=True, sdf=True, A=10, alpha=0.05,
+                                    beta=0.1, bbox=False, ortho=False, viewdir=True),
+    'viewdir_density_rgb_coarse_only': dict(B=1, H=8, W=8, S=24, scene_range=0.55, radius=1.6, focal=1.0254,
+                                            white=False, fine=False, randomize=True, sdf=False, A=0, alpha=1.0,
+                                            beta=0.1, bbox=False, ortho=False, viewdir=True),
     'persp_s96_black_fine_det': dict(B=1, H=6, W=6, S=96, scene_range=0.55, radius=1.3, focal=1.0254,
                                      white=False, fine=True, randomize=False, sdf=True, A=10, alpha=0.02,
                                      beta=0.1, bbox=False, ortho=False),
@@ -166,14 +173,15 @@ def run_case(name, c, planes_all):
     g = torch.Generator().manual_seed(sum(ord(ch) * (i + 1) for i, ch in enumerate(name)))
     B, H, W, S, A = c['B'], c['H'], c['W'], c['S'], c['A']
     planes = planes_all[:B]
-    cfg_args = types.SimpleNamespace(use_viewdir=False, use_sdf=c['sdf'], attention_values=A,
+    vd = bool(c.get('viewdir', False))
+    cfg_args = types.SimpleNamespace(use_viewdir=vd, use_sdf=c['sdf'], attention_values=A,
                                      fine_sampling=c['fine'])
     dataset_config = {'scene_range': c['scene_range'], 'white_background': c['white']}
     render, _ = load_reference_render(cfg_args, dataset_config)
 
     torch.manual_seed(1234)
     gen = ref_gen.Generator(512, c['scene_range'], attention_values=A, use_sdf=c['sdf'],
-                            disable_stylegan_noise=True)
+                            disable_stylegan_noise=True, use_viewdir=vd)
     gen.eval()
     # plane producer stub: the StyleGAN2 synthesis network is outside the hot path
     class PlaneStub(torch.nn.Module):
@@ -183,11 +191,17 @@ def run_case(name, c, planes_all):
     with torch.no_grad():
         gen.decoder.net[0].weight.copy_(torch.randn(64, 32, generator=g))
         gen.decoder.net[0].bias.copy_(0.5 * torch.randn(64, generator=g))
-        gen.decoder.net[2].weight.copy_(torch.randn(1 + max(A, 3) if A == 0 else 1 + A, 64, generator=g))
+        gen.decoder.net[2].weight.copy_(torch.randn(gen.decoder.net[2].weight.shape[0], 64, generator=g))
         gen.decoder.net[2].bias.copy_(0.5 * torch.randn(gen.decoder.net[2].bias.shape[0], generator=g))
         if c['sdf']:
             gen.beta.fill_(c['beta'])
             gen.alpha.fill_(c['alpha'])
+        if vd:     # the output layer is zero-initialised in the reference (generator.py:217-219)
+            gen.viewdir_mapper.output.weight.copy_(torch.randn(gen.viewdir_mapper.output.weight.shape, generator=g))
+            gen.viewdir_mapper.output.bias.copy_(0.5 * torch.randn(gen.viewdir_mapper.output.bias.shape, generator=g))
+    ray_feature = []
+    if vd:
+        gen.viewdir_mapper.fc6.register_forward_hook(lambda m, i, o_: ray_feature.append(o_.detach().clone()))
     cam = look_at_cameras(B, c['radius'], g)
     focal = None if c['ortho'] else torch.full((B,), c['focal']) * (1 + 0.05 * torch.randn(B, generator=g))
     bbox = None
@@ -238,12 +252,16 @@ def run_case(name, c, planes_all):
     beta = gen.beta.detach() if c['sdf'] else None
     alpha = gen.alpha.detach() if c['sdf'] else None
 
+    viewdir = None
+    if vd:
+        viewdir = dict(x=ray_feature[0].reshape(B, H * W, 32), w3=gen.viewdir_mapper.output.weight.detach(),
+                       b3=gen.viewdir_mapper.output.bias.detach())
     # ---- oracle must reproduce the reference bit for bit -------------------
     with torch.no_grad():
         o = orc.render(planes, w1, b1, w2, b2, cam, focal, H, W, S, c['scene_range'],
                        white_background=c['white'], fine_sampling=c['fine'], bbox=bbox,
                        noise_coarse=noise_c, noise_fine=noise_f, use_sdf=c['sdf'], beta=beta,
-                       alpha=alpha, attention_values=att, want_semantics=(A > 0))
+                       alpha=alpha, attention_values=att, want_semantics=(A > 0), viewdir=viewdir)
 
     def same(a, b, what):
         assert a.shape == b.shape, (name, what, a.shape, b.shape)
@@ -282,6 +300,8 @@ def run_case(name, c, planes_all):
     if c['sdf']:
         out['beta'] = beta
         out['alpha'] = alpha
+    if vd:
+        out.update(viewdir_x=viewdir['x'], w3=viewdir['w3'], b3=viewdir['b3'])
     if noise_c is not None:
         out['noise_coarse'] = noise_c
     if noise_f is not None:

@@ -150,9 +150,15 @@ def decoder_params(w1, b1, w2, b2):
 def field_query(planes: torch.Tensor, w1, b1, w2, b2, x_in: torch.Tensor,
                 scene_range: float, use_sdf: bool = True,
                 beta: Optional[torch.Tensor] = None, alpha: Optional[torch.Tensor] = None,
-                attention_values: Optional[torch.Tensor] = None) -> Dict[str, torch.Tensor]:
+                attention_values: Optional[torch.Tensor] = None,
+                viewdir: Optional[dict] = None) -> Dict[str, torch.Tensor]:
     """planes [B,3,C,Hp,Wp]; x_in [B,...,3] world points; raw (un-gained) decoder
     weights w1 [64,C], b1 [64], w2 [1+A,64], b2 [1+A]; attention_values [B,A,3] or None.
+
+    viewdir (models/generator.py:189-253, 376-377, 662-663; --use_viewdir): dict(x=[B,N,32] per-ray output
+    of ViewDirectionMapper.fc6, w3=[A or 3,32], b3 raw `output` layer); x_in must then be [B,N,S,3]
+    (N rays of S samples: the closure broadcasts the ray feature over the sample axis) and w2/b2 have
+    1+32 rows: feat = output(leaky_relu(x + feat, 0.2)).
 
     Returns flat per-scene tensors: sigma [B,P], rgb [B,P,3], sdf [B,P],
     outside [B,P] (1.0 where the point is outside the scene cube) and, when
@@ -172,6 +178,11 @@ def field_query(planes: torch.Tensor, w1, b1, w2, b2, x_in: torch.Tensor,
     out = F.linear(hidden, gw2, gb2)
     dist = out[..., 0]
     feat = out[..., 1:]
+    if viewdir is not None:
+        xr = viewdir['x'].reshape(bs, -1, 1, feat.shape[-1])
+        y = F.leaky_relu(xr + feat.view(bs, xr.shape[1], -1, feat.shape[-1]), 0.2).view(feat.shape)
+        w3 = viewdir['w3']
+        feat = F.linear(y, w3 * (1.0 / math.sqrt(w3.shape[1])), viewdir['b3'])
     res = {'sdf': dist, 'outside': outside}
     if use_sdf:
         neg = -dist
@@ -251,7 +262,7 @@ def composite(sigma, rgb, rd, t, semantics=None, white_background=True):
 def render(planes, w1, b1, w2, b2, cam2world, focal, height, width, num_samples,
            scene_range, white_background=True, fine_sampling=True, bbox=None, center=None,
            noise_coarse=None, noise_fine=None, use_sdf=True, beta=None, alpha=None,
-           attention_values=None, want_semantics=False):
+           attention_values=None, want_semantics=False, viewdir=None):
     """Oracle restatement of run.py:176-350 given precomputed planes.
 
     noise_coarse [B,H,W,S] / noise_fine [B*H*W,S] in [0,1) or None (deterministic:
@@ -265,7 +276,7 @@ def render(planes, w1, b1, w2, b2, cam2world, focal, height, width, num_samples,
     t_c = stratified_depths(near, far, num_samples, noise_coarse)
     x_c = points_on_rays(ro, rd, t_c)
     shp = x_c.shape[:-1]
-    q = field_query(planes, w1, b1, w2, b2, x_c, scene_range, use_sdf, beta, alpha, attention_values)
+    q = field_query(planes, w1, b1, w2, b2, x_c, scene_range, use_sdf, beta, alpha, attention_values, viewdir)
     sigma = q['sigma'].view(*shp)
     rgb = q['rgb'].view(*shp, 3)
     sem = q['semantics'].view(*shp, -1) if (want_semantics and 'semantics' in q) else None
@@ -283,7 +294,7 @@ def render(planes, w1, b1, w2, b2, cam2world, focal, height, width, num_samples,
         o.update(weights_coarse=w, weights_smooth=ws, cdf=cdf, inds=inds, t_fine=t_f)
         t, perm = torch.sort(torch.cat((t_c, t_f), dim=-1), dim=-1)
         x_f = points_on_rays(ro, rd, t_f)
-        qf = field_query(planes, w1, b1, w2, b2, x_f, scene_range, use_sdf, beta, alpha, attention_values)
+        qf = field_query(planes, w1, b1, w2, b2, x_f, scene_range, use_sdf, beta, alpha, attention_values, viewdir)
         sigma_f = qf['sigma'].view(*shp[:3], -1)
         rgb_f = qf['rgb'].view(*shp[:3], -1, 3)
         o.update(sigma_fine=sigma_f, rgb_fine=rgb_f, perm=perm, t_sorted=t)

@@ -14,11 +14,19 @@ def oracle_render(meta, t, device='cpu'):
             meta['H'], meta['W'], meta['S'], meta['scene_range'], white_background=meta['white'],
             fine_sampling=meta['fine'], bbox=g.get('bbox'), noise_coarse=g.get('noise_coarse'),
             noise_fine=g.get('noise_fine'), use_sdf=meta['sdf'], beta=g.get('beta'), alpha=g.get('alpha'),
-            attention_values=g.get('attention_values'), want_semantics=meta['A'] > 0)
+            attention_values=g.get('attention_values'), want_semantics=meta['A'] > 0, viewdir=viewdir_of(g))
+
+
+def viewdir_of(t):
+    """dict(x, w3, b3) of a --use_viewdir golden case, else None."""
+    return dict(x=t['viewdir_x'], w3=t['w3'], b3=t['b3']) if 'viewdir_x' in t else None
 
 
 def hip_field_setup(meta, t, dev, texel_dtype=ops.TEXEL_F32):
     texels = ops.planes_to_texels(t['planes'].to(dev), texel_dtype)
+    if 'viewdir_x' in t:
+        return texels, ops.decoder_pack_viewdir(*(t[k].to(dev) for k in ('w1', 'b1', 'w2', 'b2', 'w3', 'b3')), meta['A'],
+                                                texel_dtype)
     image = ops.decoder_pack(t['w1'].to(dev), t['b1'].to(dev), t['w2'].to(dev), t['b2'].to(dev), meta['A'], texel_dtype)
     return texels, image
 
@@ -30,7 +38,8 @@ def hip_render(meta, t, dev, taps=(), skip_missed_rays=False, texel_dtype=ops.TE
         g('cam2world'), g('focal'), meta['H'], meta['W'], meta['S'], texels, image, meta['scene_range'], meta['A'],
         attention_values=g('attention_values'), use_sdf=meta['sdf'], beta=g('beta'), alpha=g('alpha'),
         bbox=g('bbox'), noise_coarse=g('noise_coarse'), noise_fine=g('noise_fine'), fine_sampling=meta['fine'],
-        white_background=meta['white'], taps=taps, skip_missed_rays=skip_missed_rays)
+        white_background=meta['white'], taps=taps, skip_missed_rays=skip_missed_rays,
+        ray_features=ops.pad_ray_features(t['viewdir_x'].to(dev)) if 'viewdir_x' in t else None)
 
 
 def err(a, b):

@@ -13,7 +13,7 @@ import pytest
 import torch
 
 from conftest import golden_case_names, load_golden
-from parity_util import err, hip_field_setup, hip_render, oracle_render
+from parity_util import err, hip_field_setup, hip_render, oracle_render, viewdir_of
 from nerf_from_image_amd import ops
 from oracle import nfi_oracle as orc
 
@@ -85,14 +85,17 @@ def test_field_query(case):
     B = meta['B']
     x = orc.points_on_rays(o['ro'], o['rd'], o['t_coarse']).reshape(B, -1, 3)
     q = ops.field_query(x.to(dev), texels, image, meta['scene_range'], meta['A'], g('attention_values'), meta['sdf'],
-                        g('beta'), g('alpha'), want_sdf=True, want_semantics=meta['A'] > 0, want_outside=True)
+                        g('beta'), g('alpha'), want_sdf=True, want_semantics=meta['A'] > 0, want_outside=True,
+                        ray_features=ops.pad_ray_features(g('viewdir_x')) if 'viewdir_x' in t else None,
+                        samples_per_ray=meta['S'])
     exact(q['outside'].float(), o['outside_coarse'].reshape(B, -1), 'outside mask')
     close(q['sdf'], o['sdf_coarse'].reshape(B, -1), 1e-5, 'sdf')
     close(q['sigma'], o['sigma_coarse'].reshape(B, -1), sigma_tol(meta, t), 'sigma')
     close(q['rgb'], o['rgb_coarse'].reshape(B, -1, 3), ATOL, 'rgb')
     if meta['A'] > 0:
-        ref = orc.field_query(t['planes'], t['w1'], t['b1'], t['w2'], t['b2'], x, meta['scene_range'], meta['sdf'],
-                              t.get('beta'), t.get('alpha'), t['attention_values'])
+        ref = orc.field_query(t['planes'], t['w1'], t['b1'], t['w2'], t['b2'], x.view(B, -1, meta['S'], 3),
+                              meta['scene_range'], meta['sdf'], t.get('beta'), t.get('alpha'), t['attention_values'],
+                              viewdir_of(t))
         close(q['semantics'], ref['semantics'], 1e-5, 'semantics')
 
 

@@ -44,8 +44,10 @@ __global__ __launch_bounds__(256) void scatter(float* __restrict__ img, unsigned
   }
 }
 
-int main() {
-  const unsigned n_texels = 4u * 3u * 256u * 256u;   // B=4 scenes x 3 planes x 256^2
+int main(int argc, char** argv) {
+  // default: B=4 scenes x 3 planes x 256^2 texels (100 MB, far beyond the 8 x 4 MB L2); pass a small
+  // count (e.g. 4096 = 512 KB) to see the L2-resident atomic rate
+  const unsigned n_texels = argc > 1 ? (unsigned)atoi(argv[1]) : 4u * 3u * 256u * 256u;
   float* img; hipMalloc(&img, (size_t)n_texels * 32 * 4);
   hipMemset(img, 0, (size_t)n_texels * 32 * 4);
   const int blocks = 256 * 8, rounds = 768;          // 8192 waves x 768 x 16 texel updates = 100.7M texel updates
