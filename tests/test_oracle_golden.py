@@ -15,7 +15,8 @@ def run_oracle(meta, t):
         meta['H'], meta['W'], meta['S'], meta['scene_range'], white_background=meta['white'],
         fine_sampling=meta['fine'], bbox=t.get('bbox'), noise_coarse=t.get('noise_coarse'),
         noise_fine=t.get('noise_fine'), use_sdf=meta['sdf'], beta=t.get('beta'), alpha=t.get('alpha'),
-        attention_values=t.get('attention_values'), want_semantics=meta['A'] > 0)
+        attention_values=t.get('attention_values'), want_semantics=meta['A'] > 0,
+        viewdir=dict(x=t['viewdir_x'], w3=t['w3'], b3=t['b3']) if 'viewdir_x' in t else None)
 
 
 @pytest.mark.parametrize('name', golden_case_names())
