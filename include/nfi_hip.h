@@ -313,8 +313,14 @@ typedef struct nfi_field_bwd_args {
    * (eps 1e-12).  Together with g_sdf == 1 this yields the analytic surface normals
    * normalize(d sdf / d x) of models/generator.py:599-623 without autograd. */
   int points_only; int normalize_g_points;
+  /* view-direction decoder (decoder_image from nfi_decoder_pack_viewdir; w2 is [33,64], g_w2 [33,64], g_b2 [33]):
+   * ray_features [B, P/samples_per_ray, NFI_RAY_FEATURE_PITCH], w3 raw [n3,32]; gradients g_ray_features (same
+   * padded shape, zero-initialised by the caller, columns 1..32 accumulate), g_w3 [n3,32], g_b3 [n3]. */
+  const float* ray_features; int samples_per_ray; const float* w3;
+  float* g_ray_features; float* g_w3; float* g_b3;
 } nfi_field_bwd_args;
-size_t nfi_decoder_bwd_image_floats(void);
+size_t nfi_decoder_bwd_image_floats(void);          /* workspace floats, plain decoder */
+size_t nfi_decoder_bwd_image_floats_viewdir(void);  /* workspace floats, view-direction decoder */
 int nfi_field_query_bwd(const nfi_field_bwd_args* a, nfi_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------

@@ -6,8 +6,10 @@ from . import _lib, ops
 
 def field_query_bwd(points, texels, decoder_image, w1, w2, scene_range, n_attention, attention_values, use_sdf, beta,
                     alpha, g_sigma, g_rgb, g_sdf=None, g_semantics=None, want_points=False, points_only=False,
-                    normalize_points=False):
-    """Returns dict(g_texels [B,3,R,R,32], g_w1, g_b1, g_w2, g_b2, g_attention_values?, g_beta?, g_alpha?, g_points?)."""
+                    normalize_points=False, viewdir=None):
+    """Returns dict(g_texels [B,3,R,R,32], g_w1, g_b1, g_w2, g_b2, g_attention_values?, g_beta?, g_alpha?, g_points?).
+    viewdir: None or dict(ray_features=padded [B,N,48], samples_per_ray, w3) for the --use_viewdir decoder
+    (decoder_image from ops.decoder_pack_viewdir, w2 [33,64]); adds g_ray_features [B,N,32], g_w3, g_b3."""
     f = ops._f32c
     points = f(points, 'points')
     B, P = points.shape[0], points.shape[1]
@@ -15,6 +17,9 @@ def field_query_bwd(points, texels, decoder_image, w1, w2, scene_range, n_attent
     if texels.dtype != torch.float32:
         raise TypeError('field_query_bwd: gradients need fp32 texels')
     n_out = 1 + n_attention if n_attention > 0 else 4
+    n3 = n_attention if n_attention > 0 else 3
+    if viewdir is not None:
+        n_out = 33
     lib = _lib.load()
     out = {}
     if not points_only:
@@ -30,7 +35,16 @@ def field_query_bwd(points, texels, decoder_image, w1, w2, scene_range, n_attent
             out['g_alpha'] = torch.zeros((1,), dtype=torch.float32, device=dev)
     if want_points or points_only:
         out['g_points'] = torch.zeros((B, P, 3), dtype=torch.float32, device=dev)
-    ws = torch.empty((lib.nfi_decoder_bwd_image_floats(),), dtype=torch.float32, device=dev)
+    vd_args = {}
+    if viewdir is not None:
+        rf = f(viewdir['ray_features'], 'ray_features')
+        vd_args = dict(ray_features=rf, samples_per_ray=int(viewdir['samples_per_ray']), w3=f(viewdir['w3'], 'w3'))
+        if not points_only:
+            out['g_w3'] = torch.zeros((n3, 32), dtype=torch.float32, device=dev)
+            out['g_b3'] = torch.zeros((n3,), dtype=torch.float32, device=dev)
+            vd_args['g_ray_features'] = torch.zeros_like(rf)
+    n_ws = lib.nfi_decoder_bwd_image_floats_viewdir() if viewdir is not None else lib.nfi_decoder_bwd_image_floats()
+    ws = torch.empty((n_ws,), dtype=torch.float32, device=dev)
     with torch.cuda.device(dev):
         _lib.call_struct(
             'nfi_field_query_bwd', 'nfi_field_bwd_args', ops._stream(points), n_scenes=B, points_per_scene=P,
@@ -41,15 +55,22 @@ def field_query_bwd(points, texels, decoder_image, w1, w2, scene_range, n_attent
             scene_range=float(scene_range), g_sigma=f(g_sigma, 'g_sigma'), g_rgb=f(g_rgb, 'g_rgb'),
             g_sdf=f(g_sdf, 'g_sdf'), g_semantics=f(g_semantics, 'g_semantics'), workspace=ws,
             workspace_bytes=ws.numel() * 4, points_only=int(points_only), normalize_g_points=int(normalize_points),
-            **out)
+            **vd_args, **out)
+    if 'g_ray_features' in vd_args:
+        out['g_ray_features'] = vd_args['g_ray_features'][..., 1:33]
     return out
 
 
-def make_field_bwd(texels, decoder_image, scene_range, n_attention, use_sdf, want_sdf, want_sem):
+def make_field_bwd(texels, decoder_image, scene_range, n_attention, use_sdf, want_sdf, want_sem, viewdir_pad=None,
+                   samples_per_ray=0):
     """Backward closure for ``autograd.differentiable('field_query', ...)``.
-    inputs = (points, planes, w1, b1, w2, b2, attention_values, beta, alpha); outputs = (sigma, rgb[, sdf][, semantics])."""
+    inputs = (points, planes, w1, b1, w2, b2, attention_values, beta, alpha[, ray_feature, w3, b3]);
+    outputs = (sigma, rgb[, sdf][, semantics]).  viewdir_pad: padded ray features of the --use_viewdir decoder."""
     def bwd(inputs, outputs, grads, needs):
-        pts, planes, w1, b1, w2, b2, att, be, al = inputs
+        pts, planes, w1, b1, w2, b2, att, be, al = inputs[:9]
+        vd = None
+        if viewdir_pad is not None:
+            vd = dict(ray_features=viewdir_pad, samples_per_ray=samples_per_ray, w3=inputs[10])
         g_sigma = torch.zeros_like(outputs[0]) if grads[0] is None else grads[0]
         g_rgb = torch.zeros_like(outputs[1]) if grads[1] is None else grads[1]
         i = 2
@@ -60,15 +81,18 @@ def make_field_bwd(texels, decoder_image, scene_range, n_attention, use_sdf, wan
         if want_sem:
             g_sem = grads[i]
         g = field_query_bwd(pts, texels, decoder_image, w1, w2, scene_range, n_attention, att, use_sdf, be, al,
-                            g_sigma, g_rgb, g_sdf, g_sem, want_points=bool(needs[0]))
+                            g_sigma, g_rgb, g_sdf, g_sem, want_points=bool(needs[0]), viewdir=vd)
         g_planes = ops.texels_to_planes(g['g_texels']) if needs[1] else None
-        return (g.get('g_points'), g_planes, g['g_w1'], g['g_b1'], g['g_w2'], g['g_b2'],
+        base = (g.get('g_points'), g_planes, g['g_w1'], g['g_b1'], g['g_w2'], g['g_b2'],
                 g.get('g_attention_values'), g.get('g_beta'), g.get('g_alpha'))
+        if vd is None:
+            return base
+        return base + (g['g_ray_features'].reshape(inputs[9].shape), g['g_w3'], g['g_b3'])
     return bwd
 
 
 def surface_normals(points, texels, decoder_image, w1, w2, scene_range, n_attention, attention_values, use_sdf, beta,
-                    alpha):
+                    alpha, viewdir=None):
     """normalize(d sdf / d x) per point [B,P,3]: the `normals` output of the sampler closure
     (models/generator.py:599-623), from the coordinate-gradient path of the backward kernel."""
     B, P = points.shape[0], points.shape[1]
@@ -77,5 +101,5 @@ def surface_normals(points, texels, decoder_image, w1, w2, scene_range, n_attent
     g = field_query_bwd(points, texels, decoder_image, w1, w2, scene_range, n_attention, attention_values, use_sdf,
                         beta, alpha, zeros, torch.zeros((B, P, 3), dtype=torch.float32, device=dev),
                         g_sdf=torch.ones((B, P), dtype=torch.float32, device=dev), points_only=True,
-                        normalize_points=True)
+                        normalize_points=True, viewdir=viewdir)
     return g['g_points']

@@ -66,15 +66,26 @@ def decoder_parameters(decoder):
 
 
 def make_sampler(planes, decoder, scene_range, n_attention, attention_values, use_sdf, beta, alpha,
-                 texel_dtype=ops.TEXEL_F32, request_model_outputs=()):
+                 texel_dtype=ops.TEXEL_F32, request_model_outputs=(), viewdir=None):
     """Builds the ``sampler(x_in, request_sampler_outputs)`` closure over HIP kernels.
 
-    planes [B,3,32,R,R] (view of the synthesis output), decoder: module with .net[0]/.net[2]."""
+    planes [B,3,32,R,R] (view of the synthesis output), decoder: module with .net[0]/.net[2].
+    viewdir (--use_viewdir): (ray_feature [B,H,W,1,32] = output of ViewDirectionMapper.fc6, output_layer =
+    the mapper's `output` EqualizedLinear); the closure of generator.py:243-251 is then part of the kernels."""
     w1, b1, w2, b2 = decoder_parameters(decoder)
     texels = ops.planes_to_texels(planes.detach(), texel_dtype)
-    image = ops.decoder_pack(w1.detach(), b1.detach(), w2.detach(), b2.detach(), n_attention, texel_dtype)
+    ray_feature = w3 = b3 = ray_pad = None
+    if viewdir is not None:
+        ray_feature, out_layer = viewdir
+        w3, b3 = out_layer.weight, out_layer.bias
+        image = ops.decoder_pack_viewdir(w1.detach(), b1.detach(), w2.detach(), b2.detach(), w3.detach(), b3.detach(),
+                                         n_attention, texel_dtype)
+        ray_pad = ops.pad_ray_features(ray_feature.detach().reshape(ray_feature.shape[0], -1, 32))   # [B,N,48]
+    else:
+        image = ops.decoder_pack(w1.detach(), b1.detach(), w2.detach(), b2.detach(), n_attention, texel_dtype)
     fused = FusedField(texels, image, attention_values, n_attention, use_sdf, beta, alpha, scene_range,
-                       planes=planes, decoder_params=(w1, b1, w2, b2))
+                       planes=planes, decoder_params=(w1, b1, w2, b2) + ((ray_feature, w3, b3) if viewdir is not None else ()))
+    fused.ray_features = ray_pad
 
     def sampler(x_in, request_sampler_outputs=['sigma', 'rgb']):
         for output in request_sampler_outputs:
@@ -87,21 +98,28 @@ def make_sampler(planes, decoder, scene_range, n_attention, attention_values, us
                 raise NotImplementedError('sampler: normals need fp32 texels')
         bs = x_in.shape[0]
         pts = x_in.reshape(bs, -1, 3)
+        spr = 0
+        if ray_pad is not None:
+            # generator.py:243-247: the ray feature is broadcast over x_in's sample axis
+            spr = x_in.shape[-2]
+            assert pts.shape[1] == ray_pad.shape[1] * spr, (tuple(x_in.shape), tuple(ray_pad.shape))
         want_sem = 'semantics' in request_sampler_outputs
         if want_sem:
             assert n_attention > 0
         want_sdf = 'sdf_distance' in request_sampler_outputs
 
-        def fwd(p, pl, a_w1, a_b1, a_w2, a_b2, att, be, al):
+        def fwd(p, pl, a_w1, a_b1, a_w2, a_b2, att, be, al, *vd_unused):
             q = ops.field_query(p, texels, image, scene_range, n_attention, att, use_sdf, be, al,
-                                want_sdf=want_sdf, want_semantics=want_sem)
+                                want_sdf=want_sdf, want_semantics=want_sem, ray_features=ray_pad, samples_per_ray=spr)
             return tuple(q[k] for k in ('sigma', 'rgb') + (('sdf',) if want_sdf else ()) +
                          (('semantics',) if want_sem else ()))
         bwd = None
         if texel_dtype == ops.TEXEL_F32:
-            bwd = make_field_bwd(texels, image, scene_range, n_attention, use_sdf, want_sdf, want_sem)
+            bwd = make_field_bwd(texels, image, scene_range, n_attention, use_sdf, want_sdf, want_sem, ray_pad, spr)
         args = (pts, planes, w1, b1, w2, b2, attention_values if n_attention > 0 else None,
                 beta if use_sdf else None, alpha if use_sdf else None)
+        if ray_pad is not None:
+            args = args + (ray_feature, w3, b3)
         if want_normals:
             args = tuple(None if t is None else t.detach() for t in args)
         res = differentiable('field_query', fwd, *args, bwd=bwd)
@@ -109,7 +127,9 @@ def make_sampler(planes, decoder, scene_range, n_attention, attention_values, us
         if want_normals:
             out['normals'] = surface_normals(pts.detach(), texels, image, w1.detach(), w2.detach(), scene_range,
                                              n_attention, None if attention_values is None else attention_values.detach(),
-                                             use_sdf, beta.detach(), alpha.detach())
+                                             use_sdf, beta.detach(), alpha.detach(),
+                                             viewdir=None if ray_pad is None else dict(
+                                                 ray_features=ray_pad, samples_per_ray=spr, w3=w3.detach()))
         i = 2
         if want_sdf:
             out['sdf_distance'] = res[i].unsqueeze(-1)
@@ -140,8 +160,6 @@ def hip_forward(self, viewdir, c, request_model_outputs=['sampler'], model_input
     for reg in ('sdf_eikonal_loss', 'sdf_distance_loss', 'total_variation_loss', 'entropy_loss'):
         if reg in request_model_outputs:
             raise NotImplementedError('%s (regulariser branch, generator.py:505-585) is outside the HIP hot path' % reg)
-    if self.use_viewdir:
-        raise NotImplementedError('use_viewdir (ViewDirectionMapper, carla only) is not implemented on the HIP path')
 
     # ---- latent handling (generator.py:423-446) ----
     label = None
@@ -199,11 +217,34 @@ def hip_forward(self, viewdir, c, request_model_outputs=['sampler'], model_input
         model_outputs['path_length'] = grad.square().sum(dim=-1).mean(dim=-1).sqrt()
 
     if 'sampler' in request_model_outputs:
+        vd = None
+        if self.use_viewdir and viewdir is not None:
+            # generator.py:468-469: the per-ray MLP stays PyTorch; only its output and its last layer are handed over
+            with _capture_ray_feature(self.viewdir_mapper) as cap:
+                self.viewdir_mapper(viewdir)
+            vd = (cap['x'], self.viewdir_mapper.output)
         model_outputs['sampler'] = make_sampler(
             planes, self.decoder, self.scene_range, self.attention_values, attention_values, self.use_sdf,
             self.beta if self.use_sdf else None, self.alpha if self.use_sdf else None,
-            texel_dtype=getattr(self, 'nfi_texel_dtype', ops.TEXEL_F32), request_model_outputs=request_model_outputs)
+            texel_dtype=getattr(self, 'nfi_texel_dtype', ops.TEXEL_F32), request_model_outputs=request_model_outputs,
+            viewdir=vd)
     return model_outputs
+
+
+class _capture_ray_feature:
+    """Context manager: forward hook on ViewDirectionMapper.fc6 recording its output (the per-ray feature the
+    mapper's closure adds to the decoder features, generator.py:237-247)."""
+
+    def __init__(self, mapper):
+        self.mapper = mapper
+        self.store = {}
+
+    def __enter__(self):
+        self.hook = self.mapper.fc6.register_forward_hook(lambda m, i, o: self.store.__setitem__('x', o))
+        return self.store
+
+    def __exit__(self, *a):
+        self.hook.remove()
 
 
 def wrapped_forward(self, viewdir, c, request_model_outputs=['sampler'], model_inputs={}):
@@ -212,8 +253,6 @@ def wrapped_forward(self, viewdir, c, request_model_outputs=['sampler'], model_i
     mapping / synthesis / texture networks, path-length and the SDF regulariser branch (505-585, plain
     PyTorch incl. its double backward) - while a forward hook captures the planes it produced; only the
     returned ``sampler`` closure is replaced by the HIP one.  The plane producer therefore runs once."""
-    if self.use_viewdir:
-        raise NotImplementedError('use_viewdir (ViewDirectionMapper, carla only) is not implemented on the HIP path')
     want_sampler = 'sampler' in request_model_outputs
     req = list(request_model_outputs)
     added_att = False
@@ -222,8 +261,13 @@ def wrapped_forward(self, viewdir, c, request_model_outputs=['sampler'], model_i
         added_att = True
     captured = {}
     hook = self.synthesis_network.register_forward_hook(lambda mod, inp, out: captured.__setitem__('planes', out))
+    use_vd = bool(self.use_viewdir) and viewdir is not None
     try:
-        model_outputs = self._nfi_original_forward(viewdir, c, req, model_inputs)
+        if use_vd:
+            with _capture_ray_feature(self.viewdir_mapper) as cap:
+                model_outputs = self._nfi_original_forward(viewdir, c, req, model_inputs)
+        else:
+            model_outputs = self._nfi_original_forward(viewdir, c, req, model_inputs)
     finally:
         hook.remove()
     if want_sampler:
@@ -233,7 +277,8 @@ def wrapped_forward(self, viewdir, c, request_model_outputs=['sampler'], model_i
         model_outputs['sampler'] = make_sampler(
             planes, self.decoder, self.scene_range, self.attention_values, att, self.use_sdf,
             self.beta if self.use_sdf else None, self.alpha if self.use_sdf else None,
-            texel_dtype=getattr(self, 'nfi_texel_dtype', ops.TEXEL_F32), request_model_outputs=request_model_outputs)
+            texel_dtype=getattr(self, 'nfi_texel_dtype', ops.TEXEL_F32), request_model_outputs=request_model_outputs,
+            viewdir=(cap['x'], self.viewdir_mapper.output) if use_vd else None)
     if added_att:
         del model_outputs['attention_values']
     return model_outputs

@@ -59,14 +59,18 @@ def _render(cfg, dcfg, target_model, height, width, tform_cam2world, focal_lengt
         raise NotImplementedError('depth_samples_per_ray > 128 per pass is not supported by the HIP kernels')
     scene_range = dcfg['scene_range']
     white = dcfg['white_background']
-    if cfg.use_viewdir:
-        raise NotImplementedError('use_viewdir is not implemented on the HIP path')
     if compute_normals:
         assert cfg.use_sdf
     if compute_semantics:
         assert cfg.attention_values > 0
 
-    model_outputs = target_model(None, model_input, ['sampler'] + extra_model_outputs, extra_model_inputs)
+    rays = None
+    viewdirs = None
+    if cfg.use_viewdir:
+        # run.py:192-219: the model needs the normalised ray directions before it can build the sampler
+        rays = nerf_utils.get_ray_bundle_normalized(height, width, focal_length, tform_cam2world, bbox, center)
+        viewdirs = (rays[1].detach() if force_no_cam_grad else rays[1]).unsqueeze(-2)
+    model_outputs = target_model(viewdirs, model_input, ['sampler'] + extra_model_outputs, extra_model_inputs)
     sampler = model_outputs['sampler']
     del model_outputs['sampler']
     fused = getattr(sampler, 'fused', None)
@@ -88,11 +92,11 @@ def _render(cfg, dcfg, target_model, height, width, tform_cam2world, focal_lengt
             None if fused.beta is None else fused.beta.detach(), None if fused.alpha is None else fused.alpha.detach(),
             bbox=None if bbox is None else bbox.detach(), center=None if center is None else center.detach(),
             noise_coarse=noise_c, noise_fine=noise_f, fine_sampling=bool(cfg.fine_sampling),
-            white_background=bool(white), skip_missed_rays=True)
+            white_background=bool(white), skip_missed_rays=True, ray_features=getattr(fused, 'ray_features', None))
         return out['rgb'], out['depth'], out['mask'], None, None, model_outputs
 
     # ---------------- staged path (differentiable / extra maps) ----------------
-    ray_origins, ray_directions = nerf_utils.get_ray_bundle_normalized(
+    ray_origins, ray_directions = rays if rays is not None else nerf_utils.get_ray_bundle_normalized(
         height, width, focal_length, tform_cam2world, bbox, center)
     with torch.no_grad():
         near, far = nerf_utils.compute_near_far_planes(ray_origins.detach(), ray_directions.detach(), scene_range)

@@ -62,19 +62,36 @@ class _Texture(nn.Module):
         return torch.sigmoid(self.lin(w).view(-1, self.A, 3)) * 2.004 - 1.002
 
 
+class _ViewDirMapper(nn.Module):
+    """Shape-compatible stand-in of ViewDirectionMapper (models/generator.py:189-253): a per-ray MLP whose last
+    hidden layer is `fc6` (its output is the per-ray feature) and whose `output` is the Linear(32, A or 3) the
+    closure applies per sample (raw EqualizedLinear parameters, gain 1/sqrt(32))."""
+
+    def __init__(self, n_out, gen):
+        super().__init__()
+        self.fc0 = nn.Linear(3, 64)
+        self.fc6 = nn.Linear(64, 32)
+        self.output = _Lin(32, n_out, gen)
+
+    def forward(self, viewdir):
+        return self.fc6(torch.nn.functional.leaky_relu(self.fc0(viewdir), 0.2))
+
+
 class StandInGenerator(nn.Module):
-    def __init__(self, scene_range, attention_values=10, use_sdf=True, plane_res=64, seed=5):
+    def __init__(self, scene_range, attention_values=10, use_sdf=True, plane_res=64, seed=5, use_viewdir=False):
         super().__init__()
         gen = torch.Generator().manual_seed(seed)
         self.scene_range = scene_range
         self.attention_values = attention_values
         self.use_sdf = use_sdf
-        self.use_viewdir = False
+        self.use_viewdir = use_viewdir
         self.use_encoder = False
         self.num_classes = None
         self.mapping_network = _Mapping(15 if attention_values > 0 else 14, gen)
         self.synthesis_network = _Synthesis(plane_res, gen)
-        self.decoder = _Decoder(1 + attention_values if attention_values > 0 else 4, gen)
+        self.decoder = _Decoder(33 if use_viewdir else (1 + attention_values if attention_values > 0 else 4), gen)
+        if use_viewdir:
+            self.viewdir_mapper = _ViewDirMapper(attention_values if attention_values > 0 else 3, gen)
         if attention_values > 0:
             self.texture_mapper = _Texture(attention_values)
         if use_sdf:

@@ -24,7 +24,8 @@ def test_wrapped_forward_keeps_reference_outputs_and_captures_planes(monkeypatch
     seen = {}
 
     def fake_make_sampler(planes, decoder, scene_range, n_att, att, use_sdf, beta, alpha, texel_dtype=0,
-                          request_model_outputs=()):
+                          request_model_outputs=(), viewdir=None):
+        assert viewdir is None
         seen.update(planes=planes, att=att, decoder=decoder, beta=beta, alpha=alpha, scene_range=scene_range)
         return lambda x, req=['sigma', 'rgb']: {'sigma': None}
     monkeypatch.setattr(nfi_gen, 'make_sampler', fake_make_sampler)
@@ -58,3 +59,45 @@ def test_wrapped_forward_keeps_reference_outputs_and_captures_planes(monkeypatch
     with torch.no_grad():
         model(None, z, ['sampler'], {'attention_values': att_over})
     assert torch.equal(seen['att'], att_over)
+
+
+def test_wrapped_forward_hands_over_the_view_direction_feature(monkeypatch):
+    """--use_viewdir: the per-ray feature captured from ViewDirectionMapper.fc6 and the mapper's output layer,
+    fed to the oracle's restatement of the closure, reproduce the reference's own sampler."""
+    sys.path.insert(0, REF)
+    try:
+        from models import generator as ref_gen
+    finally:
+        sys.path.remove(REF)
+    import nerf_from_image_amd.generator as nfi_gen
+    from oracle import nfi_oracle as orc
+    torch.manual_seed(0)
+    model = ref_gen.Generator(512, 0.55, attention_values=10, use_sdf=True, disable_stylegan_noise=True, use_viewdir=True)
+    with torch.no_grad():
+        model.viewdir_mapper.output.weight.normal_()
+        model.viewdir_mapper.output.bias.normal_()
+    model.eval()
+    seen = {}
+
+    def fake_make_sampler(planes, decoder, scene_range, n_att, att, use_sdf, beta, alpha, texel_dtype=0,
+                          request_model_outputs=(), viewdir=None):
+        seen.update(planes=planes, att=att, viewdir=viewdir)
+        return lambda x, req=['sigma', 'rgb']: {}
+    monkeypatch.setattr(nfi_gen, 'make_sampler', fake_make_sampler)
+    nfi_gen.attach(model)
+    z = torch.randn(2, 512)
+    H = W = 3
+    S = 5
+    viewdirs = torch.nn.functional.normalize(torch.randn(2, H, W, 1, 3), dim=-1)
+    x = torch.rand(2, H, W, S, 3) - 0.5
+    with torch.no_grad():
+        model(viewdirs, z, ['sampler'])
+        ref = model._nfi_original_forward(viewdirs, z, ['sampler'])['sampler'](x, ['sigma', 'rgb'])
+        ray_feature, out_layer = seen['viewdir']
+        assert ray_feature.shape == (2, H, W, 1, 32) and out_layer is model.viewdir_mapper.output
+        dec = model.decoder.net
+        mine = orc.field_query(seen['planes'], dec[0].weight, dec[0].bias, dec[2].weight, dec[2].bias, x, 0.55, True,
+                               model.beta, model.alpha, seen['att'],
+                               viewdir=dict(x=ray_feature.reshape(2, H * W, 32), w3=out_layer.weight, b3=out_layer.bias))
+    assert torch.allclose(mine['sigma'], ref['sigma'], atol=1e-6)
+    assert torch.allclose(mine['rgb'], ref['rgb'], atol=1e-6)

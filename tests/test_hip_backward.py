@@ -215,6 +215,67 @@ def test_field_query_backward(gpu_device, A, use_sdf, P):
         rel_close(a, b, 'grad ' + n, 5e-4)
 
 
+@pytest.mark.parametrize('A,use_sdf,N,S', [(10, True, 12, 16), (0, False, 7, 10), (10, True, 5, 64)])
+def test_field_query_backward_viewdir(gpu_device, A, use_sdf, N, S):
+    """--use_viewdir decoder (33 outputs + per-ray feature + third layer): every gradient, incl. the ray feature
+    (-> ViewDirectionMapper) and the mapper's output layer, against float64 autograd of the oracle."""
+    dev = gpu_device
+    g = torch.Generator().manual_seed(300 + A + N)
+    B, R = 2, 24
+    P = N * S
+    r = float(torch.tensor(0.55, dtype=torch.float32))
+    low = torch.randn(B * 3, 32, 6, 6, generator=g)
+    planes = torch.nn.functional.interpolate(low, size=(R, R), mode='bilinear', align_corners=True)
+    planes = (planes + 0.1 * torch.randn(B * 3, 32, R, R, generator=g)).view(B, 3, 32, R, R)
+    dec = _Decoder(33, g)
+    n3 = A if A > 0 else 3
+    out_layer = torch.nn.Linear(32, n3)
+    with torch.no_grad():
+        out_layer.weight.copy_(torch.randn(n3, 32, generator=g))
+        out_layer.bias.copy_(0.3 * torch.randn(n3, generator=g))
+    x = (torch.rand(B, N, S, 3, generator=g) * 2 - 1) * r * 1.1
+    xr = torch.randn(B, N, 1, 32, generator=g)
+    att = (torch.rand(B, A, 3, generator=g) * 2 - 1) if A > 0 else None
+    beta, alpha = torch.tensor([0.12]), torch.tensor([0.3])
+    w_sig, w_rgb = torch.randn(B, P, generator=g), torch.randn(B, P, 3, generator=g)
+    w_sdf = torch.randn(B, P, generator=g)
+    w_sem = torch.randn(B, P, A, generator=g) if A > 0 else None
+
+    dd = lambda t: None if t is None else t.detach().double().requires_grad_()
+    o_x, o_pl, o_att, o_be, o_al, o_xr = dd(x), dd(planes), dd(att), dd(beta), dd(alpha), dd(xr)
+    o_w = [dd(p) for p in (dec.net[0].weight, dec.net[0].bias, dec.net[2].weight, dec.net[2].bias,
+                           out_layer.weight, out_layer.bias)]
+    q = orc.field_query(o_pl, o_w[0], o_w[1], o_w[2], o_w[3], o_x, r, use_sdf, o_be if use_sdf else None,
+                        o_al if use_sdf else None, o_att, viewdir=dict(x=o_xr, w3=o_w[4], b3=o_w[5]))
+    loss = (q['sigma'] * w_sig.double()).sum() + (q['rgb'] * w_rgb.double()).sum() + (q['sdf'] * w_sdf.double()).sum()
+    if A > 0:
+        loss = loss + (q['semantics'] * w_sem.double()).sum()
+    leaves = [o_x, o_pl] + o_w + [o_xr] + ([o_att] if A > 0 else []) + ([o_be, o_al] if use_sdf else [])
+    ref = torch.autograd.grad(loss, leaves)
+
+    dec, out_layer = dec.to(dev), out_layer.to(dev)
+    h_pl, h_x, h_xr = planes.to(dev).requires_grad_(), x.to(dev).requires_grad_(), xr.to(dev).requires_grad_()
+    h_att = att.to(dev).requires_grad_() if A > 0 else None
+    h_be = beta.to(dev).requires_grad_() if use_sdf else None
+    h_al = alpha.to(dev).requires_grad_() if use_sdf else None
+    sampler = nfi_gen.make_sampler(h_pl, dec, r, A, h_att, use_sdf, h_be, h_al, viewdir=(h_xr, out_layer))
+    req = ['sigma', 'rgb', 'sdf_distance'] + (['semantics'] if A > 0 else [])
+    res = sampler(h_x, req)
+    rel_close(res['sigma'], q['sigma'], 'forward sigma', 2e-4)
+    rel_close(res['rgb'], q['rgb'], 'forward rgb', 2e-4)
+    loss_h = (res['sigma'] * w_sig.to(dev)).sum() + (res['rgb'] * w_rgb.to(dev)).sum() + \
+             (res['sdf_distance'][..., 0] * w_sdf.to(dev)).sum()
+    if A > 0:
+        loss_h = loss_h + (res['semantics'] * w_sem.to(dev)).sum()
+    h_w = [dec.net[0].weight, dec.net[0].bias, dec.net[2].weight, dec.net[2].bias, out_layer.weight, out_layer.bias]
+    h_leaves = [h_x, h_pl] + h_w + [h_xr] + ([h_att] if A > 0 else []) + ([h_be, h_al] if use_sdf else [])
+    got = torch.autograd.grad(loss_h, h_leaves)
+    names = ['points', 'planes', 'w1', 'b1', 'w2', 'b2', 'w3', 'b3', 'ray_feature'] + \
+            (['attention_values'] if A > 0 else []) + (['beta', 'alpha'] if use_sdf else [])
+    for n, a, b in zip(names, got, ref):
+        rel_close(a, b, 'grad ' + n, 5e-4)
+
+
 @pytest.mark.parametrize('fine,ortho', [(True, False), (False, False), (True, True)])
 def test_render_backward_end_to_end(gpu_device, fine, ortho):
     """d(rgb, mask)/d(planes producer params, decoder, beta, alpha, attention values, camera, focal) through
