@@ -171,6 +171,13 @@ typedef struct nfi_field_args {
 } nfi_field_args;
 int nfi_field_query_fwd(const nfi_field_args* a, nfi_stream_t stream);
 
+/* 'bbox' visualisation overlay of the sampler closure (models/generator.py:645-659, only with 'coords' in the
+ * sampler request and 'bbox' in the model request): sigma_out = sigma_in + 100 for points inside the scene cube
+ * that lie within 5e-2 of at least one face pair on every axis pair (the wire frame of the cube).
+ *   points [n,3], sigma_in / sigma_out [n] (may alias); threshold = (float)(scene_range - 5e-2) from the caller. */
+int nfi_bbox_overlay(const float* points, int64_t n_points, float scene_range, float threshold, const float* sigma_in,
+                     float* sigma_out, nfi_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------
  * Per-ray weights.  Replaces nerf_utils.render_volume_density_weights_only
  * (lib/nerf_utils.py:164-180, cumprod_exclusive 20-25).

@@ -590,6 +590,32 @@ extern "C" int nfi_field_query_fwd(const nfi_field_args* a, nfi_stream_t stream)
   return check_launch("field_query_fwd");
 }
 
+__global__ __launch_bounds__(256) void bbox_overlay_kernel(const float* __restrict__ points, int64_t n, float scene_range,
+                                                           float thr, const float* __restrict__ sigma_in,
+                                                           float* __restrict__ sigma_out) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float x = points[i * 3], y = points[i * 3 + 1], z = points[i * 3 + 2];
+  const bool outside = (fabsf(x / scene_range) > 1.0f) || (fabsf(y / scene_range) > 1.0f) || (fabsf(z / scene_range) > 1.0f);
+  const bool ix = fabsf(x) < thr, iy = fabsf(y) < thr, iz = fabsf(z) < thr;
+  // generator.py:650-658: product of (1 - both-inside) over the axis pairs xy, xz, yz (the last one twice)
+  float m = 1.0f;
+  m *= 1.0f - ((ix && iy) ? 1.0f : 0.0f);
+  m *= 1.0f - ((ix && iz) ? 1.0f : 0.0f);
+  m *= 1.0f - ((iy && iz) ? 1.0f : 0.0f);
+  m *= 1.0f - ((iy && iz) ? 1.0f : 0.0f);
+  m *= 1.0f - (outside ? 1.0f : 0.0f);
+  sigma_out[i] = sigma_in[i] + 100.0f * m;
+}
+
+extern "C" int nfi_bbox_overlay(const float* points, int64_t n_points, float scene_range, float threshold,
+                                const float* sigma_in, float* sigma_out, nfi_stream_t stream) {
+  REQUIRE(points && sigma_in && sigma_out && n_points > 0, "bbox_overlay: null pointer / empty");
+  hipLaunchKernelGGL(bbox_overlay_kernel, dim3((unsigned)((n_points + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     points, n_points, scene_range, threshold, sigma_in, sigma_out);
+  return check_launch("bbox_overlay");
+}
+
 // ------------------------------------------------------------------------------------------------
 // per-wave LDS slab used by the sampling / compositing stages
 // ------------------------------------------------------------------------------------------------

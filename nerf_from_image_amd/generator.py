@@ -139,7 +139,10 @@ def make_sampler(planes, decoder, scene_range, n_attention, attention_values, us
         if 'coords' in request_sampler_outputs:
             out['coords'] = x_in
             if 'bbox' in request_model_outputs:
-                raise NotImplementedError("sampler: the 'bbox' visualisation overlay is not implemented")
+                # visualisation overlay (generator.py:645-659): the reference adds it to sigma in place
+                pts_d = pts.detach()
+                out['sigma'] = differentiable('bbox_overlay', lambda s_: ops.bbox_overlay(pts_d, s_, scene_range), res[0],
+                                              bwd=lambda inputs, outputs, grads, needs: (grads[0],))
         if want_sem:
             out['semantics'] = res[i]
         if 'rgb' in request_sampler_outputs:

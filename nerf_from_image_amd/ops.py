@@ -205,6 +205,21 @@ def field_query(points, texels, decoder_image, scene_range, n_attention, attenti
     return out
 
 
+def bbox_overlay(points, sigma, scene_range):
+    """sigma + 100 on the wire frame of the scene cube (generator.py:645-659)."""
+    import numpy as np
+    points, sigma = _f32c(points, 'points'), _f32c(sigma, 'sigma')
+    n = sigma.numel()
+    if points.numel() != 3 * n:
+        raise ValueError('bbox_overlay: points %s do not match sigma %s' % (tuple(points.shape), tuple(sigma.shape)))
+    out = torch.empty_like(sigma)
+    thr = float(np.float32(scene_range - 5e-2))          # `x < scene_range - eps` against an fp32 tensor
+    with torch.cuda.device(sigma.device):
+        _lib.check(_lib.load().nfi_bbox_overlay(_lib.ptr(points), n, float(scene_range), thr, _lib.ptr(sigma),
+                                                _lib.ptr(out), _stream(sigma)), 'nfi_bbox_overlay')
+    return out
+
+
 # --------------------------------------------------------------------------- #
 def ray_weights(sigma, ray_directions, depth):
     sigma, rd, depth = _f32c(sigma, 'sigma'), _f32c(ray_directions, 'ray_directions'), _f32c(depth, 'depth')

@@ -199,6 +199,20 @@ def field_query(planes: torch.Tensor, w1, b1, w2, b2, x_in: torch.Tensor,
     return res
 
 
+def bbox_overlay(x_in: torch.Tensor, sigma: torch.Tensor, outside: torch.Tensor, scene_range: float) -> torch.Tensor:
+    """models/generator.py:645-659: the 'bbox' visualisation adds 100 to sigma on the wire frame of the cube.
+    x_in [B,...,3], sigma / outside [B,P]."""
+    eps = 5e-2
+    x_flat = x_in.view(x_in.shape[0], -1, 3).abs()
+    bbox_mask = torch.ones_like(sigma)
+    bbox_mask = bbox_mask * (1 - (x_flat[..., [0, 1]] < scene_range - eps).all(dim=-1).float())
+    bbox_mask = bbox_mask * (1 - (x_flat[..., [0, 2]] < scene_range - eps).all(dim=-1).float())
+    bbox_mask = bbox_mask * (1 - (x_flat[..., [1, 2]] < scene_range - eps).all(dim=-1).float())
+    bbox_mask = bbox_mask * (1 - (x_flat[..., [1, 2]] < scene_range - eps).all(dim=-1).float())
+    bbox_mask = bbox_mask * (1 - outside)
+    return sigma + 100 * bbox_mask
+
+
 # --------------------------------------------------------------------------- #
 # per-ray sampling / compositing
 # --------------------------------------------------------------------------- #

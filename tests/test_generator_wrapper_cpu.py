@@ -101,3 +101,26 @@ def test_wrapped_forward_hands_over_the_view_direction_feature(monkeypatch):
                                viewdir=dict(x=ray_feature.reshape(2, H * W, 32), w3=out_layer.weight, b3=out_layer.bias))
     assert torch.allclose(mine['sigma'], ref['sigma'], atol=1e-6)
     assert torch.allclose(mine['rgb'], ref['rgb'], atol=1e-6)
+
+
+def test_oracle_bbox_overlay_matches_reference():
+    """The 'bbox' visualisation overlay (generator.py:645-659) restated in the oracle, against the live closure."""
+    sys.path.insert(0, REF)
+    try:
+        from models import generator as ref_gen
+    finally:
+        sys.path.remove(REF)
+    from oracle import nfi_oracle as orc
+    torch.manual_seed(3)
+    model = ref_gen.Generator(512, 0.55, attention_values=10, use_sdf=True, disable_stylegan_noise=True).eval()
+    z = torch.randn(1, 512)
+    x = (torch.rand(1, 6, 6, 40, 3) * 2 - 1) * 0.6          # inside, near the faces / edges, and outside
+    with torch.no_grad():
+        out = model(None, z, ['sampler', 'bbox'])
+        ref = out['sampler'](x, ['sigma', 'coords'])
+        plain = model(None, z, ['sampler'])['sampler'](x, ['sigma'])['sigma']
+        outside = ((x.view(1, -1, 3) / 0.55).abs() > 1).any(dim=-1).float()
+        mine = orc.bbox_overlay(x, plain, outside, 0.55)
+    assert torch.equal(ref['coords'], x)
+    assert torch.equal(mine, ref['sigma'])
+    assert (mine != plain).float().mean() > 0.01

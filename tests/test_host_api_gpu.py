@@ -293,3 +293,18 @@ def test_render_with_view_directions(gpu_device):
         o = _viewdir_oracle(model, z, cam, focal, H, W, S, tap.draws, False)
     close(rgb, o['rgb'], 1e-4, 'fused rgb'); close(mask, o['mask'], 1e-4, 'fused mask'); close(depth, o['depth'], 1e-4, 'depth')
     assert o['mask'].mean() > 0.05
+
+
+def test_bbox_overlay(setup):
+    """'bbox' in the model request + 'coords' in the sampler request: sigma gets +100 on the cube's wire frame."""
+    model, cam, focal, z = setup
+    g = torch.Generator().manual_seed(4)
+    x = ((torch.rand(2, 5, 5, 33, 3, generator=g) * 2 - 1) * 0.6).to(cam.device)
+    with torch.no_grad():
+        plain = model(None, z, ['sampler'])['sampler'](x, ['sigma'])['sigma']
+        res = model(None, z, ['sampler', 'bbox'])['sampler'](x, ['sigma', 'coords'])
+    outside = ((x.view(2, -1, 3) / 0.55).abs() > 1).any(dim=-1).float()
+    ref = orc.bbox_overlay(x.cpu(), plain.cpu(), outside.cpu(), 0.55)
+    assert torch.equal(res['coords'], x)
+    assert torch.equal(res['sigma'].cpu(), ref)
+    assert (ref != plain.cpu()).float().mean() > 0.01
