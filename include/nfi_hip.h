@@ -325,7 +325,13 @@ typedef struct nfi_field_bwd_args {
    * padded shape, zero-initialised by the caller, columns 1..32 accumulate), g_w3 [n3,32], g_b3 [n3]. */
   const float* ray_features; int samples_per_ray; const float* w3;
   float* g_ray_features; float* g_w3; float* g_b3;
+  /* plane-gradient scatter.  0: fp32 atomics straight from the backward kernel (384 atomic dwords per point).
+   * 1: binned - the kernel writes the per-point feature gradient (128 B) to the workspace, the points are counting-
+   * sorted by texel cell per plane, and one half-wave per cell sums its points in registers before ONE set of
+   * atomics per cell; needs nfi_field_bwd_workspace_bytes(a) of workspace.  Same result up to fp32 summation order. */
+  int scatter_mode;
 } nfi_field_bwd_args;
+size_t nfi_field_bwd_workspace_bytes(const nfi_field_bwd_args* a);  /* for the scatter_mode / decoder of *a */
 size_t nfi_decoder_bwd_image_floats(void);          /* workspace floats, plain decoder */
 size_t nfi_decoder_bwd_image_floats_viewdir(void);  /* workspace floats, view-direction decoder */
 int nfi_field_query_bwd(const nfi_field_bwd_args* a, nfi_stream_t stream);

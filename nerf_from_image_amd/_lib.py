@@ -122,3 +122,10 @@ def call_struct(fname, struct_name, stream, **kw):
     lib = load()
     a = make_args(struct_name, **kw)
     check(getattr(lib, fname)(ctypes.byref(a), ctypes.c_void_p(stream)), fname)
+
+
+def struct_query(fname, struct_name, **kw):
+    """size_t f(const struct*) style helpers (workspace sizes)."""
+    lib = load()
+    a = make_args(struct_name, **kw)
+    return int(getattr(lib, fname)(ctypes.byref(a)))

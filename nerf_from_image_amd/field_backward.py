@@ -4,9 +4,12 @@ import torch
 from . import _lib, ops
 
 
+BINNED_SCATTER_MIN_POINTS = 1 << 16
+
+
 def field_query_bwd(points, texels, decoder_image, w1, w2, scene_range, n_attention, attention_values, use_sdf, beta,
                     alpha, g_sigma, g_rgb, g_sdf=None, g_semantics=None, want_points=False, points_only=False,
-                    normalize_points=False, viewdir=None):
+                    normalize_points=False, viewdir=None, scatter_mode=None):
     """Returns dict(g_texels [B,3,R,R,32], g_w1, g_b1, g_w2, g_b2, g_attention_values?, g_beta?, g_alpha?, g_points?).
     viewdir: None or dict(ray_features=padded [B,N,48], samples_per_ray, w3) for the --use_viewdir decoder
     (decoder_image from ops.decoder_pack_viewdir, w2 [33,64]); adds g_ray_features [B,N,32], g_w3, g_b3."""
@@ -43,19 +46,25 @@ def field_query_bwd(points, texels, decoder_image, w1, w2, scene_range, n_attent
             out['g_w3'] = torch.zeros((n3, 32), dtype=torch.float32, device=dev)
             out['g_b3'] = torch.zeros((n3,), dtype=torch.float32, device=dev)
             vd_args['g_ray_features'] = torch.zeros_like(rf)
-    n_ws = lib.nfi_decoder_bwd_image_floats_viewdir() if viewdir is not None else lib.nfi_decoder_bwd_image_floats()
-    ws = torch.empty((n_ws,), dtype=torch.float32, device=dev)
-    with torch.cuda.device(dev):
-        _lib.call_struct(
-            'nfi_field_query_bwd', 'nfi_field_bwd_args', ops._stream(points), n_scenes=B, points_per_scene=P,
+    if scatter_mode is None:
+        # binned plane-gradient scatter pays once the counting sort is amortised (dense renders); tiny queries
+        # (tests, the regulariser's 31^3 probes) scatter straight from the kernel
+        scatter_mode = 1 if (P >= BINNED_SCATTER_MIN_POINTS and not points_only) else 0
+    fields = dict(
+            n_scenes=B, points_per_scene=P,
             points=points, texels=texels, plane_res=texels.shape[2], texel_dtype=ops.TEXEL_F32,
             decoder_image=decoder_image, w1=f(w1, 'w1'), w2=f(w2, 'w2'), n_attention=n_attention,
             attention_values=f(attention_values, 'attention_values') if n_attention > 0 else None,
             use_sdf=int(use_sdf), beta=f(beta, 'beta') if use_sdf else None, alpha=f(alpha, 'alpha') if use_sdf else None,
             scene_range=float(scene_range), g_sigma=f(g_sigma, 'g_sigma'), g_rgb=f(g_rgb, 'g_rgb'),
-            g_sdf=f(g_sdf, 'g_sdf'), g_semantics=f(g_semantics, 'g_semantics'), workspace=ws,
-            workspace_bytes=ws.numel() * 4, points_only=int(points_only), normalize_g_points=int(normalize_points),
+            g_sdf=f(g_sdf, 'g_sdf'), g_semantics=f(g_semantics, 'g_semantics'),
+            points_only=int(points_only), normalize_g_points=int(normalize_points), scatter_mode=int(scatter_mode),
             **vd_args, **out)
+    n_ws = _lib.struct_query('nfi_field_bwd_workspace_bytes', 'nfi_field_bwd_args', **fields)
+    ws = torch.empty(((n_ws + 3) // 4,), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        _lib.call_struct('nfi_field_query_bwd', 'nfi_field_bwd_args', ops._stream(points), workspace=ws,
+                         workspace_bytes=ws.numel() * 4, **fields)
     if 'g_ray_features' in vd_args:
         out['g_ray_features'] = vd_args['g_ray_features'][..., 1:33]
     return out

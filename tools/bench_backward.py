@@ -29,14 +29,15 @@ def main():
         for _ in range(n): fn()
         torch.cuda.synchronize(); return (time.perf_counter() - t0) / n * 1e3
     fwd = timeit(lambda: ops.field_query(x, texels, image, 0.55, A, att, True, beta, alpha))
-    full = timeit(lambda: field_query_bwd(x, texels, image, w1, w2, 0.55, A, att, True, beta, alpha, gs, gr, want_points=True))
-    nocoord = timeit(lambda: field_query_bwd(x, texels, image, w1, w2, 0.55, A, att, True, beta, alpha, gs, gr, want_points=False))
+    full = timeit(lambda: field_query_bwd(x, texels, image, w1, w2, 0.55, A, att, True, beta, alpha, gs, gr, want_points=True, scatter_mode=0))
+    binned = timeit(lambda: field_query_bwd(x, texels, image, w1, w2, 0.55, A, att, True, beta, alpha, gs, gr, want_points=True, scatter_mode=1))
+    nocoord = timeit(lambda: field_query_bwd(x, texels, image, w1, w2, 0.55, A, att, True, beta, alpha, gs, gr, want_points=False, scatter_mode=0))
     ponly = timeit(lambda: field_query_bwd(x, texels, image, w1, w2, 0.55, A, att, True, beta, alpha, gs, gr, points_only=True))
     # zero upstream gradient: everything but the atomics and (skipped) scatter
     z1, z3 = torch.zeros_like(gs), torch.zeros_like(gr)
     zero = timeit(lambda: field_query_bwd(x, texels, image, w1, w2, 0.55, A, att, True, beta, alpha, z1, z3, want_points=False))
-    print('points %.1fM: fwd %.2f ms | bwd full(+coord) %.2f | bwd no coord grads %.2f | points_only (no atomics, no dW) %.2f | '
-          'zero upstream (no atomics) %.2f' % (B * P / 1e6, fwd, full, nocoord, ponly, zero))
+    print('points %.1fM: fwd %.2f ms | bwd full(+coord) atomic scatter %.2f, binned scatter %.2f | bwd no coord grads %.2f | points_only (no atomics, no dW) %.2f | '
+          'zero upstream (no atomics) %.2f' % (B * P / 1e6, fwd, full, binned, nocoord, ponly, zero))
 
 
 if __name__ == '__main__':
