@@ -1,0 +1,102 @@
+"""Edge cases of the fused renderer and the field query against the oracle (GPU): smallest and odd image sizes,
+minimum / odd sample counts, the largest attention table, the smallest and a large plane resolution, single
+points, rays that graze cube edges, and inputs the reference rejects."""
+import pytest
+import torch
+
+from parity_util import err
+from stand_in import look_at_cameras
+from nerf_from_image_amd import ops
+from oracle import nfi_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+def scene(B, A, PR, seed, use_sdf=True):
+    g = torch.Generator().manual_seed(seed)
+    n_out = 1 + A if A > 0 else 4
+    planes = torch.randn(B, 3, 32, PR, PR, generator=g)
+    if PR >= 64:      # white noise at this resolution is a field no sampler resolves: band-limit it like a real plane producer
+        low = torch.randn(B * 3, 32, 16, 16, generator=g)
+        planes = torch.nn.functional.interpolate(low, size=(PR, PR), mode='bilinear', align_corners=True).view(B, 3, 32, PR, PR) \
+            + 0.05 * planes
+    d = dict(planes=planes, w1=torch.randn(64, 32, generator=g),
+             b1=0.3 * torch.randn(64, generator=g), w2=torch.randn(n_out, 64, generator=g),
+             b2=0.3 * torch.randn(n_out, generator=g), beta=torch.tensor([0.1]), alpha=torch.tensor([0.2]),
+             att=(torch.rand(B, A, 3, generator=g) * 2 - 1) if A > 0 else None)
+    return d, g
+
+
+def both(d, cam, focal, H, W, S, A, noise_c, noise_f, dev, fine=True, white=True, use_sdf=True):
+    mv = lambda t: None if t is None else t.to(dev)
+    texels = ops.planes_to_texels(d['planes'].to(dev))
+    image = ops.decoder_pack(mv(d['w1']), mv(d['b1']), mv(d['w2']), mv(d['b2']), A)
+    r = ops.render_fwd(mv(cam), mv(focal), H, W, S, texels, image, 0.55, A, mv(d['att']), use_sdf, mv(d['beta']),
+                       mv(d['alpha']), noise_coarse=mv(noise_c), noise_fine=mv(noise_f), fine_sampling=fine,
+                       white_background=white, skip_missed_rays=True)
+    with torch.no_grad():
+        o = orc.render(d['planes'], d['w1'], d['b1'], d['w2'], d['b2'], cam, focal, H, W, S, 0.55, white_background=white,
+                       fine_sampling=fine, noise_coarse=noise_c, noise_fine=noise_f, use_sdf=use_sdf, beta=d['beta'],
+                       alpha=d['alpha'], attention_values=d['att'])
+    return r, o
+
+
+@pytest.mark.parametrize('H,W,S,A,PR,B', [(1, 1, 4, 10, 16, 1), (5, 7, 5, 14, 2, 2), (3, 9, 64, 1, 33, 1),
+                                           (2, 2, 65, 10, 8, 3), (4, 6, 127, 0, 16, 1), (8, 8, 17, 10, 512, 1)])
+def test_render_shapes_and_limits(gpu_device, H, W, S, A, PR, B):
+    d, g = scene(B, A, PR, 11 * H + S + A)
+    cam = look_at_cameras(B, 1.4, g)
+    focal = torch.full((B,), 2.5)          # narrow enough for the single off-centre ray of a 1x1 image to hit the cube
+    noise_c = torch.rand(B, H, W, S, generator=g)
+    noise_f = torch.rand(B * H * W, S, generator=g)
+    r, o = both(d, cam, focal, H, W, S, A, noise_c, noise_f, gpu_device, white=(S % 2 == 0))
+    for k in ('rgb', 'depth', 'mask'):
+        e = err(r[k], o[k])
+        assert e['max'] <= 1e-4 and e['nonfinite'] == 0, (k, e)
+
+
+def test_density_branch_coarse_only_odd_sizes(gpu_device):
+    d, g = scene(2, 0, 24, 5)
+    cam = look_at_cameras(2, 1.8, g)
+    focal = torch.full((2,), 0.9)
+    H, W, S = 7, 3, 31
+    noise_c = torch.rand(2, H, W, S, generator=g)
+    r, o = both(d, cam, focal, H, W, S, 0, noise_c, None, gpu_device, fine=False, use_sdf=False)
+    for k in ('rgb', 'depth', 'mask'):
+        assert err(r[k], o[k])['max'] <= 1e-4, k
+
+
+def test_single_point_and_cube_corners(gpu_device):
+    d, g = scene(1, 10, 16, 3)
+    dev = gpu_device
+    texels = ops.planes_to_texels(d['planes'].to(dev))
+    image = ops.decoder_pack(d['w1'].to(dev), d['b1'].to(dev), d['w2'].to(dev), d['b2'].to(dev), 10)
+    r = 0.55
+    for x in (torch.zeros(1, 1, 3), torch.tensor([[[r, r, r]]]), torch.tensor([[[-r, r, -r], [r, -r, 0.0], [0.0, 0.0, -r]]]),
+              torch.tensor([[[r * (1 + 2e-7), 0.0, 0.0]]])):
+        q = ops.field_query(x.to(dev), texels, image, r, 10, d['att'].to(dev), True, d['beta'].to(dev), d['alpha'].to(dev),
+                            want_sdf=True, want_outside=True)
+        ref = orc.field_query(d['planes'], d['w1'], d['b1'], d['w2'], d['b2'], x, r, True, d['beta'], d['alpha'], d['att'])
+        assert torch.equal(q['outside'].cpu().float(), ref['outside'])
+        assert err(q['sdf'], ref['sdf'])['max'] <= 1e-5 and err(q['rgb'], ref['rgb'])['max'] <= 1e-4
+        assert err(q['sigma'], ref['sigma'])['max'] <= 1e-3
+
+
+def test_rejected_inputs(gpu_device):
+    d, g = scene(1, 10, 16, 4)
+    dev = gpu_device
+    texels = ops.planes_to_texels(d['planes'].to(dev))
+    image = ops.decoder_pack(d['w1'].to(dev), d['b1'].to(dev), d['w2'].to(dev), d['b2'].to(dev), 10)
+    cam = look_at_cameras(1, 1.4, g).to(dev)
+    focal = torch.full((1,), 1.0, device=dev)
+    args = (texels, image, 0.55, 10, d['att'].to(dev), True, d['beta'].to(dev), d['alpha'].to(dev))
+    with pytest.raises(RuntimeError):
+        ops.render_fwd(cam, focal, 4, 4, 3, *args)            # fewer than 4 samples
+    with pytest.raises(RuntimeError):
+        ops.render_fwd(cam, focal, 4, 4, 129, *args)          # more than 128 samples per pass
+    with pytest.raises((RuntimeError, TypeError, ValueError)):
+        ops.render_fwd(cam.cpu(), focal.cpu(), 4, 4, 8, *args)   # CPU tensors: no CPU path
+    with pytest.raises((RuntimeError, ValueError)):
+        ops.decoder_pack(d['w1'].to(dev), d['b1'].to(dev), d['w2'][:5].to(dev), d['b2'][:5].to(dev), 10)
+    with pytest.raises(RuntimeError):
+        ops.planes_to_texels(torch.randn(1, 3, 32, 1, 1, device=dev))     # plane_res < 2
