@@ -509,10 +509,13 @@ __device__ __forceinline__ void tile_epilogue(const FieldParams& P, int lane, co
 // x[0..7] -> hi = fp16(x) (round toward zero), lo = fp16(x - hi): hi + lo carries 22 significand bits
 // (fp16 subnormals are preserved by the MFMA in the default kernel mode, so small values lose nothing)
 __device__ __forceinline__ void split_f16x8(const float (&x)[8], f16x8& hi, f16x8& lo) {
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     auto h = __builtin_amdgcn_cvt_pkrtz(x[2 * i], x[2 * i + 1]);
-    auto l = __builtin_amdgcn_cvt_pkrtz(x[2 * i] - (float)h[0], x[2 * i + 1] - (float)h[1]);
+    const f32x2 xv = {x[2 * i], x[2 * i + 1]}, hv = {(float)h[0], (float)h[1]};
+    const f32x2 r = xv - hv;                                  // one v_pk_add_f32 (exact: Sterbenz-like residual)
+    auto l = __builtin_amdgcn_cvt_pkrtz(r[0], r[1]);
     hi[2 * i] = h[0]; hi[2 * i + 1] = h[1];
     lo[2 * i] = l[0]; lo[2 * i + 1] = l[1];
   }
@@ -554,10 +557,12 @@ __device__ __forceinline__ void tile_mlp(const FieldParams& P, int lane, const f
       for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
+          // softplus in base 2.  v_med3(sp, h, 128) == (h > thr ? h : sp) of nn.Softplus wherever the two differ
+          // in fp32: for h beyond ~25 log2(1 + 2^h) rounds to h, beyond 128 2^h overflows and the median is h.
           float h = acc1[n][nt][r];
           float e = __builtin_amdgcn_exp2f(h);
           float sp = __builtin_amdgcn_logf(1.0f + e);
-          acc1[n][nt][r] = (h > kSoftplusThr2) ? h : sp;
+          acc1[n][nt][r] = __builtin_amdgcn_fmed3f(sp, h, 128.0f);
         }
     const f32x4 b2 = ldsv[(kB2F >> 2) + g];
 #pragma unroll
