@@ -25,7 +25,9 @@ def test_header_declares_the_expected_entry_points():
     declared = set(re.findall(r'\b(nfi_[a-z_0-9]+)\s*\(', src))
     assert declared == set(_lib.FUNCTIONS), declared ^ set(_lib.FUNCTIONS)
     for name in ('nfi_render_fwd', 'nfi_field_query_fwd', 'nfi_raygen', 'nfi_near_far', 'nfi_sample_pdf',
-                 'nfi_composite_fwd', 'nfi_planes_to_texels', 'nfi_decoder_pack'):
+                 'nfi_composite_fwd', 'nfi_planes_to_texels', 'nfi_decoder_pack', 'nfi_decoder_pack_viewdir',
+                 'nfi_field_query_bwd', 'nfi_field_bwd_workspace_bytes', 'nfi_composite_bwd', 'nfi_points_bwd',
+                 'nfi_raygen_bwd', 'nfi_bbox_overlay', 'nfi_resample', 'nfi_ray_weights'):
         assert name in declared
 
 
@@ -34,6 +36,11 @@ def test_library_exports_every_declared_symbol(lib):
         assert hasattr(lib, name), name
     assert lib.nfi_version() >= 100
     assert lib.nfi_decoder_image_floats() == 6224
+    assert lib.nfi_decoder_image_floats_viewdir() == 6016
+    # workspace of the binned scatter: feature gradients (128 B/point) + order + ranks + two cell tables
+    n_ws = _lib.struct_query('nfi_field_bwd_workspace_bytes', 'nfi_field_bwd_args', n_scenes=2, points_per_scene=1000,
+                             plane_res=16, scatter_mode=1)
+    assert n_ws >= 2 * 1000 * (128 + 24) + 2 * 3 * 2 * 256 * 4
     # 8 floats + 1 byte per ray + reduce words
     assert lib.nfi_render_workspace_bytes(16384) >= 16384 * 33
 
