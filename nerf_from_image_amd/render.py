@@ -13,8 +13,6 @@ Randomness follows the reference: ``torch.rand`` of [B,H,W,S] for the stratified
 ``torch.rand`` of [B*H*W,S] for the inverse-CDF draws (nerf_utils.py:115, 202), even in eval
 (``randomize`` defaults to True and no caller overrides it).
 """
-import types
-
 import torch
 
 from . import nerf_utils, ops

@@ -8,7 +8,6 @@ Reported per step: PSNR and mask IoU (lib/metrics.py:30-45, 79-94 restated) of b
   python tools/inversion_synthetic.py [--res 128 --samples 64 --batch 4 --steps 30]
 """
 import argparse
-import copy
 import os
 import sys
 import time
@@ -55,7 +54,6 @@ def pose_matrix(cam0, delta):
 
 def run(dev, res=32, samples=32, batch=2, steps=10, plane_res=48, seed=0, verbose=False):
     from stand_in import StandInGenerator, look_at_cameras
-    from test_host_api_gpu import RandTap
     import nerf_from_image_amd.generator as nfi_gen
     import nerf_from_image_amd.render as nfi_render
     from oracle import nfi_oracle as orc

@@ -1,5 +1,5 @@
 """Quick timing of the fused render on synthetic shapenet_chairs-like inputs (GPU box)."""
-import os, sys, math, time
+import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch
