@@ -161,6 +161,21 @@ def extras(dev, ops, d):
                        alpha=dd['alpha'], attention_values=dd['att'])
             torch.cuda.synchronize()
             times.append(time.perf_counter() - t0)
+    # BASELINE config 3 stand-in (no p3d_car data / checkpoint exists offline): synthetic inversion, 30 Adam steps on
+    # latent + pose, HIP renderer (forward + HIP backward kernels) vs the oracle under PyTorch-ROCm autograd, same noise
+    try:
+        sys.path.insert(0, os.path.join(ROOT, 'tools'))
+        sys.path.insert(0, os.path.join(ROOT, 'tests'))
+        import inversion_synthetic
+        h_hip, h_ref, t_hip, t_ref = inversion_synthetic.run(dev, res=128, samples=64, batch=4, steps=30, plane_res=256)
+        ex['inversion_synthetic'] = {
+            'psnr_start': h_hip[0][0], 'psnr_hip': h_hip[-1][0], 'psnr_reference_path': h_ref[-1][0],
+            'iou_hip': h_hip[-1][1], 'iou_reference_path': h_ref[-1][1],
+            'ms_per_step_hip': t_hip * 1e3, 'ms_per_step_reference_path': t_ref * 1e3,
+            'sample': '4 images 128x128, 64+64 samples, 30 Adam steps (lr 2e-3, betas 0.9/0.95) on latent + pose, '
+                      'stand-in plane producer; reference path = oracle ops under PyTorch-ROCm autograd; median step'}
+    except Exception as e:      # reported, never fatal for the headline line
+        ex['inversion_synthetic'] = {'error': repr(e)}
     ex['pytorch_rocm_reference_path'] = {'value': 2 * R * R / min(times[1:]), 'unit': 'rays/s',
                                          'sample': 'oracle (reference ATen op sequence) on this GPU, 2 images, '
                                                    'render only, fp32, best of 2 after warm-up'}
