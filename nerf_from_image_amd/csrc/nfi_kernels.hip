@@ -1121,6 +1121,10 @@ struct RenderKernelParams {
   uint32_t* counter;   // work counter (zeroed with reduce[])
   int width;           // image width (tile order of the work queue)
   int tile_order;      // 1: hand rays out in 8x8 pixel tiles instead of scanlines
+  int xcd_blocks;      // 1: every XCD marches its own 16x16-pixel blocks (own queue, steals when it runs dry)
+  uint32_t* xcd_counter;   // 8 counters, 64 bytes apart
+  int xcd_block_shift;     // log2 of the block side: 3, 4 or 5
+  int fetch_batch;         // positions taken per atomic
   // field
   const void* texels; int res;
   const float* image; int A; const float* att;
@@ -1146,6 +1150,57 @@ struct RenderKernelParams {
 struct RayInputs {
   float ox, oy, oz, dx, dy, dz, near, far, noise, u;
   uint32_t hit;
+};
+
+// Work hand-out of the persistent render kernels.  One device-scope counter for all waves serialises at ~12 ns per
+// fetch on this chip (131 k rays -> 1.6 ms: with it the counter, not the field, set the kernel time), so every XCD
+// has its own counter, served by its own L2: the image is cut into square pixel blocks, block b belongs to XCD b % 8
+// (all XCDs stay on the same scene), positions inside a block walk 8x8 sub-tiles, and an XCD that runs dry steals
+// from the next one's queue.  fetch() is wave-uniform and returns a RAY ID (n_rays: no work left); without the
+// per-XCD queues (image sides not multiples of the block side, or tuning bit 4) it returns a position of the single
+// queue, which ray_of() maps to a ray.
+struct RayQueue {
+  const RenderKernelParams& k;
+  int lane;
+  uint32_t n_rays, xcd, bsh, bw, bps, n_blocks, q_cur, pos_next, pos_end, batch;
+  bool dry;
+  __device__ __forceinline__ RayQueue(const RenderKernelParams& kk, int l) : k(kk), lane(l) {
+    n_rays = (uint32_t)k.n_scenes * (uint32_t)k.hw;
+    xcd = k.xcd_blocks ? (__builtin_amdgcn_s_getreg(6164) & 7u) : 0u;     // hwreg(HW_REG_XCC_ID, 0, 4)
+    bsh = (uint32_t)k.xcd_block_shift;                                   // log2 of the block side (3..5)
+    bw = (uint32_t)k.width >> bsh;
+    bps = bw * (((uint32_t)k.hw / (uint32_t)k.width) >> bsh);
+    n_blocks = bps * (uint32_t)k.n_scenes;
+    q_cur = xcd; pos_next = 0; pos_end = 0; dry = false;
+    batch = (uint32_t)k.fetch_batch;
+  }
+  __device__ __forceinline__ uint32_t ray_at(uint32_t q, uint32_t pos) const {
+    const uint32_t b = (pos >> (2 * bsh)) * 8u + q;
+    const uint32_t in = pos & ((1u << (2 * bsh)) - 1u), scene = b / bps, bb = b - scene * bps;
+    const uint32_t by = bb / bw, bx = bb - by * bw;
+    const uint32_t st = in >> 6, sty = st >> (bsh - 3), stx = st & ((1u << (bsh - 3)) - 1u);   // 8x8 sub-tile of the block
+    const uint32_t y = (by << bsh) + (sty << 3) + ((in >> 3) & 7u), x = (bx << bsh) + (stx << 3) + (in & 7u);
+    return scene * (uint32_t)k.hw + y * (uint32_t)k.width + x;
+  }
+  __device__ __forceinline__ uint32_t fetch() {
+    if (!k.xcd_blocks) {
+      uint32_t p = 0;
+      if (lane == 0) p = atomicAdd(k.counter, 1u);
+      return (uint32_t)__builtin_amdgcn_readfirstlane((int)p);
+    }
+    if (pos_next == pos_end && !dry) {
+      dry = true;
+      for (uint32_t i = 0; i < 8; ++i) {
+        uint32_t base = 0;
+        if (lane == 0) base = atomicAdd(k.xcd_counter + q_cur * 16, batch);
+        base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+        if ((base >> (2 * bsh)) * 8u + q_cur < n_blocks) { pos_next = base; pos_end = base + batch; dry = false; break; }
+        q_cur = (q_cur + 1) & 7u;        // this queue is empty: steal from the next XCD's
+      }
+    }
+    if (dry) return n_rays;
+    return ray_at(q_cur, pos_next++);
+  }
 };
 
 template <int TEX, bool ATT, int OCC, bool TAPS, int PREC, bool PROF = false, bool VD = false>
@@ -1178,7 +1233,7 @@ __global__ __launch_bounds__(256, OCC) void render_fwd_kernel(RenderKernelParams
   // planes) instead of a band of scanlines - better L2/Infinity-Cache reuse of the gather stream.
   const uint32_t tiles_x = (uint32_t)k.width >> 3;
   auto ray_of = [&](uint32_t pos) -> uint32_t {
-    if (!k.tile_order) return pos;
+    if (k.xcd_blocks || !k.tile_order) return pos;
     const uint32_t scene = pos / (uint32_t)k.hw, p = pos - scene * (uint32_t)k.hw;
     const uint32_t tile = p >> 6, in = p & 63u;
     const uint32_t ty = tile / tiles_x, tx = tile - ty * tiles_x;
@@ -1200,10 +1255,9 @@ __global__ __launch_bounds__(256, OCC) void render_fwd_kernel(RenderKernelParams
   };
 
   // ray indices: cur (being marched), nxt (inputs being loaded), and one more in flight
-  uint32_t cur = 0, nxt = 0, fly = 0;
-  if (lane == 0) { cur = atomicAdd(counter, 1u); nxt = atomicAdd(counter, 1u); }
-  cur = (uint32_t)__builtin_amdgcn_readfirstlane((int)cur);
-  nxt = (uint32_t)__builtin_amdgcn_readfirstlane((int)nxt);
+  RayQueue queue(k, lane);
+  auto fetch = [&]() -> uint32_t { return queue.fetch(); };
+  uint32_t cur = fetch(), nxt = fetch(), fly = 0;
   RayInputs in, pre;
   // PROF: per-wave cycle accumulators [0..3] field tiles (see field_wave), [4] ray set-up, [5] coarse field,
   // [6] resample, [7] fine field, [8] merge, [9] composite + store, [10] rays, [11] total
@@ -1211,7 +1265,7 @@ __global__ __launch_bounds__(256, OCC) void render_fwd_kernel(RenderKernelParams
   unsigned long long tk0 = PROF ? __builtin_readcyclecounter() : 0;
   if (cur < n_rays) load_inputs(ray_of(cur), in);
   while (cur < n_rays) {
-    if (lane == 0) fly = atomicAdd(counter, 1u);
+    fly = fetch();
     if (nxt < n_rays) load_inputs(ray_of(nxt), pre);
     const uint32_t ray = ray_of(cur);
     const uint32_t hitb = in.hit;
@@ -1318,7 +1372,7 @@ __global__ __launch_bounds__(256, OCC) void render_fwd_kernel(RenderKernelParams
     }
     in = pre;
     cur = nxt;
-    nxt = (uint32_t)__builtin_amdgcn_readfirstlane((int)fly);
+    nxt = fly;
   }
   if (PROF && k.prof && lane == 0) {
     pc[11] = __builtin_readcyclecounter() - tk0;
@@ -1353,7 +1407,7 @@ __global__ __launch_bounds__(256, 2) void render_fwd_wide_kernel(RenderKernelPar
   const uint32_t n_rays = (uint32_t)k.n_scenes * (uint32_t)k.hw;
   const uint32_t tiles_x = (uint32_t)k.width >> 3;
   auto ray_of = [&](uint32_t pos) -> uint32_t {
-    if (!k.tile_order) return pos;
+    if (k.xcd_blocks || !k.tile_order) return pos;
     const uint32_t scene = pos / (uint32_t)k.hw, p = pos - scene * (uint32_t)k.hw;
     const uint32_t tile = p >> 6, in = p & 63u;
     const uint32_t ty = tile / tiles_x, tx = tile - ty * tiles_x;
@@ -1362,11 +1416,10 @@ __global__ __launch_bounds__(256, 2) void render_fwd_wide_kernel(RenderKernelPar
   FieldParams P = make_field_params(k.texels, k.res, TEX, k.A, k.use_sdf, k.beta, k.alpha, lds, kImg);
   P.vf = vf;
   int cur_scene = -1;
-  uint32_t cur = 0, nxt = 0;
-  if (lane == 0) cur = atomicAdd(k.counter, 1u);
-  cur = (uint32_t)__builtin_amdgcn_readfirstlane((int)cur);
+  RayQueue queue(k, lane);
+  uint32_t cur = queue.fetch(), nxt = 0;
   while (cur < n_rays) {
-    if (lane == 0) nxt = atomicAdd(k.counter, 1u);
+    nxt = queue.fetch();
     const uint32_t ray = ray_of(cur);
     const uint32_t hitb = k.hit[ray];
     if (k.skip_missed && !(hitb & 2)) {
@@ -1492,14 +1545,14 @@ __global__ __launch_bounds__(256, 2) void render_fwd_wide_kernel(RenderKernelPar
       }
       wave_lds_fence();  // slab is reused by the next ray
     }
-    cur = (uint32_t)__builtin_amdgcn_readfirstlane((int)nxt);
+    cur = nxt;
   }
 }
 
 extern "C" size_t nfi_render_workspace_bytes(int64_t n_rays) {
   // ro, rd, near_raw, far_raw (fp32) + hit (u8, padded) + reduce[4]
   size_t n = (size_t)n_rays;
-  return n * 8 * sizeof(float) + ((n + 15) & ~(size_t)15) + 64;
+  return n * 8 * sizeof(float) + ((n + 63) & ~(size_t)63) + 64 + 8 * 64;     // + 8 per-XCD work counters
 }
 
 extern "C" int nfi_render_fwd(const nfi_render_args* a, nfi_stream_t stream) {
@@ -1548,6 +1601,21 @@ extern "C" int nfi_render_fwd(const nfi_render_args* a, nfi_stream_t stream) {
 
   k.counter = reduce + 3;
   k.width = a->width;
+  // per-XCD queues (tuning bit 4): 16x16-pixel blocks, needs image sides that are multiples of 16
+  {
+    // defaults: 16x16-pixel blocks, one position per atomic (MI355X, 8 x 128^2 x (64+64): 1.00 ms chairs-like /
+    // 1.36 ms every-ray-hits; 8x8 blocks 0.94-1.01 / 1.39-1.49; 4 positions per atomic 1.06-1.10 / 1.44-1.51; one
+    // device-wide counter 1.82 / 2.10).  Experiment knobs: bits 5-6 = 1 -> 8x8, 2 -> 32x32 blocks; bit 7 -> 4,
+    // bit 8 -> 2 positions per atomic.
+    k.fetch_batch = ((a->tuning >> 7) & 1) ? 4 : (((a->tuning >> 8) & 1) ? 2 : 1);
+    const int sel = (a->tuning >> 5) & 3;
+    k.xcd_block_shift = sel == 1 ? 3 : (sel == 2 ? 5 : 4);
+    const int side = 1 << k.xcd_block_shift;
+    k.xcd_blocks = (((a->tuning >> 4) & 1) == 0 && (a->width % side == 0) && (a->height % side == 0)) ? 1 : 0;
+  }
+  k.xcd_counter = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(a->workspace) + 64 + (size_t)n * 32 +
+                                              (((size_t)n + 63) & ~(size_t)63));
+  if (k.xcd_blocks && hipMemsetAsync(k.xcd_counter, 0, 8 * 64, s) != hipSuccess) return fail(NFI_ERR_LAUNCH, "render: memset failed");
   k.tile_order = (((a->tuning >> 2) & 1) == 0 && (a->width % 8 == 0) && (a->height % 8 == 0)) ? 1 : 0;
   k.prof = (unsigned long long*)a->profile_cycles;
   k.xray = a->ray_features;

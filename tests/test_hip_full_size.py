@@ -143,7 +143,13 @@ def test_mlp_precision_modes(gpu_device):
     def run(tuning):
         return ops.render_fwd(d['cam'], d['focal'], R, R, S, texels, image, 0.55, A, d['att'], True, d['beta'], d['alpha'],
                               noise_coarse=d['noise_c'], noise_fine=d['noise_f'], tuning=tuning)
-    split, strict, scan = run(0), run(8), run(4)
+    split, strict, scan, xcd = run(0), run(8), run(4 + 16), run(16)
+    for tuning in (32, 64, 128, 256 + 32):        # block sizes / fetch batches of the per-XCD queues
+        v = run(tuning)
+        for k in ('rgb', 'depth', 'mask'):
+            assert torch.equal(v[k], split[k]), (tuning, k)
+    for k in ('rgb', 'depth', 'mask'):
+        assert torch.equal(xcd[k], split[k]), ('work hand-out (per-XCD queues vs one counter) must not change a bit', k)
     for k in ('rgb', 'depth', 'mask'):
         assert err(split[k], o[k])['max'] <= 1e-4, ('split-fp16', k, err(split[k], o[k]))
         assert err(strict[k], o[k])['max'] <= 1e-4, ('fp32', k, err(strict[k], o[k]))
