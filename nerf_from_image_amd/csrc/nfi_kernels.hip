@@ -1621,7 +1621,9 @@ extern "C" int nfi_render_fwd(const nfi_render_args* a, nfi_stream_t stream) {
   k.xray = a->ray_features;
   REQUIRE(!(a->ray_features && a->profile_cycles), "render: no cycle profile with the view-direction decoder");
   // persistent 1-D grid: OCC blocks of 4 waves per CU, never more blocks than rays need
-  const int occ = 3;
+  // 2 blocks (8 waves) per CU: with the whole 256-VGPR budget the field tile keeps more loads and MFMA chains in
+  // flight than at 3 blocks/CU (MI355X, 8 x 128^2: 0.96 vs 1.01-1.08 ms; 4 blocks/CU spill: 1.52 ms)
+  const int occ = 2;
   int64_t blocks = (int64_t)256 * occ;
   if (blocks > (n + 3) / 4) blocks = (n + 3) / 4;
   dim3 grid((unsigned)blocks);
@@ -1630,11 +1632,11 @@ extern "C" int nfi_render_fwd(const nfi_render_args* a, nfi_stream_t stream) {
   const bool strict = ((a->tuning >> 3) & 1) != 0;   // exact-fp32 MLP instead of the split-fp16 one
 #define NFI_LAUNCH_RENDER(TEX, ATT)                                                                                   \
   do {                                                                                                                \
-    if (k.prof) hipLaunchKernelGGL((render_fwd_kernel<TEX, ATT, 3, false, 1, true>), grid, dim3(256), 0, s, k);         \
+    if (k.prof) hipLaunchKernelGGL((render_fwd_kernel<TEX, ATT, 2, false, 1, true>), grid, dim3(256), 0, s, k);         \
     else if (any_tap && strict) hipLaunchKernelGGL((render_fwd_kernel<TEX, ATT, 2, true, 0>), grid, dim3(256), 0, s, k); \
     else if (any_tap) hipLaunchKernelGGL((render_fwd_kernel<TEX, ATT, 2, true, 1>), grid, dim3(256), 0, s, k);          \
-    else if (strict) hipLaunchKernelGGL((render_fwd_kernel<TEX, ATT, 3, false, 0>), grid, dim3(256), 0, s, k);          \
-    else hipLaunchKernelGGL((render_fwd_kernel<TEX, ATT, 3, false, 1>), grid, dim3(256), 0, s, k);                      \
+    else if (strict) hipLaunchKernelGGL((render_fwd_kernel<TEX, ATT, 2, false, 0>), grid, dim3(256), 0, s, k);          \
+    else hipLaunchKernelGGL((render_fwd_kernel<TEX, ATT, 2, false, 1>), grid, dim3(256), 0, s, k);                      \
   } while (0)
 #define NFI_LAUNCH_RENDER_WIDE(TEX, ATT)                                                                             \
   do {                                                                                                                \
