@@ -3,6 +3,7 @@
 #include "nfi_device.hpp"
 #include "../../include/nfi_hip.h"
 
+#include <algorithm>
 #include <cstdio>
 #include <cstring>
 
@@ -289,17 +290,19 @@ extern "C" int nfi_decoder_pack_viewdir(const float* w1, const float* b1, const 
 // ------------------------------------------------------------------------------------------------
 // reduce[0] = ~key(min near | hit) (so that zero-initialised memory + atomicMax works),
 // reduce[1] = key(max far | hit), reduce[2] = hit count.
-__device__ __forceinline__ void block_reduce_planes(bool hit, float near, float far, uint32_t* reduce) {
+// Per-thread accumulators (a thread may have seen several rays): kmin/kmax keys as above, cnt = its hit count.
+// The three atomics per block all go to the same three addresses, and same-address device atomics serialise at
+// ~12 ns on this chip, so the ray kernels run a grid-stride loop over at most kRayBlocks blocks.
+constexpr int kRayBlocks = 256;
+__device__ __forceinline__ void block_reduce_keys(uint32_t kmin, uint32_t kmax, uint32_t cnt, uint32_t* reduce) {
   __shared__ uint32_t s_min[4], s_max[4], s_cnt[4];
-  uint32_t kmin = hit ? ~ordered_key(near) : 0u;  // maximise the complement
-  uint32_t kmax = hit ? ordered_key(far) : 0u;
 #pragma unroll
   for (int d = 32; d >= 1; d >>= 1) {
     uint32_t a = (uint32_t)__shfl_xor((int)kmin, d, 64), b = (uint32_t)__shfl_xor((int)kmax, d, 64);
     kmin = a > kmin ? a : kmin;
     kmax = b > kmax ? b : kmax;
+    cnt += (uint32_t)__shfl_xor((int)cnt, d, 64);
   }
-  uint32_t cnt = (uint32_t)__popcll(__ballot(hit));
   int wave = threadIdx.x >> 6;
   if ((threadIdx.x & 63) == 0) { s_min[wave] = kmin; s_max[wave] = kmax; s_cnt[wave] = cnt; }
   __syncthreads();
@@ -328,10 +331,8 @@ struct RaygenOut {
 __global__ __launch_bounds__(256) void raygen_kernel(CameraParams cam, int n_scenes, RaygenOut out) {
   const int hw = cam.height * cam.width;
   const int64_t n = (int64_t)n_scenes * hw;
-  const int64_t ray = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  bool hit = false;
-  float near = 0.0f, far = 0.0f;
-  if (ray < n) {
+  uint32_t kmin = 0u, kmax = 0u, cnt = 0u;
+  for (int64_t ray = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; ray < n; ray += (int64_t)gridDim.x * blockDim.x) {
     int b = (int)(ray / hw);
     int pix = (int)(ray - (int64_t)b * hw);
     int row = pix / cam.width, col = pix - row * cam.width;
@@ -340,36 +341,48 @@ __global__ __launch_bounds__(256) void raygen_kernel(CameraParams cam, int n_sce
     if (out.ro) { out.ro[ray * 3 + 0] = o[0]; out.ro[ray * 3 + 1] = o[1]; out.ro[ray * 3 + 2] = o[2]; }
     if (out.rd) { out.rd[ray * 3 + 0] = d[0]; out.rd[ray * 3 + 1] = d[1]; out.rd[ray * 3 + 2] = d[2]; }
     if (out.near_raw) {
-      hit = slab_test(o, d, out.scene_range, near, far);
+      float near = 0.0f, far = 0.0f;
+      const bool hit = slab_test(o, d, out.scene_range, near, far);
       // second, inflated test: lets the fused renderer skip rays that provably never enter the cube
       float n2, f2;
       bool hit_wide = slab_test(o, d, out.scene_range * 1.0001f, n2, f2);
       out.near_raw[ray] = near;
       out.far_raw[ray] = far;
       out.hit[ray] = (uint8_t)((hit ? 1 : 0) | (hit_wide ? 2 : 0));
+      if (hit) {
+        const uint32_t a = ~ordered_key(near), c = ordered_key(far);   // maximise the complement of the near key
+        kmin = a > kmin ? a : kmin;
+        kmax = c > kmax ? c : kmax;
+        ++cnt;
+      }
     }
   }
-  if (out.near_raw) block_reduce_planes(hit, near, far, out.reduce);
+  if (out.near_raw) block_reduce_keys(kmin, kmax, cnt, out.reduce);
 }
 
 __global__ __launch_bounds__(256) void slab_kernel(const float* __restrict__ ro, const float* __restrict__ rd, int64_t n,
                                                    float scene_range, float* __restrict__ near_raw,
                                                    float* __restrict__ far_raw, uint8_t* __restrict__ hit_out,
                                                    uint32_t* reduce) {
-  const int64_t ray = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  bool hit = false;
-  float near = 0.0f, far = 0.0f;
-  if (ray < n) {
+  uint32_t kmin = 0u, kmax = 0u, cnt = 0u;
+  for (int64_t ray = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; ray < n; ray += (int64_t)gridDim.x * blockDim.x) {
     float o[3] = {ro[ray * 3], ro[ray * 3 + 1], ro[ray * 3 + 2]};
     float d[3] = {rd[ray * 3], rd[ray * 3 + 1], rd[ray * 3 + 2]};
-    hit = slab_test(o, d, scene_range, near, far);
+    float near = 0.0f, far = 0.0f;
+    const bool hit = slab_test(o, d, scene_range, near, far);
     float n2, f2;
     bool hit_wide = slab_test(o, d, scene_range * 1.0001f, n2, f2);
     near_raw[ray] = near;
     far_raw[ray] = far;
     hit_out[ray] = (uint8_t)((hit ? 1 : 0) | (hit_wide ? 2 : 0));
+    if (hit) {
+      const uint32_t a = ~ordered_key(near), c = ordered_key(far);
+      kmin = a > kmin ? a : kmin;
+      kmax = c > kmax ? c : kmax;
+      ++cnt;
+    }
   }
-  block_reduce_planes(hit, near, far, reduce);
+  block_reduce_keys(kmin, kmax, cnt, reduce);
 }
 
 __global__ __launch_bounds__(256) void finish_planes_kernel(const float* __restrict__ near_raw,
@@ -392,7 +405,7 @@ extern "C" int nfi_raygen(const nfi_raygen_args* a, nfi_stream_t stream) {
   CameraParams cam{a->cam2world, a->focal, a->bbox, a->focal ? a->center : nullptr, a->height, a->width, a->normalize};
   RaygenOut out{a->ray_origins, a->ray_directions, nullptr, nullptr, nullptr, nullptr, 0.0f};
   int64_t n = (int64_t)a->n_scenes * a->height * a->width;
-  hipLaunchKernelGGL(raygen_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, cam,
+  hipLaunchKernelGGL(raygen_kernel, dim3((unsigned)std::min<int64_t>((n + 255) / 256, kRayBlocks)), dim3(256), 0, (hipStream_t)stream, cam,
                      a->n_scenes, out);
   return check_launch("raygen");
 }
@@ -404,7 +417,7 @@ extern "C" int nfi_near_far(const nfi_near_far_args* a, nfi_stream_t stream) {
   hipStream_t s = (hipStream_t)stream;
   if (hipMemsetAsync(a->reduce, 0, 16, s) != hipSuccess) return fail(NFI_ERR_LAUNCH, "near_far: memset failed");
   unsigned blocks = (unsigned)((a->n_rays + 255) / 256);
-  hipLaunchKernelGGL(slab_kernel, dim3(blocks), dim3(256), 0, s, a->ray_origins, a->ray_directions, a->n_rays,
+  hipLaunchKernelGGL(slab_kernel, dim3(std::min<unsigned>(blocks, kRayBlocks)), dim3(256), 0, s, a->ray_origins, a->ray_directions, a->n_rays,
                      a->scene_range, a->near_raw, a->far_raw, a->hit, a->reduce);
   if (a->near_plane && a->far_plane)
     hipLaunchKernelGGL(finish_planes_kernel, dim3(blocks), dim3(256), 0, s, a->near_raw, a->far_raw, a->hit, a->reduce,
@@ -1580,7 +1593,7 @@ extern "C" int nfi_render_fwd(const nfi_render_args* a, nfi_stream_t stream) {
   if (hipMemsetAsync(reduce, 0, 16, s) != hipSuccess) return fail(NFI_ERR_LAUNCH, "render: memset failed");
   CameraParams cam{a->cam2world, a->focal, a->bbox, a->focal ? a->center : nullptr, a->height, a->width, 1};
   RaygenOut rout{ro, rd, near_raw, far_raw, hit, reduce, a->scene_range};
-  hipLaunchKernelGGL(raygen_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, cam, a->n_scenes, rout);
+  hipLaunchKernelGGL(raygen_kernel, dim3((unsigned)std::min<int64_t>((n + 255) / 256, kRayBlocks)), dim3(256), 0, s, cam, a->n_scenes, rout);
 
   const bool any_tap = a->t_coarse || a->sigma_coarse || a->rgb_coarse || a->t_fine || a->sigma_fine || a->rgb_fine ||
                        a->t_sorted || a->weights || a->perm || a->near_plane || a->far_plane;
