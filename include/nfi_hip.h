@@ -337,6 +337,31 @@ size_t nfi_decoder_bwd_image_floats_viewdir(void);  /* workspace floats, view-di
 int nfi_field_query_bwd(const nfi_field_bwd_args* a, nfi_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Distance field + its spatial gradient as one differentiable operator: the regulariser branch of
+ * Generator.forward (models/generator.py:505-585).  The reference gets d(sdf)/d(x) from
+ * torch.autograd.grad(..., create_graph=True) through a double-differentiable grid_sample
+ * (lib/ops.py:58-120); here the gradient is a second OUTPUT, so nfi_sdf_gradient_bwd is that double backward.
+ *   points [B,P,3] (inside the cube: stratified samples, lib/ops.py:20-26), texels fp32 [B,3,R,R,32],
+ *   raw decoder parameters w1 [64,32] b1 [64] w2 [n_out,64] b2 [n_out] (row 0 = distance head)
+ *   fwd: sdf [B,P], gradient [B,P,3] = d sdf / d points
+ *   bwd: upstream g_sdf [B,P] / g_gradient [B,P,3] (either may be NULL) -> g_texels [B,3,R,R,32], g_w1 [64,32],
+ *        g_b1 [64], g_w2 [64] (row 0), g_b2 [1]; all ACCUMULATED into (zero-initialise them).
+ * ------------------------------------------------------------------------------------------ */
+typedef struct nfi_sdf_gradient_args {
+  int n_scenes;
+  int64_t points_per_scene;
+  const float* points;
+  const float* texels; int plane_res;
+  float scene_range;
+  const float* w1; const float* b1; const float* w2; const float* b2;
+  float* sdf; float* gradient;                       /* forward outputs */
+  const float* g_sdf; const float* g_gradient;       /* backward inputs */
+  float* g_texels; float* g_w1; float* g_b1; float* g_w2; float* g_b2;
+} nfi_sdf_gradient_args;
+int nfi_sdf_gradient_fwd(const nfi_sdf_gradient_args* a, nfi_stream_t stream);
+int nfi_sdf_gradient_bwd(const nfi_sdf_gradient_args* a, nfi_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
  * Fused forward render: run.py::render (176-350) from cameras + texels to pixels in one
  * persistent launch (plus the ray set-up launch), no per-sample HBM round trips.
  * ------------------------------------------------------------------------------------------ */

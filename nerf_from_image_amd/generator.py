@@ -153,6 +153,75 @@ def make_sampler(planes, decoder, scene_range, n_attention, attention_values, us
     return sampler
 
 
+def sample_volume_stratified(batch_size, nstrata, scene_range, device=None):
+    """lib/ops.sample_volume_stratified (20-26): one jittered point per cell of an (nstrata-1)^3 grid over the cube;
+    same draw (torch.rand_like of the [B,n,n,n,3] cell indices) as the reference."""
+    bins = torch.arange(nstrata - 1, device=device)
+    bins = torch.stack(torch.meshgrid(bins, bins, bins, indexing='xy'), dim=-1).float().unsqueeze(0).expand(
+        batch_size, -1, -1, -1, -1)
+    bins = (bins + torch.rand_like(bins)) / (nstrata - 1) * 2 - 1
+    return bins.flatten(1, 3) * scene_range
+
+
+def sdf_and_gradient(points, planes, decoder, scene_range):
+    """(sdf [B,P], d sdf / d points [B,P,3]) at fixed points as ONE autograd node (HIP forward + HIP backward): the
+    gradient output replaces torch.autograd.grad(..., create_graph=True) of generator.py:534-540, its backward is the
+    double backward lib/ops.grid_sample2d exists for.  Differentiable w.r.t. planes and the decoder parameters."""
+    w1, b1, w2, b2 = decoder_parameters(decoder)
+    pts = points.detach()
+    texels = ops.planes_to_texels(planes.detach())
+
+    def fwd(pl, a_w1, a_b1, a_w2, a_b2):
+        return ops.sdf_gradient_fwd(pts, texels, a_w1, a_b1, a_w2, a_b2, scene_range)
+
+    def bwd(inputs, outputs, grads, needs):
+        pl, a_w1, a_b1, a_w2, a_b2 = inputs
+        g = ops.sdf_gradient_bwd(pts, texels, a_w1, a_b1, a_w2, a_b2, scene_range, grads[0], grads[1])
+        return (ops.texels_to_planes(g['g_texels']) if needs[0] else None, g['g_w1'], g['g_b1'], g['g_w2'], g['g_b2'])
+    return differentiable('sdf_gradient', fwd, planes, w1, b1, w2, b2, bwd=bwd)
+
+
+def regulariser_outputs(self, planes, request_model_outputs):
+    """generator.py:505-585 on HIP kernels: eikonal / distance / total-variation / entropy terms of the SDF."""
+    out = {}
+    assert torch.is_grad_enabled()
+    bins_in = sample_volume_stratified(planes.shape[0], 32, self.scene_range, device=planes.device)
+    if 'sdf_eikonal_loss' in request_model_outputs:
+        assert self.use_sdf and self.training
+    d, g = sdf_and_gradient(bins_in, planes, self.decoder, self.scene_range)
+    if 'sdf_eikonal_loss' in request_model_outputs:
+        out['sdf_eikonal_loss'] = ((g.norm(dim=-1) - 1) ** 2).flatten(1).mean(dim=1)
+    if 'sdf_distance_loss' in request_model_outputs:
+        assert self.use_sdf
+        with torch.no_grad():
+            target = bins_in.norm(dim=-1) - 1                         # unit sphere
+        out['sdf_distance_loss'] = torch.nn.functional.mse_loss(d.flatten(1), target.flatten(1), reduction='none').mean(dim=1)
+    want_tv = 'total_variation_loss' in request_model_outputs
+    if want_tv or 'entropy_loss' in request_model_outputs:
+        d_p = None
+        if want_tv:
+            coords = (bins_in / self.scene_range).view(planes.shape[0], 1, -1, 3)
+            coords_p = coords + torch.randn_like(coords) * 0.004
+            smp = make_sampler(planes, self.decoder, self.scene_range, self.attention_values,
+                               torch.zeros((planes.shape[0], max(self.attention_values, 1), 3), device=planes.device),
+                               self.use_sdf, self.beta if self.use_sdf else None, self.alpha if self.use_sdf else None)
+            d_p = smp((coords_p * self.scene_range).detach(), ['sdf_distance'])['sdf_distance'][..., 0]
+        if self.use_sdf:
+            beta = self.beta
+            cdf = lambda z: 0.5 + 0.5 * torch.sign(z) * (1 - torch.exp(-z.abs() / beta))      # laplace_cdf, 30-33
+            if want_tv:
+                out['total_variation_loss'] = torch.nn.functional.l1_loss(cdf(-d), cdf(-d_p), reduction='none').flatten(1).mean(dim=1)
+            if 'entropy_loss' in request_model_outputs:
+                out['entropy_loss'] = (0.5 * torch.exp(-d.abs() / beta) / beta).flatten(1).mean(dim=1)      # laplace_pdf, 24-27
+        else:
+            tv = torch.sigmoid(d - 1)
+            if want_tv:
+                out['total_variation_loss'] = torch.nn.functional.l1_loss(tv, torch.sigmoid(d_p - 1), reduction='none').flatten(1).mean(dim=1)
+            if 'entropy_loss' in request_model_outputs:
+                out['entropy_loss'] = (tv * (1 - tv)).flatten(1).mean(dim=1)
+    return out
+
+
 def hip_forward(self, viewdir, c, request_model_outputs=['sampler'], model_inputs={}):
     """Replacement for Generator.forward (models/generator.py:407-686): same arguments, same
     returned dict; the plane producer is called as in the reference, the field is HIP."""
@@ -160,9 +229,6 @@ def hip_forward(self, viewdir, c, request_model_outputs=['sampler'], model_input
         assert output in _MODEL_OUTPUTS
     for k in model_inputs.keys():
         assert k in _MODEL_INPUTS
-    for reg in ('sdf_eikonal_loss', 'sdf_distance_loss', 'total_variation_loss', 'entropy_loss'):
-        if reg in request_model_outputs:
-            raise NotImplementedError('%s (regulariser branch, generator.py:505-585) is outside the HIP hot path' % reg)
 
     # ---- latent handling (generator.py:423-446) ----
     label = None
@@ -218,6 +284,10 @@ def hip_forward(self, viewdir, c, request_model_outputs=['sampler'], model_input
             target = target + (attention_values * torch.randn_like(attention_values)).sum()
         grad, = torch.autograd.grad(target, inputs=ws, create_graph=True)
         model_outputs['path_length'] = grad.square().sum(dim=-1).mean(dim=-1).sqrt()
+
+    if any(r in request_model_outputs for r in ('sdf_eikonal_loss', 'total_variation_loss', 'entropy_loss')):
+        # (as in the reference, 'sdf_distance_loss' is only produced together with one of these three, 505-506 / 542)
+        model_outputs.update(regulariser_outputs(self, planes, request_model_outputs))
 
     if 'sampler' in request_model_outputs:
         vd = None

@@ -381,6 +381,43 @@ def render_fwd(cam2world, focal, height, width, num_samples, texels, decoder_ima
 
 
 # --------------------------------------------------------------------------- #
+# regulariser branch: distance + spatial gradient as one operator
+# --------------------------------------------------------------------------- #
+def sdf_gradient_fwd(points, texels, w1, b1, w2, b2, scene_range):
+    """points [B,P,3] (inside the cube) -> (sdf [B,P], d sdf / d points [B,P,3])."""
+    points = _f32c(points, 'points')
+    if texels.dtype != torch.float32:
+        raise TypeError('sdf_gradient: fp32 texels only')
+    B, P = points.shape[0], points.shape[1]
+    sdf = torch.empty((B, P), dtype=torch.float32, device=points.device)
+    grad = torch.empty((B, P, 3), dtype=torch.float32, device=points.device)
+    with torch.cuda.device(points.device):
+        _lib.call_struct('nfi_sdf_gradient_fwd', 'nfi_sdf_gradient_args', _stream(points), n_scenes=B, points_per_scene=P,
+                         points=points, texels=texels, plane_res=texels.shape[2], scene_range=float(scene_range),
+                         w1=_f32c(w1, 'w1'), b1=_f32c(b1, 'b1'), w2=_f32c(w2, 'w2'), b2=_f32c(b2, 'b2'), sdf=sdf,
+                         gradient=grad)
+    return sdf, grad
+
+
+def sdf_gradient_bwd(points, texels, w1, b1, w2, b2, scene_range, g_sdf, g_gradient):
+    """Backward (= the reference's double backward) of sdf_gradient_fwd.  Returns dict(g_texels, g_w1, g_b1, g_w2
+    [n_out,64] with row 0 filled, g_b2 [n_out] with entry 0 filled)."""
+    points = _f32c(points, 'points')
+    B, P = points.shape[0], points.shape[1]
+    dev = points.device
+    w2, b2 = _f32c(w2, 'w2'), _f32c(b2, 'b2')
+    out = {'g_texels': torch.zeros_like(texels), 'g_w1': torch.zeros((64, 32), dtype=torch.float32, device=dev),
+           'g_b1': torch.zeros((64,), dtype=torch.float32, device=dev), 'g_w2': torch.zeros_like(w2),
+           'g_b2': torch.zeros_like(b2)}
+    with torch.cuda.device(dev):
+        _lib.call_struct('nfi_sdf_gradient_bwd', 'nfi_sdf_gradient_args', _stream(points), n_scenes=B, points_per_scene=P,
+                         points=points, texels=texels, plane_res=texels.shape[2], scene_range=float(scene_range),
+                         w1=_f32c(w1, 'w1'), b1=_f32c(b1, 'b1'), w2=w2, b2=b2, g_sdf=_f32c(g_sdf, 'g_sdf'),
+                         g_gradient=_f32c(g_gradient, 'g_gradient'), **out)
+    return out
+
+
+# --------------------------------------------------------------------------- #
 # backward wrappers
 # --------------------------------------------------------------------------- #
 def composite_bwd(ray_directions, depth_a, sigma_a, rgb_a, g_rgb_map, g_mask=None, depth_b=None, sigma_b=None,

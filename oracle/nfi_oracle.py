@@ -199,6 +199,80 @@ def field_query(planes: torch.Tensor, w1, b1, w2, b2, x_in: torch.Tensor,
     return res
 
 
+# --------------------------------------------------------------------------- #
+# regulariser branch (models/generator.py:505-585, lib/ops.py:20-26, 58-120)
+# --------------------------------------------------------------------------- #
+def _bilinear_double_differentiable(plane: torch.Tensor, gx: torch.Tensor, gy: torch.Tensor) -> torch.Tensor:
+    """plane [B,C,H,W], normalised coordinates gx, gy [B,P] -> [B,C,P]; bilinear, align_corners=True, indices
+    clamped to the image (no coordinate clamp), written with plain tensor ops so that autograd can differentiate
+    it twice - the semantics of lib/ops.grid_sample2d (58-120)."""
+    B, C, H, W = plane.shape
+    ix = ((gx + 1) / 2) * (W - 1)
+    iy = ((gy + 1) / 2) * (H - 1)
+    x0, y0 = torch.floor(ix), torch.floor(iy)
+    x1, y1 = x0 + 1, y0 + 1
+    w_nw, w_ne = (x1 - ix) * (y1 - iy), (ix - x0) * (y1 - iy)
+    w_sw, w_se = (x1 - ix) * (iy - y0), (ix - x0) * (iy - y0)
+    flat = plane.reshape(B, C, H * W)
+
+    def take(xi, yi):
+        idx = yi.long().clamp(0, H - 1) * W + xi.long().clamp(0, W - 1)
+        return torch.gather(flat, 2, idx.unsqueeze(1).expand(-1, C, -1))
+    return (take(x0, y0) * w_nw.unsqueeze(1) + take(x1, y0) * w_ne.unsqueeze(1) +
+            take(x0, y1) * w_sw.unsqueeze(1) + take(x1, y1) * w_se.unsqueeze(1))
+
+
+def sdf_and_gradient(planes, w1, b1, w2, b2, x_in, scene_range, create_graph=True):
+    """Distance output of the decoder and d(distance)/d(x_in) (generator.py:518-540): x_in [B,P,3] -> d [B,P], g [B,P,3].
+    The gradient keeps its graph (create_graph), so losses on it can be differentiated w.r.t. planes and weights."""
+    x = x_in if x_in.requires_grad else x_in.clone().requires_grad_()
+    c = x / scene_range
+    feats = (_bilinear_double_differentiable(planes[:, 0], c[..., 0], c[..., 1]) +
+             _bilinear_double_differentiable(planes[:, 1], c[..., 0], c[..., 2]) +
+             _bilinear_double_differentiable(planes[:, 2], c[..., 1], c[..., 2])) / 3
+    feats = feats.transpose(-2, -1)
+    gw1, gb1, gw2, gb2 = decoder_params(w1, b1, w2, b2)
+    d = F.linear(F.softplus(F.linear(feats, gw1, gb1)), gw2, gb2)[..., 0]
+    g, = torch.autograd.grad(d.sum(), x, create_graph=create_graph)
+    return d, g
+
+
+def stratified_volume(batch, nstrata, scene_range, jitter):
+    """lib/ops.sample_volume_stratified (20-26) with the rand_like draw passed in: jitter [B,n,n,n,3], n = nstrata-1."""
+    bins = torch.arange(nstrata - 1, device=jitter.device)
+    bins = torch.stack(torch.meshgrid(bins, bins, bins, indexing='xy'), dim=-1).float().unsqueeze(0).expand(batch, -1, -1, -1, -1)
+    bins = (bins + jitter) / (nstrata - 1) * 2 - 1
+    return bins.flatten(1, 3) * scene_range
+
+
+def regularisers(planes, w1, b1, w2, b2, bins_in, scene_range, use_sdf=True, beta=None, perturb=None):
+    """generator.py:505-585 given the stratified points bins_in [B,P,3] and (for the TV term) the randn_like draw
+    `perturb` [B,1,P,3] in normalised coordinates.  Returns per-scene losses."""
+    out = {}
+    d, g = sdf_and_gradient(planes, w1, b1, w2, b2, bins_in, scene_range)
+    if use_sdf:
+        out['sdf_eikonal_loss'] = ((g.norm(dim=-1) - 1) ** 2).flatten(1).mean(dim=1)
+        with torch.no_grad():
+            target = bins_in.norm(dim=-1) - 1
+        out['sdf_distance_loss'] = F.mse_loss(d.flatten(1), target.flatten(1), reduction='none').mean(dim=1)
+    d_p = None
+    if perturb is not None:
+        x_p = ((bins_in.detach() / scene_range).view(bins_in.shape[0], 1, -1, 3) + perturb * 0.004) * scene_range
+        d_p = field_query(planes, w1, b1, w2, b2, x_p.view(bins_in.shape[0], -1, 3), scene_range, use_sdf, beta,
+                          torch.ones(1), None)['sdf']
+    if use_sdf:
+        cdf = lambda z: 0.5 + 0.5 * torch.sign(z) * (1 - torch.exp(-z.abs() / beta))
+        if d_p is not None:
+            out['total_variation_loss'] = F.l1_loss(cdf(-d), cdf(-d_p), reduction='none').flatten(1).mean(dim=1)
+        out['entropy_loss'] = (0.5 * torch.exp(-d.abs() / beta) / beta).flatten(1).mean(dim=1)
+    else:
+        tv = torch.sigmoid(d - 1)
+        if d_p is not None:
+            out['total_variation_loss'] = F.l1_loss(tv, torch.sigmoid(d_p - 1), reduction='none').flatten(1).mean(dim=1)
+        out['entropy_loss'] = (tv * (1 - tv)).flatten(1).mean(dim=1)
+    return out
+
+
 def bbox_overlay(x_in: torch.Tensor, sigma: torch.Tensor, outside: torch.Tensor, scene_range: float) -> torch.Tensor:
     """models/generator.py:645-659: the 'bbox' visualisation adds 100 to sigma on the wire frame of the cube.
     x_in [B,...,3], sigma / outside [B,P]."""

@@ -27,7 +27,8 @@ def test_header_declares_the_expected_entry_points():
     for name in ('nfi_render_fwd', 'nfi_field_query_fwd', 'nfi_raygen', 'nfi_near_far', 'nfi_sample_pdf',
                  'nfi_composite_fwd', 'nfi_planes_to_texels', 'nfi_decoder_pack', 'nfi_decoder_pack_viewdir',
                  'nfi_field_query_bwd', 'nfi_field_bwd_workspace_bytes', 'nfi_composite_bwd', 'nfi_points_bwd',
-                 'nfi_raygen_bwd', 'nfi_bbox_overlay', 'nfi_resample', 'nfi_ray_weights'):
+                 'nfi_raygen_bwd', 'nfi_bbox_overlay', 'nfi_resample', 'nfi_ray_weights', 'nfi_sdf_gradient_fwd',
+                 'nfi_sdf_gradient_bwd'):
         assert name in declared
 
 

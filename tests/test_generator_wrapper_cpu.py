@@ -124,3 +124,47 @@ def test_oracle_bbox_overlay_matches_reference():
     assert torch.equal(ref['coords'], x)
     assert torch.equal(mine, ref['sigma'])
     assert (mine != plain).float().mean() > 0.01
+
+
+def test_oracle_regularisers_match_reference():
+    """The regulariser branch (generator.py:505-585: eikonal with its double backward, distance, total variation,
+    entropy) restated in the oracle against the live Generator: losses AND their gradients w.r.t. the decoder."""
+    sys.path.insert(0, REF)
+    try:
+        from models import generator as ref_gen
+    finally:
+        sys.path.remove(REF)
+    from oracle import nfi_oracle as orc
+    torch.manual_seed(5)
+    model = ref_gen.Generator(512, 0.55, attention_values=10, use_sdf=True, disable_stylegan_noise=True).train()
+    z = torch.randn(2, 512)
+    cap, draws = {}, {}
+    hook = model.synthesis_network.register_forward_hook(lambda m, i, o: cap.__setitem__('planes', o))
+    real_rand_like, real_randn_like = torch.rand_like, torch.randn_like
+
+    def rand_like(t, **k):
+        draws['jitter'] = real_rand_like(t, **k)
+        return draws['jitter']
+
+    def randn_like(t, **k):
+        draws['perturb'] = real_randn_like(t, **k)
+        return draws['perturb']
+    torch.rand_like, torch.randn_like = rand_like, randn_like
+    try:
+        ref = model(None, z, ['sdf_eikonal_loss', 'sdf_distance_loss', 'total_variation_loss', 'entropy_loss'])
+    finally:
+        torch.rand_like, torch.randn_like = real_rand_like, real_randn_like
+        hook.remove()
+    names = ['sdf_eikonal_loss', 'sdf_distance_loss', 'total_variation_loss', 'entropy_loss']
+    dec = model.decoder.net
+    params = [dec[0].weight, dec[0].bias, dec[2].weight, dec[2].bias]
+    ref_g = torch.autograd.grad(sum(ref[n].sum() for n in names), params, retain_graph=True)
+
+    planes = cap['planes'].detach().view(2, 3, 32, 256, 256)
+    bins = orc.stratified_volume(2, 32, 0.55, draws['jitter'])
+    mine = orc.regularisers(planes, *params, bins, 0.55, True, model.beta, draws['perturb'])
+    for n in names:
+        assert torch.allclose(mine[n], ref[n], rtol=1e-5, atol=1e-7), (n, mine[n], ref[n])
+    my_g = torch.autograd.grad(sum(mine[n].sum() for n in names), params)
+    for a, b in zip(my_g, ref_g):
+        assert torch.allclose(a, b, rtol=1e-4, atol=1e-7 * float(b.abs().max() + 1)), (a - b).abs().max()

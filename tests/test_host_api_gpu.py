@@ -308,3 +308,55 @@ def test_bbox_overlay(setup):
     assert torch.equal(res['coords'], x)
     assert torch.equal(res['sigma'].cpu(), ref)
     assert (ref != plain.cpu()).float().mean() > 0.01
+
+
+def test_regulariser_outputs(gpu_device):
+    """Generator.forward's regulariser branch (generator.py:505-585) on the HIP path of a bare container: eikonal
+    (d sdf/dx as an operator output, its backward = the reference's double backward), distance, total variation and
+    entropy terms, and their gradients w.r.t. the plane producer and the decoder, against float64 autograd of the
+    oracle with the same two random draws."""
+    import copy
+    torch.manual_seed(3)
+    model = StandInGenerator(0.55, attention_values=10, use_sdf=True, plane_res=32).to(gpu_device).train()
+    nfi_gen.attach(model)
+    g = torch.Generator().manual_seed(5)
+    z = torch.randn(2, 512, generator=g).to(gpu_device)
+    names = ['sdf_eikonal_loss', 'sdf_distance_loss', 'total_variation_loss', 'entropy_loss']
+    draws = {}
+    real_rand_like, real_randn_like = torch.rand_like, torch.randn_like
+
+    def rand_like(t, **k):
+        # plane_res 32 and 31 strata: the texel coordinate of a point is (cell index + jitter), so keeping the jitter
+        # off 0 and 1 keeps every point off the texel boundaries, where d sdf/dx jumps and an fp32 kernel and a
+        # float64 oracle may legitimately pick different cells
+        draws['jitter'] = real_rand_like(t, **k).clamp_(1e-3, 1 - 1e-3)
+        return draws['jitter']
+
+    def randn_like(t, **k):
+        draws['perturb'] = real_randn_like(t, **k)
+        return draws['perturb']
+    torch.rand_like, torch.randn_like = rand_like, randn_like
+    try:
+        out = model(None, z, names)
+    finally:
+        torch.rand_like, torch.randn_like = real_rand_like, real_randn_like
+    assert set(out) == set(names)
+    dec = model.decoder.net
+    params = [model.synthesis_network.basis, model.synthesis_network.proj.weight, dec[0].weight, dec[0].bias,
+              dec[2].weight, dec[2].bias, model.beta]
+    weights = [1.0, 0.7, 3.0, 0.01]
+    got = torch.autograd.grad(sum(w * out[n].sum() for w, n in zip(weights, names)), params)
+
+    m64 = copy.deepcopy(model).cpu().double()
+    planes64, _ = m64.planes_and_values(z.cpu().double())
+    d64 = m64.decoder.net
+    p64 = [m64.synthesis_network.basis, m64.synthesis_network.proj.weight, d64[0].weight, d64[0].bias, d64[2].weight,
+           d64[2].bias, m64.beta]
+    bins = orc.stratified_volume(2, 32, 0.55, draws['jitter'].cpu().double())
+    ref = orc.regularisers(planes64, *p64[2:6], bins, 0.55, True, m64.beta, draws['perturb'].cpu().double())
+    for n in names:
+        close(out[n], ref[n], 2e-4 * float(ref[n].detach().abs().max()) + 1e-6, n)
+    ref_g = torch.autograd.grad(sum(w * ref[n].sum() for w, n in zip(weights, names)), p64)
+    for name, a, b in zip(['basis', 'proj', 'w1', 'b1', 'w2', 'b2', 'beta'], got, ref_g):
+        scale = b.abs().max().item()
+        assert (a.cpu().double() - b).abs().max().item() <= 2e-3 * scale + 1e-9, (name, (a.cpu().double() - b).abs().max().item(), scale)
