@@ -328,6 +328,13 @@ def wrapped_forward(self, viewdir, c, request_model_outputs=['sampler'], model_i
     returned ``sampler`` closure is replaced by the HIP one.  The plane producer therefore runs once."""
     want_sampler = 'sampler' in request_model_outputs
     req = list(request_model_outputs)
+    # opt-in (attach(..., hip_regularisers=True)): the regulariser branch on the HIP kernels as well; the names are
+    # then withheld from the original forward (which still runs the plane producer) and filled in afterwards
+    reg_all = ('sdf_eikonal_loss', 'sdf_distance_loss', 'total_variation_loss', 'entropy_loss')
+    hip_reg = getattr(self, 'nfi_hip_regularisers', False) and any(
+        r in req for r in ('sdf_eikonal_loss', 'total_variation_loss', 'entropy_loss'))
+    if hip_reg:
+        req = [r for r in req if r not in reg_all]
     added_att = False
     if want_sampler and self.attention_values > 0 and 'attention_values' not in req:
         req.append('attention_values')           # the original forward returns the (possibly overridden) table
@@ -343,9 +350,12 @@ def wrapped_forward(self, viewdir, c, request_model_outputs=['sampler'], model_i
             model_outputs = self._nfi_original_forward(viewdir, c, req, model_inputs)
     finally:
         hook.remove()
-    if want_sampler:
-        planes = captured['planes']
+    planes = captured.get('planes')
+    if planes is not None:
         planes = planes.view(planes.shape[0], 3, 32, planes.shape[-2], planes.shape[-1])
+    if hip_reg:
+        model_outputs.update(regulariser_outputs(self, planes, request_model_outputs))
+    if want_sampler:
         att = model_outputs.get('attention_values') if self.attention_values > 0 else None
         model_outputs['sampler'] = make_sampler(
             planes, self.decoder, self.scene_range, self.attention_values, att, self.use_sdf,
@@ -357,8 +367,11 @@ def wrapped_forward(self, viewdir, c, request_model_outputs=['sampler'], model_i
     return model_outputs
 
 
-def attach(model, texel_dtype=ops.TEXEL_F32):
+def attach(model, texel_dtype=ops.TEXEL_F32, hip_regularisers=False):
     """Gives a reference-style Generator the HIP sampler.  Returns the same module.
+
+    hip_regularisers: also serve sdf_eikonal / sdf_distance / total_variation / entropy losses of a module that has
+    its own forward from the HIP kernels (bare containers always do).
 
     A module whose class implements ``forward`` itself (the reference ``Generator``) keeps that
     forward for the non-hot-path outputs and only gets its sampler swapped (``wrapped_forward``);
@@ -367,6 +380,7 @@ def attach(model, texel_dtype=ops.TEXEL_F32):
     if missing:
         raise AttributeError('attach(): module lacks %s' % missing)
     model.nfi_texel_dtype = texel_dtype
+    model.nfi_hip_regularisers = bool(hip_regularisers)
     if type(model).forward is not torch.nn.Module.forward and not hasattr(model, '_nfi_original_forward'):
         model._nfi_original_forward = model.forward          # bound method of the reference class
         model.forward = types.MethodType(wrapped_forward, model)

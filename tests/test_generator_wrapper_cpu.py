@@ -168,3 +168,31 @@ def test_oracle_regularisers_match_reference():
     my_g = torch.autograd.grad(sum(mine[n].sum() for n in names), params)
     for a, b in zip(my_g, ref_g):
         assert torch.allclose(a, b, rtol=1e-4, atol=1e-7 * float(b.abs().max() + 1)), (a - b).abs().max()
+
+
+def test_wrapped_forward_can_hand_the_regularisers_to_hip(monkeypatch):
+    """attach(..., hip_regularisers=True): the four regulariser names are withheld from the reference forward (which
+    still produces the planes) and served by generator.regulariser_outputs on the captured planes."""
+    sys.path.insert(0, REF)
+    try:
+        from models import generator as ref_gen
+    finally:
+        sys.path.remove(REF)
+    import nerf_from_image_amd.generator as nfi_gen
+    torch.manual_seed(0)
+    model = ref_gen.Generator(512, 0.55, attention_values=10, use_sdf=True, disable_stylegan_noise=True).train()
+    seen = {}
+
+    def fake_regularisers(self, planes, request):
+        seen.update(planes=planes, request=list(request))
+        return {r: torch.zeros(planes.shape[0]) for r in request if r.endswith('_loss')}
+    monkeypatch.setattr(nfi_gen, 'regulariser_outputs', fake_regularisers)
+    nfi_gen.attach(model, hip_regularisers=True)
+    inner = {}
+    orig = model._nfi_original_forward
+    model._nfi_original_forward = lambda v, c, req, mi: (inner.__setitem__('req', list(req)) or orig(v, c, req, mi))
+    monkeypatch.setattr(nfi_gen, 'make_sampler', lambda *a, **k: (lambda x, req=['sigma', 'rgb']: {}))
+    out = model(None, torch.randn(2, 512), ['sampler', 'sdf_distance_loss', 'sdf_eikonal_loss', 'path_length'])
+    assert inner['req'] == ['sampler', 'path_length', 'attention_values']
+    assert set(out) == {'sampler', 'sdf_distance_loss', 'sdf_eikonal_loss', 'path_length'}
+    assert seen['planes'].shape == (2, 3, 32, 256, 256) and seen['planes'].requires_grad
