@@ -360,3 +360,37 @@ def test_regulariser_outputs(gpu_device):
     for name, a, b in zip(['basis', 'proj', 'w1', 'b1', 'w2', 'b2', 'beta'], got, ref_g):
         scale = b.abs().max().item()
         assert (a.cpu().double() - b).abs().max().item() <= 2e-3 * scale + 1e-9, (name, (a.cpu().double() - b).abs().max().item(), scale)
+
+
+def test_wrapped_module_with_hip_regularisers(gpu_device):
+    """A module that has its own forward (like the reference Generator) attached with hip_regularisers=True gives the
+    same regulariser losses as the bare-container path (same parameters, same random draws)."""
+    class WithForward(StandInGenerator):
+        def forward(self, viewdir, c, request_model_outputs=['sampler'], model_inputs={}):
+            ws = self.mapping_network(c)
+            self.synthesis_network(ws[:, :14])
+            out = {}
+            if 'attention_values' in request_model_outputs:
+                out['attention_values'] = self.texture_mapper(ws[:, 14])
+            if 'sampler' in request_model_outputs:
+                out['sampler'] = None
+            return out
+    torch.manual_seed(11)
+    wrapped = WithForward(0.55, attention_values=10, use_sdf=True, plane_res=32).to(gpu_device).train()
+    torch.manual_seed(11)
+    bare = StandInGenerator(0.55, attention_values=10, use_sdf=True, plane_res=32).to(gpu_device).train()
+    bare.load_state_dict(wrapped.state_dict())
+    nfi_gen.attach(wrapped, hip_regularisers=True)
+    nfi_gen.attach(bare)
+    z = torch.randn(2, 512, device=gpu_device)
+    names = ['sdf_eikonal_loss', 'sdf_distance_loss', 'entropy_loss']
+    torch.manual_seed(99)
+    a = wrapped(None, z, names)
+    torch.manual_seed(99)
+    b = bare(None, z, names)
+    assert set(a) == set(names)
+    for n in names:
+        assert torch.equal(a[n], b[n]), n
+    ga = torch.autograd.grad(sum(a[n].sum() for n in names), wrapped.decoder.net[0].weight)[0]
+    gb = torch.autograd.grad(sum(b[n].sum() for n in names), bare.decoder.net[0].weight)[0]
+    close(ga, gb, 1e-5 * float(gb.abs().max()) + 1e-9, 'w1 gradient')
