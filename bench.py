@@ -285,8 +285,9 @@ def main():
             'roofline': {'bound': 'hbm', 'kernel': 'render_fwd_kernel', 'achieved': ach_gbs, 'peak': HBM_PEAK_GBS,
                          'unit': 'GB/s', 'frac': ach_gbs / HBM_PEAK_GBS, 'traffic': traffic,
                          'kernel_ms': kernel_ms, 'rays_marched_per_launch': marched,
-                         'note': 'algorithmic gather stream (196608 B per marched ray); it is served mostly by '
-                                 'L2/Infinity Cache, so frac > 1 is possible - see DESIGN.md'},
+                         'note': 'algorithmic gather stream (196608 B per marched ray) over the HBM peak; the stream is served '
+                                 'mostly by L2/Infinity Cache (`traffic` = measured fabric bytes per launch), so frac > 1: '
+                                 'the kernel is instruction-issue bound (79 % of the issue slots, DESIGN.md 4.3)'},
             'roofline_mfma': {'bound': 'mfma', 'achieved': marched * MLP_FLOP_PER_RAY / (kernel_ms * 1e-3) / 1e12,
                               'peak': MFMA_F32_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                               'frac': marched * MLP_FLOP_PER_RAY / (kernel_ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS},
