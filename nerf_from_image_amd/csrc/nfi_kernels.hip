@@ -815,15 +815,29 @@ __device__ __forceinline__ void merge_pair_scatter(WaveSlab& slab, const MergeIn
   wave_lds_fence();
   const uint4* kv = reinterpret_cast<const uint4*>(slab.key);
   const int n4 = (S + 3) >> 2;
-  int cnt_a = 0, cnt_b = 0, cnt_c = 0;
+  int cnt_a = 0, cnt_b = 0, cnt_c = 0, cnt_e = 0;
   for (int i = 0; i < n4; ++i) {
     const uint4 q = kv[i];
     const uint32_t qq[4] = {q.x, q.y, q.z, q.w};
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      const int idx = 4 * i + e;
       cnt_a += (qq[e] < kc) ? 1 : 0;
-      cnt_b += ((qq[e] < kf) || (qq[e] == kf && idx < lane)) ? 1 : 0;
+      cnt_b += (qq[e] < kf) ? 1 : 0;
+      cnt_e += (qq[e] == kf) ? 1 : 0;
+    }
+  }
+  // fine depths are almost never equal (then cnt_e == 1: the key itself); only if some are, redo the count with the
+  // stable tie-break of torch.sort (earlier index first)
+  if (!__all(!valid || cnt_e == 1)) {
+    cnt_b = 0;
+    for (int i = 0; i < n4; ++i) {
+      const uint4 q = kv[i];
+      const uint32_t qq[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int idx = 4 * i + e;
+        cnt_b += ((qq[e] < kf) || (qq[e] == kf && idx < lane)) ? 1 : 0;
+      }
     }
   }
   if (ascending) {
