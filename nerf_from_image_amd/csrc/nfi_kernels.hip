@@ -873,6 +873,86 @@ __device__ __forceinline__ void merge_pair_scatter(WaveSlab& slab, const MergeIn
   wave_lds_fence();
 }
 
+// The same for two elements per lane and list (64 < S <= 128, element e = slot*64 + lane).  Returns false - nothing
+// written - when the coarse depths are not ascending; the caller then uses the general merge_scatter.
+template <class Slab>
+__device__ __forceinline__ bool merge_pair_scatter_wide(Slab& slab, const float (&dep)[4], const float (&sig)[4],
+                                                        const float (&cr)[4], const float (&cg)[4], const float (&cb)[4],
+                                                        int S, int lane, int (&rank)[4]) {
+  // dep[0..1] coarse slots, dep[2..3] fine slots
+  uint32_t kc[2], kf[2];
+  bool val[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    val[j] = j * 64 + lane < S;
+    kc[j] = val[j] ? ordered_key(dep[j]) : 0xFFFFFFFFu;
+    kf[j] = val[j] ? ordered_key(dep[2 + j]) : 0xFFFFFFFFu;
+  }
+  // ascending check of the coarse list across the two slots
+  const uint32_t first1 = (uint32_t)__builtin_amdgcn_readlane((int)kc[1], 0);
+  const uint32_t n0 = f2bits(lane_next(bits2f(kc[0]), bits2f(first1)));
+  const uint32_t n1 = f2bits(lane_next(bits2f(kc[1]), bits2f(0xFFFFFFFFu)));
+  const bool ok0 = (lane >= S - 1) || kc[0] <= n0, ok1 = (64 + lane >= S - 1) || kc[1] <= n1;
+  if (!__all(ok0 && ok1)) return false;
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    slab.key[j * 64 + lane] = kf[j];           // fine keys   [0,128)
+    slab.key[128 + j * 64 + lane] = kc[j];     // coarse keys [128,256)
+  }
+  wave_lds_fence();
+  const uint4* kv = reinterpret_cast<const uint4*>(slab.key);
+  const int n4 = (S + 3) >> 2;
+  int cnt_a[2] = {0, 0}, cnt_b[2] = {0, 0}, cnt_e[2] = {0, 0};
+  for (int i = 0; i < n4; ++i) {
+    const uint4 q = kv[i];
+    const uint32_t qq[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        cnt_a[j] += (qq[e] < kc[j]) ? 1 : 0;
+        cnt_b[j] += (qq[e] < kf[j]) ? 1 : 0;
+        cnt_e[j] += (qq[e] == kf[j]) ? 1 : 0;
+      }
+  }
+  if (!__all((!val[0] || cnt_e[0] == 1) && (!val[1] || cnt_e[1] == 1))) {
+    cnt_b[0] = cnt_b[1] = 0;            // equal fine depths exist: stable tie-break (earlier index first)
+    for (int i = 0; i < n4; ++i) {
+      const uint4 q = kv[i];
+      const uint32_t qq[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const int idx = 4 * i + e;
+          cnt_b[j] += ((qq[e] < kf[j]) || (qq[e] == kf[j] && idx < j * 64 + lane)) ? 1 : 0;
+        }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    int pos = 0;                        // #{coarse <= z}: upper bound over the ascending coarse keys
+#pragma unroll
+    for (int step = 128; step >= 1; step >>= 1) {
+      const int idx = pos + step;
+      if (idx <= S && slab.key[128 + idx - 1] <= kf[j]) pos = idx;
+    }
+    rank[j] = j * 64 + lane + cnt_a[j];
+    rank[2 + j] = pos + cnt_b[j];
+  }
+  wave_lds_fence();
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    if (val[j]) {
+      const int rc = rank[j], rf = rank[2 + j];
+      slab.srt[0][rc] = dep[j]; slab.srt[1][rc] = sig[j]; slab.srt[2][rc] = cr[j]; slab.srt[3][rc] = cg[j]; slab.srt[4][rc] = cb[j];
+      slab.srt[0][rf] = dep[2 + j]; slab.srt[1][rf] = sig[2 + j]; slab.srt[2][rf] = cr[2 + j]; slab.srt[3][rf] = cg[2 + j]; slab.srt[4][rf] = cb[2 + j];
+    }
+  }
+  wave_lds_fence();
+  return true;
+}
+
 struct CompositeOut { float r, g, b, depth, mask; };
 
 // composite the n samples sitting in merged order in the slab (lib/nerf_utils.py:123-161)
@@ -1528,7 +1608,8 @@ __global__ __launch_bounds__(256, 2) void render_fwd_wide_kernel(RenderKernelPar
         }
         n = 2 * S;
         wave_lds_fence();
-        merge_scatter<4>(slab, dep, sig, cr, cg, cb, eidx, n, rank);
+        if (!merge_pair_scatter_wide(slab, dep, sig, cr, cg, cb, S, lane, rank))
+          merge_scatter<4>(slab, dep, sig, cr, cg, cb, eidx, n, rank);
       } else {
         wave_lds_fence();
 #pragma unroll
