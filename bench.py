@@ -176,6 +176,18 @@ def extras(dev, ops, d):
                       'stand-in plane producer; reference path = oracle ops under PyTorch-ROCm autograd; median step'}
     except Exception as e:      # reported, never fatal for the headline line
         ex['inversion_synthetic'] = {'error': repr(e)}
+    # BASELINE config 4 stand-in: one generator-side training step in cub geometry (ortho camera, scene_range 2.0,
+    # image + alpha loss, eikonal + distance regularisers), HIP path vs the oracle's op sequence under autograd
+    try:
+        import train_step_synthetic
+        ts = train_step_synthetic.run(dev, batch=4, res=128, samples=64, steps=6, verbose=False)
+        ex['train_step_synthetic'] = {
+            'ms_per_step_hip': ts['hip']['ms_per_step'], 'ms_per_step_reference_path': ts['reference_path']['ms_per_step'],
+            'loss_hip': ts['hip']['loss'], 'loss_reference_path': ts['reference_path']['loss'],
+            'sample': '4 images 128x128 ortho, 64+64 samples, render fwd + regulariser branch + bwd into plane producer, '
+                      'decoder, beta, alpha; stand-in plane producer; median of 6 steps; different noise draws per path'}
+    except Exception as e:
+        ex['train_step_synthetic'] = {'error': repr(e)}
     ex['pytorch_rocm_reference_path'] = {'value': 2 * R * R / min(times[1:]), 'unit': 'rays/s',
                                          'sample': 'oracle (reference ATen op sequence) on this GPU, 2 images, '
                                                    'render only, fp32, best of 2 after warm-up'}
