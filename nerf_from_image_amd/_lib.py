@@ -39,7 +39,7 @@ def parse_header(path=HEADER):
             base, rest = dm.group(2), dm.group(3)
             for item in rest.split(','):
                 item = item.strip()
-                ptr = item.count('*') + (1 if False else 0)
+                ptr = item.count('*')
                 name = item.replace('*', '').strip()
                 if ptr or base == 'void':
                     fields.append((name, ctypes.c_void_p))

@@ -4,8 +4,24 @@ Every host-level op goes through :func:`differentiable`: the forward runs the HI
 any input requires grad, the call is recorded as ONE autograd node whose backward is the ``bwd``
 closure handed in by the op (it launches the HIP backward kernels).  An op without a backward
 fails loudly when a gradient is actually requested; nothing ever falls back to ATen.
+
+Lifetime: the node keeps its INPUTS through ``save_for_backward`` and, of its outputs, only their
+shape/dtype/device (:class:`OutputMeta`).  Keeping an output tensor on ``ctx`` would close the
+cycle output -> grad_fn -> ctx -> output, which the reference-counting of autograd never frees:
+every step would leak its per-sample tensors.
 """
 import torch
+
+
+class OutputMeta:
+    """What a backward closure may know about a forward output without keeping it alive."""
+    __slots__ = ('shape', 'dtype', 'device')
+
+    def __init__(self, t):
+        self.shape, self.dtype, self.device = tuple(t.shape), t.dtype, t.device
+
+    def zeros(self):
+        return torch.zeros(self.shape, dtype=self.dtype, device=self.device)
 
 
 class _HipNode(torch.autograd.Function):
@@ -16,8 +32,8 @@ class _HipNode(torch.autograd.Function):
         with torch.no_grad():
             out = fn(*tensors)
         outs = (out,) if not isinstance(out, tuple) else out
-        ctx.inputs = tensors
-        ctx.outputs = outs
+        ctx.save_for_backward(*tensors)
+        ctx.out_meta = tuple(None if o is None else OutputMeta(o) for o in outs)
         nd = [outs[i] for i in nondiff if i < len(outs) and outs[i] is not None]
         nd += [o for o in outs if o is not None and not o.dtype.is_floating_point]
         if nd:
@@ -31,7 +47,7 @@ class _HipNode(torch.autograd.Function):
                 'nerf_from_image_amd: %s has no HIP backward (forward-only op); wrap the call in '
                 'torch.no_grad() or detach its inputs' % ctx.name)
         with torch.no_grad():
-            gin = ctx.bwd(ctx.inputs, ctx.outputs, grads, ctx.needs_input_grad[4:])
+            gin = ctx.bwd(ctx.saved_tensors, ctx.out_meta, grads, ctx.needs_input_grad[4:])
         gin = tuple(g if need else None for g, need in zip(gin, ctx.needs_input_grad[4:]))
         return (None, None, None, None) + gin
 
@@ -39,7 +55,8 @@ class _HipNode(torch.autograd.Function):
 def differentiable(name, fn, *tensors, bwd=None, non_differentiable_outputs=()):
     """Runs fn(*tensors) (HIP kernels).  Records an autograd node only when a gradient can be asked for.
 
-    bwd(inputs, outputs, grad_outputs, needs) -> tuple of gradients, one per input (None allowed)."""
+    bwd(inputs, output_meta, grad_outputs, needs) -> tuple of gradients, one per input (None allowed);
+    output_meta[i] is an :class:`OutputMeta` (shape / dtype / device of output i), never the tensor."""
     needs = torch.is_grad_enabled() and any(t is not None and torch.is_tensor(t) and t.requires_grad for t in tensors)
     if not needs:
         with torch.no_grad():
@@ -48,5 +65,7 @@ def differentiable(name, fn, *tensors, bwd=None, non_differentiable_outputs=()):
 
 
 def zeros_like_or(g, ref):
-    """Autograd hands None for outputs nobody used; kernels want dense tensors."""
-    return torch.zeros_like(ref) if g is None else g.contiguous()
+    """Autograd hands None for outputs nobody used; kernels want dense tensors.  ref: tensor or OutputMeta."""
+    if g is None:
+        return ref.zeros() if isinstance(ref, OutputMeta) else torch.zeros_like(ref)
+    return g.contiguous()

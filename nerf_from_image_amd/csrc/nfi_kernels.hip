@@ -574,7 +574,7 @@ extern "C" int nfi_field_query_fwd(const nfi_field_args* a, nfi_stream_t stream)
                                a->attention_values, a->use_sdf, a->beta, a->alpha);
   if (rc) return rc;
   REQUIRE(!a->semantics || a->n_attention > 0, "field_query: semantics need attention_values > 0");
-  // unskipped tiles of invalid lanes may write semantics rows past P in the last chunk: forbid unless P%64==0
+  // (semantics rows are stored per valid point only: field_wave guards them with the lane's valid flag)
   FieldKernelParams k{a->points, a->points_per_scene, a->texels, a->plane_res, a->texel_dtype, a->decoder_image,
                       a->n_attention, a->attention_values, a->use_sdf, a->beta, a->alpha, a->scene_range,
                       a->sigma, a->rgb, a->sdf, a->semantics, a->outside, a->ray_features, a->samples_per_ray};

@@ -2,6 +2,7 @@
 import torch
 
 from . import _lib, ops
+from .autograd import zeros_like_or
 
 
 BINNED_SCATTER_MIN_POINTS = 1 << 16
@@ -80,8 +81,8 @@ def make_field_bwd(texels, decoder_image, scene_range, n_attention, use_sdf, wan
         vd = None
         if viewdir_pad is not None:
             vd = dict(ray_features=viewdir_pad, samples_per_ray=samples_per_ray, w3=inputs[10])
-        g_sigma = torch.zeros_like(outputs[0]) if grads[0] is None else grads[0]
-        g_rgb = torch.zeros_like(outputs[1]) if grads[1] is None else grads[1]
+        g_sigma = zeros_like_or(grads[0], outputs[0])
+        g_rgb = zeros_like_or(grads[1], outputs[1])
         i = 2
         g_sdf = g_sem = None
         if want_sdf:

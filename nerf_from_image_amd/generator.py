@@ -65,6 +65,18 @@ def decoder_parameters(decoder):
     return l0.weight, l0.bias, l2.weight, l2.bias
 
 
+class _distance_head:
+    """Decoder view exposing only output row 0 (the distance): net[2] becomes a 4-row layer whose rows 1..3 are zero
+    (the kernels' A == 0 shape).  Built with differentiable tensor ops, so gradients reach decoder.net[2].weight[0]."""
+
+    def __init__(self, decoder):
+        l0, l2 = decoder.net[0], decoder.net[2]
+        w = torch.cat([l2.weight[:1], torch.zeros_like(l2.weight[:3])], dim=0)
+        b = torch.cat([l2.bias[:1], torch.zeros_like(l2.bias[:3])], dim=0)
+        self.net = (l0, None, types.SimpleNamespace(weight=w, bias=b))
+        self.training = getattr(decoder, 'training', False)
+
+
 def make_sampler(planes, decoder, scene_range, n_attention, attention_values, use_sdf, beta, alpha,
                  texel_dtype=ops.TEXEL_F32, request_model_outputs=(), viewdir=None):
     """Builds the ``sampler(x_in, request_sampler_outputs)`` closure over HIP kernels.
@@ -202,8 +214,12 @@ def regulariser_outputs(self, planes, request_model_outputs):
         if want_tv:
             coords = (bins_in / self.scene_range).view(planes.shape[0], 1, -1, 3)
             coords_p = coords + torch.randn_like(coords) * 0.004
-            smp = make_sampler(planes, self.decoder, self.scene_range, self.attention_values,
-                               torch.zeros((planes.shape[0], max(self.attention_values, 1), 3), device=planes.device),
+            # the reference evaluates self.decoder only and keeps channel 0 (generator.py:559-566): no view-direction
+            # closure is involved, so a --use_viewdir decoder (33 outputs) is queried through its distance row alone
+            dec = _distance_head(self.decoder) if self.use_viewdir else self.decoder
+            n_att = 0 if self.use_viewdir else self.attention_values
+            smp = make_sampler(planes, dec, self.scene_range, n_att,
+                               torch.zeros((planes.shape[0], max(n_att, 1), 3), device=planes.device),
                                self.use_sdf, self.beta if self.use_sdf else None, self.alpha if self.use_sdf else None)
             d_p = smp((coords_p * self.scene_range).detach(), ['sdf_distance'])['sdf_distance'][..., 0]
         if self.use_sdf:

@@ -22,6 +22,11 @@ import torch
 from . import ops
 from .autograd import differentiable, zeros_like_or
 
+# True (default, the reference's behaviour): compute_near_far_planes raises when no ray of the batch meets the scene
+# cube - the reference fails on min() of an empty selection (lib/nerf_utils.py:258).  The check reads one counter back
+# from the device, i.e. one host synchronisation per call; a training loop that cannot see such a batch may clear it.
+STRICT_NEAR_FAR = True
+
 
 def cumprod_exclusive(tensor: torch.Tensor) -> torch.Tensor:
     """tf.math.cumprod(..., exclusive=True) along the last dim.  Kept for API completeness only:
@@ -64,7 +69,7 @@ def get_ray_bundle_normalized(height: int, width: int, focal_length: Optional[to
 def compute_near_far_planes(ray_origins: torch.Tensor, ray_directions: torch.Tensor, scene_range: float):
     """Slab test against [-scene_range, scene_range]^3 with the reference's miss-fill, clamps and
     its failure when no ray hits.  No gradient (the reference detaches its inputs)."""
-    near, far, _ = ops.near_far(ray_origins.detach(), ray_directions.detach(), scene_range, strict=True)
+    near, far, _ = ops.near_far(ray_origins.detach(), ray_directions.detach(), scene_range, strict=STRICT_NEAR_FAR)
     return near, far
 
 
@@ -78,12 +83,16 @@ def _points_bwd(depth):
 
 
 def compute_query_points_from_rays(ray_origins: torch.Tensor, ray_directions: torch.Tensor, near_thresh: torch.Tensor,
-                                   far_thresh: torch.Tensor, num_samples: int, randomize: bool = True):
-    """Returns (query_points [...,S,3], depth_values [...,S])."""
+                                   far_thresh: torch.Tensor, num_samples: int, randomize: bool = True,
+                                   noise: Optional[torch.Tensor] = None):
+    """Returns (query_points [...,S,3], depth_values [...,S]).  noise (extension): the [...,S] jitter already drawn
+    by the caller (render draws it before the model call to keep the reference's RNG order)."""
     if near_thresh.dim() != ray_origins.dim() - 1:
         raise NotImplementedError('per-batch scalar near/far planes are not used by run.py::render and not supported')
-    noise = torch.rand((*near_thresh.shape, num_samples), dtype=torch.float32, device=near_thresh.device) \
-        if randomize else None
+    if randomize and noise is None:
+        noise = torch.rand((*near_thresh.shape, num_samples), dtype=torch.float32, device=near_thresh.device)
+    if not randomize:
+        noise = None
     # depth first (no gradient), then the points as a differentiable function of the rays
     _, depth = ops.stratified_points(ray_origins.detach(), ray_directions.detach(), near_thresh.detach(),
                                      far_thresh.detach(), num_samples, noise, want_points=False)
@@ -124,6 +133,10 @@ def _composite(name, ray_directions, depth_a, sigma_a, rgb_a, depth_b, sigma_b, 
                extra_a, extra_b, white_background):
     """Shared body of render_volume_density (one list) and merge_and_composite (two lists)."""
     two = depth_b is not None
+    if torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in (normals_a, normals_b)):
+        # the reference composites normals with weights.detach() (lib/nerf_utils.py:146-147); the extras path of
+        # the backward kernel differentiates through the weights, which is right for semantics / coords only
+        raise NotImplementedError('normals that require grad are not supported (the sampler returns them detached)')
     ex_a = [t for t in (normals_a, extra_a) if t is not None]
     ex_b = [t for t in (normals_b, extra_b) if t is not None] if two else []
     n_norm = normals_a.shape[-1] if normals_a is not None else 0

@@ -3,10 +3,10 @@
 The reference scatters the batch along dim 0 to its GPUs, re-broadcasts all parameters on every
 forward and reduces gradients to GPU 0 on every backward.  Here every rank holds a persistent
 replica, takes its slice of the batch with :func:`shard_batch` (same dim-0 split as DP's scatter),
-renders locally (no collective on the render path: rays are independent) and, when training, calls
-:func:`allreduce_gradients` once per optimiser step: the gradients are packed into ONE flat fp32
-buffer (128.7 MB for G, 115.7 MB for D) and summed with a single all-reduce (RCCL over xGMI on the
-GPU box, gloo in the CPU tests).  Inversion needs no collective (per-image independent problems,
+renders locally (no collective on the render path: rays are independent) and, when training, keeps
+its gradients in :class:`GradientBuckets` - persistent flat fp32 buffers (128.7 MB for G, 115.7 MB
+for D) whose buckets are all-reduced (RCCL over xGMI on the GPU box, gloo in the CPU tests)
+asynchronously while backward is still running; :func:`allreduce_gradients` is the one-shot form.  Inversion needs no collective (per-image independent problems,
 run.py:2232-2241); :func:`gather_metrics` collects per-image results for the final report.
 """
 import torch
@@ -41,22 +41,162 @@ def shard_batch(*tensors, rank=None, world_size=None):
     return out[0] if len(out) == 1 else tuple(out)
 
 
+class GradientBuckets:
+    """Persistent flat fp32 gradient storage for a replica's parameters, with the collective overlapped with backward.
+
+    What it replaces: ``nn.DataParallel``'s per-backward reduce of every gradient to GPU 0 and per-forward re-broadcast
+    of all parameters (run.py:636-644).  Here every rank keeps ONE set of flat buffers ("buckets",
+    ``bucket_bytes`` each, filled in reverse parameter order = roughly the order in which backward produces gradients)
+    and every ``param.grad`` is a VIEW into its bucket, so nothing is packed or copied back.  A post-accumulate hook per
+    parameter counts arrivals; when a bucket is complete its collective is launched asynchronously (RCCL runs it on its
+    own stream, over xGMI) while backward continues with the earlier layers.  ``finish()`` launches what is left (buckets
+    containing parameters that received no gradient) and waits.  Buckets go out in the order in which backward completes
+    them (the leftovers in index order): every rank runs the same graph (SPMD), so all ranks issue the same sequence.
+
+    mode 'all_reduce'      one all-reduce per bucket;
+    mode 'reduce_scatter'  reduce-scatter + all-gather per bucket (the two halves of a ring all-reduce issued
+                           explicitly: on the fully connected xGMI mesh each is one direct exchange per peer).
+
+    Use ``zero_grad()`` of this object instead of the optimiser's (which would detach the views).
+    """
+
+    def __init__(self, parameters, bucket_bytes=32 << 20, average=False, mode='all_reduce', overlap=True, group=None):
+        if mode not in ('all_reduce', 'reduce_scatter'):
+            raise ValueError("mode must be 'all_reduce' or 'reduce_scatter'")
+        self.params = [p for p in parameters if p.requires_grad]
+        if not self.params:
+            raise ValueError('GradientBuckets: no parameter requires grad')
+        self.average, self.mode, self.overlap, self.group = average, mode, overlap, group
+        _, self.world_size = world()
+        dev = self.params[0].device
+        per = max(1, int(bucket_bytes) // 4)
+        self.buckets = []          # dict(flat, params, offsets, pending, shard)
+        cur, cur_n = [], 0
+        for p in reversed(self.params):
+            if p.dtype != torch.float32 or p.device != dev:
+                raise TypeError('GradientBuckets: fp32 parameters on one device only')
+            if cur and cur_n + p.numel() > per:
+                self._close(cur, cur_n, dev)
+                cur, cur_n = [], 0
+            cur.append(p)
+            cur_n += p.numel()
+        self._close(cur, cur_n, dev)
+        self._bucket_of = {}
+        self._ptr = {}
+        self._hooks = []
+        for bi, b in enumerate(self.buckets):
+            for p in b['params']:
+                self._bucket_of[id(p)] = bi
+                self._hooks.append(p.register_post_accumulate_grad_hook(self._arrived))
+        self.nbytes = sum(b['numel'] for b in self.buckets) * 4
+        self.zero_grad()
+
+    def _close(self, params, n, dev):
+        w = max(self.world_size, 1)
+        padded = -(-n // w) * w                          # reduce-scatter needs equal shards
+        flat = torch.zeros(padded, dtype=torch.float32, device=dev)
+        offs, o = [], 0
+        for p in params:
+            offs.append(o)
+            o += p.numel()
+        shard = torch.empty(padded // w, dtype=torch.float32, device=dev) if self.mode == 'reduce_scatter' else None
+        self.buckets.append(dict(flat=flat, params=params, offsets=offs, numel=n, shard=shard))
+
+    def zero_grad(self):
+        """Zeroes the flat buffers and (re-)attaches every param.grad as a view of its bucket."""
+        for b in self.buckets:
+            b['flat'].zero_()
+            for p, o in zip(b['params'], b['offsets']):
+                v = b['flat'][o:o + p.numel()].view_as(p)
+                if p.grad is None or p.grad.data_ptr() != v.data_ptr():
+                    p.grad = v
+                self._ptr[id(p)] = v.data_ptr()
+        self._arrivals = [0] * len(self.buckets)
+        self._launched = [False] * len(self.buckets)
+        self._handles = []
+        self.launched_in_backward = 0
+
+    def _launch(self, bi):
+        b = self.buckets[bi]
+        if self.world_size == 1:
+            return
+        if self.mode == 'all_reduce':
+            self._handles.append((bi, dist.all_reduce(b['flat'], op=dist.ReduceOp.SUM, group=self.group, async_op=True)))
+        else:
+            self._handles.append((bi, dist.reduce_scatter_tensor(b['shard'], b['flat'], op=dist.ReduceOp.SUM,
+                                                                 group=self.group, async_op=True)))
+
+    def _arrived(self, p):
+        bi = self._bucket_of[id(p)]
+        if p.grad.data_ptr() != self._ptr[id(p)]:
+            raise RuntimeError('GradientBuckets: a .grad was replaced (use GradientBuckets.zero_grad(), not the '
+                               "optimiser's zero_grad(set_to_none=True))")
+        self._arrivals[bi] += 1
+        if not self.overlap:
+            return
+        if self._arrivals[bi] == len(self.buckets[bi]['params']) and not self._launched[bi]:
+            self._launch(bi)
+            self._launched[bi] = True
+            self.launched_in_backward += 1
+
+    def finish(self):
+        """Launches the collectives not yet issued, waits for all of them, applies the 1/world_size of `average`.
+        Returns the number of gradient bytes reduced (0 with a single rank)."""
+        if self.world_size == 1:
+            return 0
+        for bi in range(len(self.buckets)):
+            if not self._launched[bi]:
+                self._launch(bi)
+                self._launched[bi] = True
+        gathers = []
+        for bi, h in self._handles:
+            h.wait()
+            b = self.buckets[bi]
+            if self.mode == 'reduce_scatter':
+                if self.average:
+                    b['shard'] /= self.world_size
+                gathers.append(dist.all_gather_into_tensor(b['flat'], b['shard'], group=self.group, async_op=True))
+            elif self.average:
+                b['flat'] /= self.world_size
+        for h in gathers:
+            h.wait()
+        self._handles = []
+        return self.nbytes
+
+    def remove_hooks(self):
+        for h in self._hooks:
+            h.remove()
+        self._hooks = []
+
+
+_FLAT_CACHE = {}
+
+
 def allreduce_gradients(parameters, average=False):
-    """Sums (or averages) .grad of the given parameters across ranks with ONE all-reduce."""
+    """Sums (or averages) .grad of the given parameters across ranks, one shot after backward (no overlap; for the
+    persistent, overlapped form use :class:`GradientBuckets`).  Gradients that already live in GradientBuckets storage
+    are reduced in place; loose gradients go through ONE persistent flat staging buffer (re-used across steps)."""
     params = [p for p in parameters if p.grad is not None]
     rank, w = world()
     if w == 1 or not params:
         return 0
-    flat = torch.cat([p.grad.reshape(-1).float() for p in params])
+    n = sum(p.grad.numel() for p in params)
+    key = (params[0].grad.device, n)
+    flat = _FLAT_CACHE.get(key)
+    if flat is None:
+        _FLAT_CACHE.clear()                     # one staging buffer at a time (G and D steps alternate sizes rarely)
+        flat = _FLAT_CACHE[key] = torch.empty(n, dtype=torch.float32, device=key[0])
+    views, off = [], 0
+    for p in params:
+        k = p.grad.numel()
+        views.append(flat[off:off + k].view_as(p.grad))
+        off += k
+    torch._foreach_copy_(views, [p.grad for p in params])
     dist.all_reduce(flat, op=dist.ReduceOp.SUM)
     if average:
         flat /= w
-    off = 0
-    for p in params:
-        n = p.grad.numel()
-        p.grad.copy_(flat[off:off + n].view_as(p.grad))
-        off += n
-    return flat.numel() * 4
+    torch._foreach_copy_([p.grad for p in params], views)
+    return n * 4
 
 
 def allreduce_scalar_mean(value, device=None):

@@ -9,9 +9,10 @@ Two execution paths, both HIP through the C ABI:
   * fused   - one persistent launch for the whole pipeline (no gradient, no per-sample extras);
   * staged  - one launch per stage through ``nerf_utils`` and the ``sampler`` closure, used when a
               gradient or normals/semantics/coords maps are requested.
-Randomness follows the reference: ``torch.rand`` of [B,H,W,S] for the stratified jitter, then
-``torch.rand`` of [B*H*W,S] for the inverse-CDF draws (nerf_utils.py:115, 202), even in eval
-(``randomize`` defaults to True and no caller overrides it).
+Randomness follows the reference, in its order: ``torch.rand`` of [B,H,W,S] for the stratified
+jitter (nerf_utils.py:115) BEFORE the model is called (its synthesis network draws noise of its own
+in training), then ``torch.rand`` of [B*H*W,S] for the inverse-CDF draws (nerf_utils.py:202), even
+in eval (``randomize`` defaults to True and no caller overrides it).
 """
 import torch
 
@@ -19,6 +20,9 @@ from . import nerf_utils, ops
 
 args = None
 dataset_config = None
+# opt-in, NOT parity: transmittance threshold below which the fused inference kernel stops marching a ray
+# (0 = exact path; see ops.render_fwd(fast_termination=...) and DESIGN.md)
+FAST_TERMINATION = 0.0
 
 
 def configure(new_args, new_dataset_config):
@@ -62,24 +66,29 @@ def _render(cfg, dcfg, target_model, height, width, tform_cam2world, focal_lengt
     if compute_semantics:
         assert cfg.attention_values > 0
 
+    B = tform_cam2world.shape[0]
+    dev = tform_cam2world.device
+    plain = not (compute_normals or compute_semantics or compute_coords)
+    cam_grad = (not force_no_cam_grad) and _needs_grad(tform_cam2world, focal_length, bbox, center)
+
+    # Order of the random draws as in the reference: the stratified jitter (rand_like inside
+    # compute_query_points_from_rays, run.py:203-209) comes BEFORE target_model is called (whose synthesis network
+    # draws its own noise in training), the inverse-CDF draw after it.
     rays = None
     viewdirs = None
     if cfg.use_viewdir:
         # run.py:192-219: the model needs the normalised ray directions before it can build the sampler
         rays = nerf_utils.get_ray_bundle_normalized(height, width, focal_length, tform_cam2world, bbox, center)
         viewdirs = (rays[1].detach() if force_no_cam_grad else rays[1]).unsqueeze(-2)
+    noise_c = torch.rand((B, height, width, S), dtype=torch.float32, device=dev) if randomize else None
+
     model_outputs = target_model(viewdirs, model_input, ['sampler'] + extra_model_outputs, extra_model_inputs)
     sampler = model_outputs['sampler']
     del model_outputs['sampler']
     fused = getattr(sampler, 'fused', None)
-    B = tform_cam2world.shape[0]
-    dev = tform_cam2world.device
 
-    plain = not (compute_normals or compute_semantics or compute_coords)
-    cam_grad = (not force_no_cam_grad) and _needs_grad(tform_cam2world, focal_length, bbox, center)
     if fused is not None and plain and not cam_grad and not fused.requires_grad:
-        # ---------------- fused inference path ----------------
-        noise_c = torch.rand((B, height, width, S), dtype=torch.float32, device=dev) if randomize else None
+        # ---------------- fused inference path (the kernel generates the rays itself) ----------------
         noise_f = None
         if cfg.fine_sampling and randomize:
             noise_f = torch.rand([B * height * width, S], dtype=torch.float32, device=dev)
@@ -90,7 +99,8 @@ def _render(cfg, dcfg, target_model, height, width, tform_cam2world, focal_lengt
             None if fused.beta is None else fused.beta.detach(), None if fused.alpha is None else fused.alpha.detach(),
             bbox=None if bbox is None else bbox.detach(), center=None if center is None else center.detach(),
             noise_coarse=noise_c, noise_fine=noise_f, fine_sampling=bool(cfg.fine_sampling),
-            white_background=bool(white), skip_missed_rays=True, ray_features=getattr(fused, 'ray_features', None))
+            white_background=bool(white), skip_missed_rays=True, ray_features=getattr(fused, 'ray_features', None),
+            fast_termination=FAST_TERMINATION)
         return out['rgb'], out['depth'], out['mask'], None, None, model_outputs
 
     # ---------------- staged path (differentiable / extra maps) ----------------
@@ -99,7 +109,7 @@ def _render(cfg, dcfg, target_model, height, width, tform_cam2world, focal_lengt
     with torch.no_grad():
         near, far = nerf_utils.compute_near_far_planes(ray_origins.detach(), ray_directions.detach(), scene_range)
     query_points, depth_values = nerf_utils.compute_query_points_from_rays(
-        ray_origins, ray_directions, near, far, S, randomize=randomize)
+        ray_origins, ray_directions, near, far, S, randomize=randomize, noise=noise_c)
     if force_no_cam_grad:
         query_points, depth_values = query_points.detach(), depth_values.detach()
         ray_directions = ray_directions.detach()

@@ -74,3 +74,88 @@ def test_single_process_is_identity():
     assert parallel.shard_range(7, rank=1, world_size=4) == (2, 4)
     assert parallel.shard_range(7, rank=3, world_size=4) == (6, 7)
     assert parallel.allreduce_gradients([torch.nn.Parameter(torch.zeros(2))]) == 0
+
+
+def _bucket_worker(rank, world, port, q, mode):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        torch.manual_seed(0)
+        net = torch.nn.Sequential(torch.nn.Linear(7, 5), torch.nn.Tanh(), torch.nn.Linear(5, 3), torch.nn.Tanh(),
+                                  torch.nn.Linear(3, 2))
+        unused = torch.nn.Parameter(torch.randn(3))
+        params = list(net.parameters()) + [unused]
+        # tiny buckets: several collectives, launched while backward is still running
+        gb = parallel.GradientBuckets(params, bucket_bytes=64, mode=mode)
+        assert len(gb.buckets) > 2
+        x = torch.randn(5, 7)                       # uneven batch: 3 images on rank 0, 2 on rank 1
+        xs = parallel.shard_batch(x)
+        assert xs.shape[0] == (3 if rank == 0 else 2)
+        ref = [p.detach().clone().requires_grad_() for p in net.parameters()]
+
+        def fwd(ps, inp):
+            h = torch.tanh(inp @ ps[0].t() + ps[1])
+            h = torch.tanh(h @ ps[2].t() + ps[3])
+            return ((h @ ps[4].t() + ps[5]) ** 2).sum()
+        for step in range(2):                      # second step: views survive zero_grad()
+            gb.zero_grad()
+            fwd(list(net.parameters()), xs).backward()
+            assert gb.launched_in_backward >= 1     # overlap: some buckets went out before finish()
+            nbytes = gb.finish()
+            assert nbytes == gb.nbytes
+            for r in ref:
+                r.grad = None
+            fwd(ref, x).backward()
+            for p, r in zip(net.parameters(), ref):
+                assert torch.allclose(p.grad, r.grad, atol=1e-5), (step, p.grad, r.grad)
+                assert p.grad.data_ptr() == gb._ptr[id(p)]
+            assert torch.equal(unused.grad, torch.zeros(3))
+        # ParallelModel + shard_batch with the uneven batch: every rank renders its own images
+        calls = []
+
+        def fake_render(model, h, w, cam, focal, center, bbox, c, spr, **kw):
+            calls.append((cam.shape[0], h, spr))
+            return (cam.sum(dim=(1, 2)),)
+        pm = parallel.ParallelModel(16, model=net, render=fake_render, depth_samples_per_ray=8)
+        cam = torch.arange(5 * 16, dtype=torch.float32).view(5, 4, 4)
+        mine = pm(parallel.shard_batch(cam), None, None, None, None, res_multiplier=2, ray_multiplier=2)[0]
+        assert calls == [(3 if rank == 0 else 2, 32, 16)]
+        assert torch.equal(parallel.gather_metrics(mine), cam.sum(dim=(1, 2)))
+        q.put((rank, 'ok'))
+    except Exception as e:  # pragma: no cover
+        import traceback
+        q.put((rank, traceback.format_exc()))
+    finally:
+        dist.destroy_process_group()
+
+
+def _run_two(target, *extra):
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=target, args=(r, 2, port, q) + extra) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    assert sorted(res) == [(0, 'ok'), (1, 'ok')], res
+
+
+def test_gradient_buckets_all_reduce_uneven_batch():
+    _run_two(_bucket_worker, 'all_reduce')
+
+
+def test_gradient_buckets_reduce_scatter():
+    _run_two(_bucket_worker, 'reduce_scatter')
+
+
+def test_gradient_buckets_single_process():
+    w = torch.nn.Parameter(torch.randn(4, 3))
+    b = torch.nn.Parameter(torch.randn(3))
+    gb = parallel.GradientBuckets([w, b])
+    (w.sum() + b.sum()).backward()
+    assert gb.finish() == 0 and torch.equal(w.grad, torch.ones(4, 3))
+    gb.zero_grad()
+    assert torch.equal(w.grad, torch.zeros(4, 3)) and w.grad.data_ptr() == gb._ptr[id(w)]
