@@ -1,21 +1,32 @@
 """Headline benchmark: rendered rays/s of the volumetric-rendering hot path (BASELINE.json cfg2).
 
-  python bench.py --gpus N --steps K --warmup W
-  (N>1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+  python bench.py --gpus N --steps K --warmup W            (N>1: python -m torch.distributed.run --nnodes=1
+                                                             --nproc-per-node N ... bench.py --gpus N ...)
+  python bench.py --mode train --gpus N ...                 cfg4-like generator training step with the RCCL
+                                                             gradient all-reduce (tools/train_bench.py)
 
-One step = one pass of the hot path over one batch per GPU: triplane hand-off (NCHW -> channel-last
-texels), decoder operand packing, the reference's two torch.rand draws, ray set-up and the fused
-render of IMAGES_PER_GPU images at 128x128 with 64 coarse + 64 fine samples (fp32 planes, fp32
-arithmetic - the reference's precision).  Planes, decoder weights and cameras are synthetic and
-already resident in HBM.  Images are sharded across ranks (weak scaling, no collective on the render
-path: SURVEY.md section 8(e)).
+One step (render mode) = one pass of the hot path over one batch per GPU: triplane hand-off (NCHW -> channel-last
+texels), decoder operand packing, the reference's two torch.rand draws, ray set-up and the fused render of
+IMAGES_PER_GPU images at 128x128 with 64 coarse + 64 fine samples (fp32 planes, fp32 accumulation; decoder MLP
+operands as split fp16 hi+lo pairs, see config.mlp).  Planes, decoder weights and cameras are synthetic and already
+resident in HBM.  Images are sharded across ranks (weak scaling, no collective on the render path: SURVEY.md 8(e)).
 
 Printed JSON (rank 0, one line) carries, besides the contract fields:
-  roofline     - the fused render kernel: algorithmic gather bytes per launch (196 608 B per ray that
-                 is actually marched) / its live HIP-event duration, against HBM peak;
-                 traffic = measured HBM bytes per launch from profiles/ (rocprofv3 PMC) or null;
-  cpu_baseline - the oracle (CPU restatement of the reference, reference ATen numerics) timed on this
-                 box's host cores on ONE image of the same workload.
+  ms_per_step_stats - min / median / max over the K timed steps (HIP events per step);
+  roofline          - the fused render kernel against the resource that binds it.  The kernel is bound by
+                      instruction issue (VALU + transcendentals), not by HBM: its algorithmic gather stream
+                      (196 608 B per marched ray) is served by L1 / L2 / Infinity Cache at about twice
+                      the HBM peak.  achieved = issue cycles per second = (issue cycles per marched ray, from the SQ
+                      counters of the committed rocprofv3 PMC profile named in `source`) x (rays marched per launch,
+                      live) / (kernel duration, live HIP events on the launch stream); peak = 1024 SIMDs x the shader
+                      clock measured in the same profile.  `levels` carries the byte-side figures, each against its
+                      own peak: L2 request bytes (34.5 TB/s), fabric bytes FETCH x2 + WRITE (8 TB/s; `traffic`),
+                      compulsory HBM bytes, the cache-served algorithmic gather stream (no peak: not a bound) and the
+                      MFMA rate;
+  parity            - max |error| of ONE image of this very workload rendered by the timed code path against the CPU
+                      oracle (untimed; budget 1e-4 on rgb / depth / mask);
+  cpu_baseline      - the oracle (CPU restatement of the reference, reference ATen numerics) timed on this box's host
+                      cores on ONE image of the same workload.
 """
 import argparse
 import ctypes
@@ -34,8 +45,12 @@ IMAGES_PER_GPU = 8
 SCENE_RANGE, RADIUS, FOCAL = 0.55, 2.0, 1.0254      # shapenet_chairs-like
 GATHER_BYTES_PER_RAY = 196608                        # 128 points x 12 texels x 128 B
 HBM_PEAK_GBS = 8000.0
+L2_PEAK_GBS = 34500.0                                # MI355X_MICROARCH.md, L2 (per XCD, aggregate)
 MFMA_F32_PEAK_TFLOPS = 157.3
+MFMA_F16_PEAK_TFLOPS = 2500.0
 MLP_FLOP_PER_RAY = 704512
+N_SIMD = 1024
+PMC_PROFILES = ('profiles/r2/pmc_render_fwd.json', 'profiles/r1/pmc_render_fwd_derived.json')
 
 
 def cameras(n, radius, gen):
@@ -91,8 +106,14 @@ class HipEvents:
         return ms.value
 
 
-def cpu_baseline(seed):
-    """Oracle (kind 'port': the CPU restatement pinned bit-exactly to the reference) on one image."""
+def stats(xs):
+    xs = sorted(xs)
+    return {'min': xs[0], 'median': xs[len(xs) // 2], 'max': xs[-1]}
+
+
+def cpu_baseline_and_parity(seed, dev, ops):
+    """Oracle (kind 'port': the CPU restatement pinned bit-exactly to the reference) on one image of the workload; the
+    same image, same noise, rendered by the timed HIP code path is compared with it (the bench's own parity figure)."""
     from oracle import nfi_oracle as orc
     d = synthetic_inputs(1, seed, 'cpu')
     g = torch.Generator().manual_seed(seed + 1)
@@ -102,70 +123,106 @@ def cpu_baseline(seed):
     with torch.no_grad():
         for i in range(4):
             t0 = time.perf_counter()
-            orc.render(d['planes'], d['w1'], d['b1'], d['w2'], d['b2'], d['cam'], d['focal'], R, R, S, SCENE_RANGE,
-                       white_background=True, noise_coarse=nc, noise_fine=nf, use_sdf=True, beta=d['beta'],
-                       alpha=d['alpha'], attention_values=d['att'])
+            ref = orc.render(d['planes'], d['w1'], d['b1'], d['w2'], d['b2'], d['cam'], d['focal'], R, R, S, SCENE_RANGE,
+                             white_background=True, noise_coarse=nc, noise_fine=nf, use_sdf=True, beta=d['beta'],
+                             alpha=d['alpha'], attention_values=d['att'])
             if i > 0:
                 times.append(time.perf_counter() - t0)
     med = sorted(times)[len(times) // 2]
-    return {'value': R * R / med, 'unit': 'rays/s', 'cores': torch.get_num_threads(), 'kind': 'port',
+    base = {'value': R * R / med, 'unit': 'rays/s', 'cores': torch.get_num_threads(), 'kind': 'port',
             'sample': '1 image 128x128, 64+64 samples, planes precomputed (render only), fp32, 1 warm-up + 3 timed runs, median'}
+    dd = {k: v.to(dev) for k, v in d.items()}
+    texels = ops.planes_to_texels(dd['planes'])
+    image = ops.decoder_pack(dd['w1'], dd['b1'], dd['w2'], dd['b2'], A)
+    out = ops.render_fwd(dd['cam'], dd['focal'], R, R, S, texels, image, SCENE_RANGE, A, dd['att'], True, dd['beta'],
+                         dd['alpha'], noise_coarse=nc.to(dev), noise_fine=nf.to(dev), fine_sampling=True,
+                         white_background=True, skip_missed_rays=True)
+    parity = {k: float((out[k].cpu() - ref[k]).abs().max()) for k in ('rgb', 'depth', 'mask')}
+    parity.update(budget=1e-4, against='CPU oracle (reference ATen numerics), 1 image of this workload, same noise',
+                  ok=bool(max(parity['rgb'], parity['depth'], parity['mask']) <= 1e-4 and
+                          all(bool(torch.isfinite(out[k]).all()) for k in ('rgb', 'depth', 'mask'))),
+                  mask_mean=float(ref['mask'].mean()))
+    return base, parity
 
 
-def extras(dev, ops, d):
-    """Untimed-side measurements reported next to the headline (never part of `value`):
-    the same render at B=1, with every ray crossing the cube (cars-like radius 1.3), with bf16 texels
-    (BASELINE config 2's storage variant; parity vs fp32 is tolerance-level, see tests), and the oracle
-    evaluated with PyTorch-ROCm ops on this GPU (= the reference's own GPU path, the north star's
-    >= 10x denominator)."""
+def time_render(ops, dev, n_img, radius, texel_dtype, iters=50, R=R, S=S, tuning=0, fast=0.0):
+    """Render-only rays/s of one configuration: HIP events around every call (on the launch stream), `iters` calls."""
+    dd = synthetic_inputs(n_img, 4321, dev)
+    g = torch.Generator().manual_seed(77)
+    dd['cam'] = cameras(n_img, radius, g).to(dev)
+    texels = ops.planes_to_texels(dd['planes'], texel_dtype)
+    image = ops.decoder_pack(dd['w1'], dd['b1'], dd['w2'], dd['b2'], A, texel_dtype)
+    nc = torch.rand((n_img, R, R, S), device=dev)
+    nf = torch.rand((n_img * R * R, S), device=dev)
+    ws = None
+    evs = [torch.cuda.Event(enable_timing=True) for _ in range(iters + 1)]
+    for i in range(iters + 5):
+        if i >= 5:
+            evs[i - 5].record()
+        out = ops.render_fwd(dd['cam'], dd['focal'], R, R, S, texels, image, SCENE_RANGE, A, dd['att'], True,
+                             dd['beta'], dd['alpha'], noise_coarse=nc, noise_fine=nf, workspace=ws, tuning=tuning,
+                             fast_termination=fast)
+        ws = out['_workspace']
+    evs[iters].record()
+    torch.cuda.synchronize()
+    per = [evs[i].elapsed_time(evs[i + 1]) for i in range(iters)]
+    n = n_img * R * R
+    return {'rays_per_s': n * iters / (sum(per) * 1e-3), 'ms': stats(per), 'iters': iters}, out
+
+
+def extras(dev, ops):
+    """Untimed-side measurements reported next to the headline (never part of `value`)."""
     from oracle import nfi_oracle as orc
-
-    def time_render(n_img, radius, texel_dtype, iters=20, R=R, S=S):
-        dd = synthetic_inputs(n_img, 4321, dev)
-        g = torch.Generator().manual_seed(77)
-        dd['cam'] = cameras(n_img, radius, g).to(dev)
-        texels = ops.planes_to_texels(dd['planes'], texel_dtype)
-        image = ops.decoder_pack(dd['w1'], dd['b1'], dd['w2'], dd['b2'], A, texel_dtype)
-        nc = torch.rand((n_img, R, R, S), device=dev)
-        nf = torch.rand((n_img * R * R, S), device=dev)
-        ws = None
-        for i in range(iters + 3):
-            if i == 3:
-                torch.cuda.synchronize()
-                t0 = time.perf_counter()
-            out = ops.render_fwd(dd['cam'], dd['focal'], R, R, S, texels, image, SCENE_RANGE, A, dd['att'], True,
-                                 dd['beta'], dd['alpha'], noise_coarse=nc, noise_fine=nf, workspace=ws)
-            ws = out['_workspace']
-        torch.cuda.synchronize()
-        return n_img * R * R * iters / (time.perf_counter() - t0)
-
-    ex = {'render_only_rays_per_s': {
-        'b1_chairs_fp32': time_render(1, RADIUS, ops.TEXEL_F32),
-        'b8_chairs_fp32': time_render(8, RADIUS, ops.TEXEL_F32),
-        'b8_all_rays_hit_fp32': time_render(8, 1.3, ops.TEXEL_F32),
-        'b8_chairs_bf16_texels': time_render(8, RADIUS, ops.TEXEL_BF16),
+    ex = {'render_only': {}}
+    cases = {
+        'b1_chairs_fp32_texels': (1, RADIUS, ops.TEXEL_F32, {}),
+        'b8_chairs_fp32_texels': (8, RADIUS, ops.TEXEL_F32, {}),
+        'b8_all_rays_hit_fp32_texels': (8, 1.3, ops.TEXEL_F32, {}),
+        'b8_chairs_bf16_texels': (8, RADIUS, ops.TEXEL_BF16, {}),
+        # the same kernels with the decoder MLP on exact-fp32 MFMA (v_mfma_f32_16x16x4_f32) instead of split fp16
+        'b8_chairs_fp32_texels_mlp_exact_fp32': (8, RADIUS, ops.TEXEL_F32, {'tuning': 8}),
+        'b8_all_rays_hit_fp32_texels_mlp_exact_fp32': (8, 1.3, ops.TEXEL_F32, {'tuning': 8}),
         # BASELINE config 5 geometry on one GPU: 256x256 rays, 128 + 128 samples per ray
-        'b2_cfg5_256px_128+128_fp32': time_render(2, RADIUS, ops.TEXEL_F32, iters=10, R=256, S=128),
-        'b2_cfg5_256px_128+128_fp16_texels': time_render(2, RADIUS, ops.TEXEL_F16, iters=10, R=256, S=128)}}
+        'b2_cfg5_256px_128+128_fp32_texels': (2, RADIUS, ops.TEXEL_F32, {'R': 256, 'S': 128}),
+        'b2_cfg5_256px_128+128_fp16_texels': (2, RADIUS, ops.TEXEL_F16, {'R': 256, 'S': 128}),
+    }
+    exact_out = {}
+    for name, (n_img, radius, tdt, kw) in cases.items():
+        ex['render_only'][name], exact_out[name] = time_render(ops, dev, n_img, radius, tdt, **kw)
+    # opt-in fast mode (NOT parity; never the headline): transmittance-threshold termination + sample compaction
+    fast = {}
+    for name in ('b8_all_rays_hit_fp32_texels', 'b2_cfg5_256px_128+128_fp16_texels'):
+        n_img, radius, tdt, kw = cases[name]
+        for eps in (1e-3, 1e-2):
+            r, out = time_render(ops, dev, n_img, radius, tdt, fast=eps, **kw)
+            r['max_abs_drgb_vs_exact'] = float((out['rgb'] - exact_out[name]['rgb']).abs().max())
+            r['max_abs_dmask_vs_exact'] = float((out['mask'] - exact_out[name]['mask']).abs().max())
+            fast['%s_eps%g' % (name, eps)] = r
+    ex['fast_termination_opt_in_not_parity'] = fast
+    del exact_out
     # reference numerics on PyTorch-ROCm: the oracle with GPU ATen ops, 2 images, planes precomputed
     dd = synthetic_inputs(2, 4321, dev)
     nc = torch.rand((2, R, R, S), device=dev)
     nf = torch.rand((2 * R * R, S), device=dev)
     times = []
     with torch.no_grad():
-        for i in range(3):
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
+        for i in range(4):
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
             orc.render(dd['planes'], dd['w1'], dd['b1'], dd['w2'], dd['b2'], dd['cam'], dd['focal'], R, R, S, SCENE_RANGE,
                        white_background=True, noise_coarse=nc, noise_fine=nf, use_sdf=True, beta=dd['beta'],
                        alpha=dd['alpha'], attention_values=dd['att'])
+            b.record()
             torch.cuda.synchronize()
-            times.append(time.perf_counter() - t0)
+            times.append(a.elapsed_time(b) * 1e-3)
+    ex['pytorch_rocm_reference_path'] = {'value': 2 * R * R / min(times[1:]), 'unit': 'rays/s',
+                                         'sample': 'oracle (reference ATen op sequence) on this GPU, 2 images, '
+                                                   'render only, fp32, best of 3 after warm-up, HIP events'}
+    sys.path.insert(0, os.path.join(ROOT, 'tools'))
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
     # BASELINE config 3 stand-in (no p3d_car data / checkpoint exists offline): synthetic inversion, 30 Adam steps on
     # latent + pose, HIP renderer (forward + HIP backward kernels) vs the oracle under PyTorch-ROCm autograd, same noise
     try:
-        sys.path.insert(0, os.path.join(ROOT, 'tools'))
-        sys.path.insert(0, os.path.join(ROOT, 'tests'))
         import inversion_synthetic
         h_hip, h_ref, t_hip, t_ref = inversion_synthetic.run(dev, res=128, samples=64, batch=4, steps=30, plane_res=256)
         ex['inversion_synthetic'] = {
@@ -188,21 +245,81 @@ def extras(dev, ops, d):
                       'decoder, beta, alpha; stand-in plane producer; median of 6 steps; different noise draws per path'}
     except Exception as e:
         ex['train_step_synthetic'] = {'error': repr(e)}
-    ex['pytorch_rocm_reference_path'] = {'value': 2 * R * R / min(times[1:]), 'unit': 'rays/s',
-                                         'sample': 'oracle (reference ATen op sequence) on this GPU, 2 images, '
-                                                   'render only, fp32, best of 2 after warm-up'}
     return ex
+
+
+def load_pmc_profile():
+    for rel in PMC_PROFILES:
+        p = os.path.join(ROOT, rel)
+        if os.path.exists(p):
+            try:
+                d = json.load(open(p))
+                if 'issue_cycles_per_marched_ray' in d:
+                    return rel, d
+            except Exception:
+                pass
+    return None, None
+
+
+def roofline(kernel_ms, marched, n_images):
+    """Roofline object of the fused render kernel (see the module docstring)."""
+    t = kernel_ms * 1e-3
+    src, prof = load_pmc_profile()
+    gather_gbs = marched * GATHER_BYTES_PER_RAY / t / 1e9
+    compulsory = n_images * (3 * 32 * PLANE_RES * PLANE_RES * 4 + R * R * (2 * S * 4 + 33 + 20))   # planes + noise + ray set-up + outputs
+    mlp_tflops = marched * MLP_FLOP_PER_RAY / t / 1e12
+    levels = {
+        'hbm_compulsory': {'bytes_per_launch': compulsory, 'achieved': compulsory / t / 1e9, 'peak': HBM_PEAK_GBS,
+                           'unit': 'GB/s', 'frac': compulsory / t / 1e9 / HBM_PEAK_GBS},
+        'gather_stream_algorithmic': {'bytes_per_launch': marched * GATHER_BYTES_PER_RAY, 'achieved': gather_gbs,
+                                      'unit': 'GB/s', 'x_hbm_peak': gather_gbs / HBM_PEAK_GBS,
+                                      'note': 'served by L1/L2/Infinity Cache, NOT a bound (exceeds the HBM peak)'},
+        'mfma': {'achieved': mlp_tflops, 'unit': 'TFLOP/s', 'peak_fp32': MFMA_F32_PEAK_TFLOPS,
+                 'frac_of_fp32_matrix_peak': mlp_tflops / MFMA_F32_PEAK_TFLOPS,
+                 'note': 'useful MLP FLOPs (704 512 per ray); issued as split-fp16 MFMA: 3 products per fp32-equivalent '
+                         'FLOP against the 2.5 PFLOP/s fp16 peak',
+                 'frac_of_fp16_matrix_peak_issued': 3 * mlp_tflops / MFMA_F16_PEAK_TFLOPS},
+    }
+    r = {'bound': 'valu-issue', 'kernel': 'render_fwd_kernel', 'kernel_ms': kernel_ms, 'rays_marched_per_launch': marched,
+         'unit': 'Gcycle/s', 'source': src, 'levels': levels}
+    if prof is None:
+        r.update(achieved=None, peak=None, frac=None, traffic=None,
+                 note='no PMC profile with issue_cycles_per_marched_ray under profiles/: run tools/gpu_pmc_render.sh')
+        return r
+    clk = prof['shader_clock_hz']
+    ach = prof['issue_cycles_per_marched_ray'] * marched / t
+    peak = N_SIMD * clk
+    scale = marched / prof['rays_marched_per_launch']                 # byte counters scale with the rays marched
+    l2 = prof['l2_request_bytes_per_launch'] * scale
+    fab = prof['fabric_bytes_per_launch'] * scale
+    levels['l2_requests'] = {'bytes_per_launch': l2, 'achieved': l2 / t / 1e9, 'peak': L2_PEAK_GBS, 'unit': 'GB/s',
+                             'frac': l2 / t / 1e9 / L2_PEAK_GBS, 'hit_rate': prof.get('l2_hit_rate')}
+    levels['fabric'] = {'bytes_per_launch': fab, 'achieved': fab / t / 1e9, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                        'frac': fab / t / 1e9 / HBM_PEAK_GBS, 'x_compulsory': fab / compulsory,
+                        'note': 'FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE; Infinity-Cache hits included; WRITE_SIZE '
+                                'is mostly the write-back of the preceding kernels\' dirty lines (texel hand-off, rand)'}
+    r.update(achieved=ach / 1e9, peak=peak / 1e9, frac=ach / peak, traffic=fab,
+             issue_cycles_per_marched_ray=prof['issue_cycles_per_marched_ray'], shader_clock_hz=clk,
+             frac_in_profile_run=prof.get('issue_frac'),
+             note='instruction-issue bound: SQ_ACTIVE_INST_ANY (x4 cycles) per marched ray from the PMC profile, scaled by '
+                  'the live ray count and kernel time, over 1024 SIMDs x the profiled shader clock')
+    return r
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=50)
-    ap.add_argument('--warmup', type=int, default=10)
-    ap.add_argument('--images-per-gpu', type=int, default=IMAGES_PER_GPU)
-    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--steps', type=int, default=200)
+    ap.add_argument('--warmup', type=int, default=20)
+    ap.add_argument('--mode', choices=('render', 'train'), default='render')
+    ap.add_argument('--images-per-gpu', type=int, default=None)
+    ap.add_argument('--no-cpu-baseline', action='store_true', help='skip the CPU oracle leg (and the parity figure)')
+    ap.add_argument('--no-extras', action='store_true')
     ap.add_argument('--no-skip', action='store_true', help='march rays that miss the scene cube too')
     ap.add_argument('--force-dist', action='store_true', help='initialise RCCL even with one rank (exercises the N>1 code path)')
+    ap.add_argument('--bucket-mb', type=int, default=32, help='train mode: gradient bucket size')
+    ap.add_argument('--reduce-mode', choices=('all_reduce', 'reduce_scatter'), default='all_reduce')
+    ap.add_argument('--no-overlap', action='store_true', help='train mode: launch the collectives after backward')
     args = ap.parse_args()
 
     rank = int(os.environ.get('RANK', 0))
@@ -227,11 +344,14 @@ def main():
         dist.barrier()
     from nerf_from_image_amd import ops
 
-    B = args.images_per_gpu
+    if args.mode == 'train':
+        return train_mode(args, dev, rank, world, use_dist)
+
+    B = args.images_per_gpu or IMAGES_PER_GPU
     d = synthetic_inputs(B, 1234 + rank, dev)
     n_rays = B * R * R
     ev = HipEvents()
-    state = {'ws': None, 'kernel_ms': 0.0, 'kernel_n': 0}
+    state = {'ws': None}
 
     def step(timed_kernel=False):
         texels = ops.planes_to_texels(d['planes'])
@@ -252,12 +372,16 @@ def main():
 
     for _ in range(args.warmup):
         out = step()
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     fence()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for i in range(args.steps):
+        marks[i].record()
         out = step()
+    marks[args.steps].record()
     fence()
     elapsed = time.perf_counter() - t0
+    per_step = [marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps)]
     if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -265,7 +389,7 @@ def main():
 
     # ---- dominant kernel, timed live with HIP events on its own stream (untimed extra launches) ----
     k_ms = []
-    for _ in range(min(20, max(5, args.steps))):
+    for _ in range(min(50, max(5, args.steps))):
         step(timed_kernel=True)
         k_ms.append(ev.elapsed_ms())
     kernel_ms = sum(k_ms) / len(k_ms)
@@ -275,40 +399,76 @@ def main():
 
     if rank == 0:
         value = world * n_rays * args.steps / elapsed
-        ach_gbs = marched * GATHER_BYTES_PER_RAY / (kernel_ms * 1e-3) / 1e9
-        traffic = None
-        pmc = os.path.join(ROOT, 'profiles', 'pmc_render_fwd.json')
-        if os.path.exists(pmc):
-            try:
-                traffic = json.load(open(pmc)).get('hbm_bytes_per_launch')
-            except Exception:
-                traffic = None
         res = {
             'metric': 'rendered rays/sec (128x128, 64+64 samples)', 'value': value, 'unit': 'rays/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': elapsed / args.steps * 1e3,
+            'ms_per_step_stats': stats(per_step),
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
             'config': {'workload': 'cfg2: shapenet_chairs-like forward render, %d images/GPU, 128x128 rays/image, '
                                    '64 coarse + 64 fine samples, 3x256x256x32 fp32 triplanes, SDF decoder, A=10; '
                                    'step = texel hand-off + decoder pack + 2 rand draws + ray set-up + fused render'
                                    % B,
+                       'mlp': 'split-fp16: decoder MLP operands as fp16 hi+lo pairs (22 significand bits), products '
+                              'hi*hi + hi*lo + lo*hi accumulated in fp32 on v_mfma_f32_16x16x32_f16; everything else '
+                              'fp32 (exact-fp32 MFMA variant timed in extras.render_only.*_mlp_exact_fp32)',
                        'images_per_gpu': B, 'resolution': R, 'samples': '64+64', 'plane_res': PLANE_RES,
                        'camera_radius': RADIUS, 'scene_range': SCENE_RANGE, 'rays_marched_fraction': marched / n_rays,
                        'skip_missed_rays': not args.no_skip, 'sharding': 'images across ranks, no collective'},
-            'roofline': {'bound': 'hbm', 'kernel': 'render_fwd_kernel', 'achieved': ach_gbs, 'peak': HBM_PEAK_GBS,
-                         'unit': 'GB/s', 'frac': ach_gbs / HBM_PEAK_GBS, 'traffic': traffic,
-                         'kernel_ms': kernel_ms, 'rays_marched_per_launch': marched,
-                         'note': 'algorithmic gather stream (196608 B per marched ray) over the HBM peak; the stream is served '
-                                 'mostly by L2/Infinity Cache (`traffic` = measured fabric bytes per launch), so frac > 1: '
-                                 'the kernel is instruction-issue bound (79 % of the issue slots, DESIGN.md 4.3)'},
-            'roofline_mfma': {'bound': 'mfma', 'achieved': marched * MLP_FLOP_PER_RAY / (kernel_ms * 1e-3) / 1e12,
-                              'peak': MFMA_F32_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-                              'frac': marched * MLP_FLOP_PER_RAY / (kernel_ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS},
+            'roofline': roofline(kernel_ms, marched, B),
+            'kernel_ms_stats': stats(k_ms),
         }
-        if not args.no_cpu_baseline and world == 1:
-            res['extras'] = extras(dev, ops, d)      # before the CPU leg: its OpenMP workers keep spinning for a while
-            res['cpu_baseline'] = cpu_baseline(1234)
+        if world == 1 and not args.no_extras:
+            res['extras'] = extras(dev, ops)      # before the CPU leg: its OpenMP workers keep spinning for a while
+        if world == 1 and not args.no_cpu_baseline:
+            res['cpu_baseline'], res['parity'] = cpu_baseline_and_parity(1234, dev, ops)
         else:
             res['cpu_baseline'] = None
+        print(json.dumps(res))
+    if use_dist:
+        dist.destroy_process_group()
+
+
+def train_mode(args, dev, rank, world, use_dist):
+    """cfg4-like generator training step (tools/train_bench.py): render fwd + regularisers + bwd + gradient
+    all-reduce (GradientBuckets over RCCL) + Adam, 4 images per GPU."""
+    sys.path.insert(0, os.path.join(ROOT, 'tools'))
+    import train_bench
+    import torch.distributed as dist
+    B = args.images_per_gpu or 4
+    r = train_bench.run(dev, steps=args.steps, warmup=args.warmup, batch=B, bucket_mb=args.bucket_mb,
+                        reduce_mode=args.reduce_mode, overlap=not args.no_overlap, use_dist=use_dist)
+    elapsed = r['elapsed_s']
+    per_rank = [r]
+    if use_dist:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, r)
+    if rank == 0:
+        alone = r['allreduce_alone_ms']
+        res = {
+            'metric': 'training rays/sec (cfg4-like generator step: render fwd + regularisers + bwd + gradient all-reduce + Adam)',
+            'value': world * r['rays_per_step'] * args.steps / elapsed, 'unit': 'rays/s', 'n_gpus': world,
+            'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': elapsed / args.steps * 1e3,
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': 'cfg4-like: %d images/GPU, 128x128 orthographic rays, 64+64 samples, scene_range 2.0, '
+                                   'black background, image + alpha loss, eikonal + distance regularisers, gradient '
+                                   'all-reduce of a generator-sized fp32 set (%d parameters), fused Adam'
+                                   % (B, r['n_params']),
+                       'collective': 'none (single rank)' if not use_dist else
+                                     'RCCL %s, %d buckets of <= %d MiB, %s' % (
+                                         args.reduce_mode, r['n_buckets'], args.bucket_mb,
+                                         'launched after backward' if args.no_overlap else
+                                         'launched from post-accumulate hooks during backward'),
+                       'gradient_bytes_per_step': r['gradient_bytes']},
+            'per_rank': [{k: pr[k] for k in ('ms_per_step', 'fwd_bwd_ms', 'allreduce_exposed_ms', 'optimiser_ms',
+                                             'allreduce_alone_ms', 'buckets_launched_in_backward', 'loss')}
+                         for pr in per_rank],
+            'allreduce_bus_gbs_alone': (2 * (world - 1) / world * r['gradient_bytes'] / (alone * 1e-3) / 1e9)
+            if (alone and world > 1) else None,
+            'cpu_baseline': None,
+        }
         print(json.dumps(res))
     if use_dist:
         dist.destroy_process_group()

@@ -413,6 +413,13 @@ typedef struct nfi_render_args {
   /* view-direction decoder: NULL, or [N, NFI_RAY_FEATURE_PITCH] (decoder_image from nfi_decoder_pack_viewdir;
    * the MLP then runs in exact fp32) */
   const float* ray_features;
+  /* OPT-IN, NOT PARITY (0 = off, the exact path): transmittance threshold eps in (0,1).  Coarse samples are marched
+   * front to back in steps of 32 and marching stops once the transmittance behind them is below eps; fine samples
+   * behind the first coarse sample with transmittance < eps are not evaluated (sigma = 0) and the surviving ones are
+   * compacted by wave ballot so that whole 16-point tiles drop out (BASELINE cfg5: "wavefront early-termination +
+   * sample compaction").  Changes rgb / mask by O(eps); sample indices differ from the reference.  Not available
+   * together with stage taps, the cycle profile, the view-direction decoder or the exact-fp32 MLP. */
+  float fast_termination;
 } nfi_render_args;
 size_t nfi_render_workspace_bytes(int64_t n_rays);
 int nfi_render_fwd(const nfi_render_args* a, nfi_stream_t stream);

@@ -1249,7 +1249,22 @@ struct RenderKernelParams {
   int skip_missed;
   unsigned long long* prof;
   const float* xray;   // view-direction decoder: padded per-ray features [N][kRayFeatPad], or null
+  float fast_od;       // FAST kernels: optical depth -ln(eps) behind which a ray is no longer marched
 };
+
+// inclusive fp32 scan over the 64 lanes (fast mode only: the exact path scans in double, see nfi_device.hpp)
+__device__ __forceinline__ float wave_incl_scan_add_f32(float v) {
+  v += dpp_f32<NFI_DPP_ROW_SHR(1)>(0.0f, v);
+  v += dpp_f32<NFI_DPP_ROW_SHR(2)>(0.0f, v);
+  v += dpp_f32<NFI_DPP_ROW_SHR(4)>(0.0f, v);
+  v += dpp_f32<NFI_DPP_ROW_SHR(8)>(0.0f, v);
+  v += dpp_f32<kDppRowBcast15, 0xa>(0.0f, v);
+  v += dpp_f32<kDppRowBcast31, 0xc>(0.0f, v);
+  return v;
+}
+__device__ __forceinline__ float uniform_f32(float v) {
+  return bits2f((uint32_t)__builtin_amdgcn_readfirstlane((int)f2bits(v)));
+}
 
 // Persistent kernel: one wave per ray, rays handed out by one device-scope counter (scene-major,
 // so the chip works on one scene's 25 MB of texels at a time).  The ray index two steps ahead is
@@ -1311,7 +1326,13 @@ struct RayQueue {
   }
 };
 
-template <int TEX, bool ATT, int OCC, bool TAPS, int PREC, bool PROF = false, bool VD = false>
+// FAST (opt-in, NOT parity; nfi_render_args.fast_termination): transmittance-threshold termination + sample
+// compaction.  Coarse pass: the front 32 samples are marched first and the back 32 only if the optical depth so far
+// is below -ln(eps) (the transmittance behind them is still above eps); fine pass: fine samples that lie behind the
+// first coarse sample whose transmittance fell below eps are dropped from the field query (sigma = 0, they stay in
+// the merge), and the surviving ones are compacted to the low lanes (wave ballot + popcount), so that whole 16-point
+// tiles disappear.  The exact path never takes these branches.
+template <int TEX, bool ATT, int OCC, bool TAPS, int PREC, bool PROF = false, bool VD = false, bool FAST = false>
 __global__ __launch_bounds__(256, OCC) void render_fwd_kernel(RenderKernelParams k) {
   constexpr int kImg = VD ? kVdImageFloats : kLdsImageFloats;
   __shared__ __attribute__((aligned(16))) float lds[kImg];
@@ -1410,7 +1431,23 @@ __global__ __launch_bounds__(256, OCC) void render_fwd_kernel(RenderKernelParams
       if (valid) tc = stratified_depth(near, far, lane, S, in.noise, k.noise_c != nullptr);
       MergeIn c;
       unsigned long long t1 = PROF ? __builtin_readcyclecounter() : 0;
-      {
+      float od_c = 0.0f;      // FAST: optical depth sigma * delta of this lane's coarse sample
+      if constexpr (FAST) {
+        const bool front = lane < 32;
+        SampleOut q = field_wave<TEX, ATT, true, PREC, VD>(P, k.scene_range, lane, ox + dx * tc, oy + dy * tc, oz + dz * tc,
+                                                           valid && front, nullptr, nullptr, &slab.srt[0][0], nullptr, k.xray, (int)ray);
+        const float dl = (lane < S - 1) ? (lane_next(tc, 0.0f) - tc) * dnorm : 0.0f;
+        const float od_front = uniform_f32(wave_sum((valid && front) ? q.sigma * dl : 0.0f));
+        if (od_front <= k.fast_od) {
+          SampleOut q2 = field_wave<TEX, ATT, true, PREC, VD>(P, k.scene_range, lane, ox + dx * tc, oy + dy * tc, oz + dz * tc,
+                                                              valid && !front, nullptr, nullptr, &slab.srt[0][0], nullptr, k.xray, (int)ray);
+          if (!front) q = q2;
+        } else if (!front) {
+          q.sigma = 0.0f; q.r = 0.0f; q.g = 0.0f; q.b = 0.0f;
+        }
+        c.t = tc; c.sigma = valid ? q.sigma : 0.0f; c.r = q.r; c.g = q.g; c.b = q.b;
+        od_c = c.sigma * dl;
+      } else {
         SampleOut q = field_wave<TEX, ATT, true, PREC, VD>(P, k.scene_range, lane, ox + dx * tc, oy + dy * tc, oz + dz * tc, valid,
                                                      nullptr, nullptr, &slab.srt[0][0], PROF ? pc : nullptr, k.xray, (int)ray);
         c.t = tc; c.sigma = q.sigma; c.r = q.r; c.g = q.g; c.b = q.b;
@@ -1420,10 +1457,31 @@ __global__ __launch_bounds__(256, OCC) void render_fwd_kernel(RenderKernelParams
       unsigned long long t2 = PROF ? __builtin_readcyclecounter() : 0, t3 = t2, t4 = t2, t5 = t2;
       if (k.fine) {
         // ---- hierarchical resampling + fine pass ----
-        const float tf = resample_ray(slab, c.sigma, tc, S, dnorm, in.u, lane, nullptr);
+        float tf = resample_ray(slab, c.sigma, tc, S, dnorm, in.u, lane, nullptr);
         MergeIn f;
         if (PROF) { asm volatile("" :: "v"(tf)); t3 = __builtin_readcyclecounter(); }
-        {
+        if constexpr (FAST) {
+          // depth of the first coarse sample in front of which the transmittance is already below eps
+          const float inc = wave_incl_scan_add_f32(od_c);
+          const uint64_t dm = __ballot(valid && (inc - od_c) > k.fast_od);
+          float t_dead = INFINITY;
+          if (dm) t_dead = bits2f((uint32_t)__builtin_amdgcn_readlane((int)f2bits(tc), (int)__builtin_ctzll(dm)));
+          // compaction: live fine samples to the low lanes, dropped ones behind them (they keep their depth)
+          const bool live = valid && tf <= t_dead;
+          const uint64_t lm = __ballot(live);
+          const int nl = __builtin_popcountll(lm);
+          const int nb = __builtin_popcountll(lm & ((1ull << lane) - 1ull));
+          const int pos = live ? nb : nl + (lane - nb);
+          wave_lds_fence();
+          slab.cdf[pos] = tf;
+          wave_lds_fence();
+          tf = slab.cdf[lane];
+          wave_lds_fence();
+          const bool vf = lane < nl;
+          SampleOut q = field_wave<TEX, ATT, true, PREC, VD>(P, k.scene_range, lane, ox + dx * tf, oy + dy * tf, oz + dz * tf, vf,
+                                                             nullptr, nullptr, &slab.srt[0][0], nullptr, k.xray, (int)ray);
+          f.t = tf; f.sigma = vf ? q.sigma : 0.0f; f.r = vf ? q.r : 0.0f; f.g = vf ? q.g : 0.0f; f.b = vf ? q.b : 0.0f;
+        } else {
           SampleOut q = field_wave<TEX, ATT, true, PREC, VD>(P, k.scene_range, lane, ox + dx * tf, oy + dy * tf, oz + dz * tf, valid,
                                                        nullptr, nullptr, &slab.srt[0][0], PROF ? pc : nullptr, k.xray, (int)ray);
           f.t = tf; f.sigma = q.sigma; f.r = q.r; f.g = q.g; f.b = q.b;
@@ -1491,7 +1549,7 @@ __global__ __launch_bounds__(256, OCC) void render_fwd_kernel(RenderKernelParams
 // The same pipeline for 64 < S <= 128 samples per pass (BASELINE cfg5, ray_multiplier=2): every lane
 // owns two coarse and two fine samples (element e = slot*64 + lane), the field is marched 64 points
 // at a time, and the merge ranks all 2S keys against each other.
-template <int TEX, bool ATT, bool TAPS, int PREC, bool VD = false>
+template <int TEX, bool ATT, bool TAPS, int PREC, bool VD = false, bool FAST = false>
 __global__ __launch_bounds__(256, 2) void render_fwd_wide_kernel(RenderKernelParams k) {
   constexpr int kImg = VD ? kVdImageFloats : kLdsImageFloats;
   __shared__ __attribute__((aligned(16))) float lds[kImg];
@@ -1568,9 +1626,37 @@ __global__ __launch_bounds__(256, 2) void render_fwd_wide_kernel(RenderKernelPar
         val[j] = e < S;
         const float nz = (k.noise_c && val[j]) ? k.noise_c[rs + e] : 0.0f;
         tc[j] = val[j] ? stratified_depth(near, far, e, S, nz, k.noise_c != nullptr) : 0.0f;
-        SampleOut q = field_wave<TEX, ATT, true, PREC, VD>(P, k.scene_range, lane, ox + dx * tc[j], oy + dy * tc[j], oz + dz * tc[j],
-                                                           val[j], nullptr, nullptr, stage, nullptr, k.xray, (int)ray);
-        sc[j] = q.sigma; rc[j] = q.r; gc[j] = q.g; bc[j] = q.b;
+      }
+      float odc[2] = {0.0f, 0.0f};   // FAST: optical depth of each coarse sample
+      if constexpr (FAST) {
+        // front to back in steps of 32 samples; stop once the optical depth so far exceeds -ln(eps)
+        float tn[2];
+        next_elem<2>(tc, tn, lane);
+        float od_run = 0.0f;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          sc[j] = rc[j] = gc[j] = bc[j] = 0.0f;
+          const float dl = (j * 64 + lane < S - 1) ? (tn[j] - tc[j]) * dnorm : 0.0f;
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            const bool mine = (lane >> 5) == h;
+            if (od_run <= k.fast_od) {
+              SampleOut q = field_wave<TEX, ATT, true, PREC, VD>(P, k.scene_range, lane, ox + dx * tc[j], oy + dy * tc[j],
+                                                                 oz + dz * tc[j], val[j] && mine, nullptr, nullptr, stage,
+                                                                 nullptr, k.xray, (int)ray);
+              if (mine && val[j]) { sc[j] = q.sigma; rc[j] = q.r; gc[j] = q.g; bc[j] = q.b; }
+              od_run += uniform_f32(wave_sum((mine && val[j]) ? q.sigma * dl : 0.0f));
+            }
+          }
+          odc[j] = sc[j] * dl;
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          SampleOut q = field_wave<TEX, ATT, true, PREC, VD>(P, k.scene_range, lane, ox + dx * tc[j], oy + dy * tc[j], oz + dz * tc[j],
+                                                             val[j], nullptr, nullptr, stage, nullptr, k.xray, (int)ray);
+          sc[j] = q.sigma; rc[j] = q.r; gc[j] = q.g; bc[j] = q.b;
+        }
       }
       int n = S;
       float dep[4], sig[4], cr[4], cg[4], cb[4];
@@ -1591,10 +1677,39 @@ __global__ __launch_bounds__(256, 2) void render_fwd_wide_kernel(RenderKernelPar
         for (int j = 0; j < 2; ++j) u[j] = val[j] ? k.noise_f[(size_t)ray * k.noise_f_stride + j * 64 + lane] : 0.0f;
         wave_lds_fence();
         resample_ray_wide<2>(slab, sc, tc, S, dnorm, u, lane, tf, wtap, smtap, ind);
+        bool vfine[2] = {val[0], val[1]};
+        if constexpr (FAST) {
+          // first coarse sample in front of which the transmittance is below eps; fine samples behind it are dropped
+          const float inc0 = wave_incl_scan_add_f32(odc[0]);
+          const float carry = bits2f((uint32_t)__builtin_amdgcn_readlane((int)f2bits(inc0), 63));
+          const float inc1 = carry + wave_incl_scan_add_f32(odc[1]);
+          const uint64_t dm0 = __ballot(val[0] && (inc0 - odc[0]) > k.fast_od);
+          const uint64_t dm1 = __ballot(val[1] && (inc1 - odc[1]) > k.fast_od);
+          float t_dead = INFINITY;
+          if (dm0) t_dead = bits2f((uint32_t)__builtin_amdgcn_readlane((int)f2bits(tc[0]), (int)__builtin_ctzll(dm0)));
+          else if (dm1) t_dead = bits2f((uint32_t)__builtin_amdgcn_readlane((int)f2bits(tc[1]), (int)__builtin_ctzll(dm1)));
+          const bool l0 = val[0] && tf[0] <= t_dead, l1 = val[1] && tf[1] <= t_dead;
+          const uint64_t lm0 = __ballot(l0), lm1 = __ballot(l1);
+          const int n0 = __builtin_popcountll(lm0), nl = n0 + __builtin_popcountll(lm1);
+          const uint64_t below = (1ull << lane) - 1ull;
+          const int b0 = __builtin_popcountll(lm0 & below), b1 = __builtin_popcountll(lm1 & below);
+          const int p0 = l0 ? b0 : nl + (lane - b0);
+          const int p1 = l1 ? n0 + b1 : nl + (64 - n0) + (lane - b1);
+          wave_lds_fence();
+          slab.cdf[p0] = tf[0];
+          slab.cdf[p1] = tf[1];
+          wave_lds_fence();
+          tf[0] = slab.cdf[lane];
+          tf[1] = slab.cdf[64 + lane];
+          wave_lds_fence();
+          vfine[0] = lane < nl;
+          vfine[1] = 64 + lane < nl;
+        }
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
           SampleOut q = field_wave<TEX, ATT, true, PREC, VD>(P, k.scene_range, lane, ox + dx * tf[j], oy + dy * tf[j], oz + dz * tf[j],
-                                                             val[j], nullptr, nullptr, stage, nullptr, k.xray, (int)ray);
+                                                             vfine[j], nullptr, nullptr, stage, nullptr, k.xray, (int)ray);
+          if (FAST && !vfine[j]) { q.sigma = 0.0f; q.r = 0.0f; q.g = 0.0f; q.b = 0.0f; }
           dep[2 + j] = tf[j]; sig[2 + j] = q.sigma; cr[2 + j] = q.r; cg[2 + j] = q.g; cb[2 + j] = q.b;
           eidx[2 + j] = val[j] ? S + j * 64 + lane : 0x7fffffff;
           if constexpr (TAPS) {
@@ -1728,6 +1843,11 @@ extern "C" int nfi_render_fwd(const nfi_render_args* a, nfi_stream_t stream) {
   k.tile_order = (((a->tuning >> 2) & 1) == 0 && (a->width % 8 == 0) && (a->height % 8 == 0)) ? 1 : 0;
   k.prof = (unsigned long long*)a->profile_cycles;
   k.xray = a->ray_features;
+  const bool fast = a->fast_termination > 0.0f;
+  REQUIRE(a->fast_termination >= 0.0f && a->fast_termination < 1.0f, "render: fast_termination must be in [0,1)");
+  REQUIRE(!fast || !(any_tap || a->profile_cycles || a->ray_features || ((a->tuning >> 3) & 1)),
+          "render: fast_termination cannot be combined with stage taps, the cycle profile, the view-direction decoder or the exact-fp32 MLP");
+  k.fast_od = fast ? -logf(a->fast_termination) : 0.0f;
   REQUIRE(!(a->ray_features && a->profile_cycles), "render: no cycle profile with the view-direction decoder");
   // persistent 1-D grid: OCC blocks of 4 waves per CU, never more blocks than rays need
   // 2 blocks (8 waves) per CU: with the whole 256-VGPR budget the field tile keeps more loads and MFMA chains in
@@ -1741,7 +1861,8 @@ extern "C" int nfi_render_fwd(const nfi_render_args* a, nfi_stream_t stream) {
   const bool strict = ((a->tuning >> 3) & 1) != 0;   // exact-fp32 MLP instead of the split-fp16 one
 #define NFI_LAUNCH_RENDER(TEX, ATT)                                                                                   \
   do {                                                                                                                \
-    if (k.prof) hipLaunchKernelGGL((render_fwd_kernel<TEX, ATT, 2, false, 1, true>), grid, dim3(256), 0, s, k);         \
+    if (fast) hipLaunchKernelGGL((render_fwd_kernel<TEX, ATT, 2, false, 1, false, false, true>), grid, dim3(256), 0, s, k); \
+    else if (k.prof) hipLaunchKernelGGL((render_fwd_kernel<TEX, ATT, 2, false, 1, true>), grid, dim3(256), 0, s, k);    \
     else if (any_tap && strict) hipLaunchKernelGGL((render_fwd_kernel<TEX, ATT, 2, true, 0>), grid, dim3(256), 0, s, k); \
     else if (any_tap) hipLaunchKernelGGL((render_fwd_kernel<TEX, ATT, 2, true, 1>), grid, dim3(256), 0, s, k);          \
     else if (strict) hipLaunchKernelGGL((render_fwd_kernel<TEX, ATT, 2, false, 0>), grid, dim3(256), 0, s, k);          \
@@ -1749,7 +1870,8 @@ extern "C" int nfi_render_fwd(const nfi_render_args* a, nfi_stream_t stream) {
   } while (0)
 #define NFI_LAUNCH_RENDER_WIDE(TEX, ATT)                                                                             \
   do {                                                                                                                \
-    if (any_tap && strict) hipLaunchKernelGGL((render_fwd_wide_kernel<TEX, ATT, true, 0>), grid, dim3(256), 0, s, k);   \
+    if (fast) hipLaunchKernelGGL((render_fwd_wide_kernel<TEX, ATT, false, 1, false, true>), grid, dim3(256), 0, s, k);   \
+    else if (any_tap && strict) hipLaunchKernelGGL((render_fwd_wide_kernel<TEX, ATT, true, 0>), grid, dim3(256), 0, s, k); \
     else if (any_tap) hipLaunchKernelGGL((render_fwd_wide_kernel<TEX, ATT, true, 1>), grid, dim3(256), 0, s, k);        \
     else if (strict) hipLaunchKernelGGL((render_fwd_wide_kernel<TEX, ATT, false, 0>), grid, dim3(256), 0, s, k);        \
     else hipLaunchKernelGGL((render_fwd_wide_kernel<TEX, ATT, false, 1>), grid, dim3(256), 0, s, k);                    \

@@ -317,9 +317,12 @@ TAP_NAMES = ('ray_origins', 'ray_directions', 'near_plane', 'far_plane', 'hit', 
 def render_fwd(cam2world, focal, height, width, num_samples, texels, decoder_image, scene_range, n_attention,
                attention_values=None, use_sdf=True, beta=None, alpha=None, bbox=None, center=None,
                noise_coarse=None, noise_fine=None, fine_sampling=True, white_background=True, taps=(),
-               skip_missed_rays=True, workspace=None, events=None, tuning=0, profile_cycles=None, ray_features=None):
+               skip_missed_rays=True, workspace=None, events=None, tuning=0, profile_cycles=None, ray_features=None,
+               fast_termination=0.0):
     """Fused forward render.  Returns dict(rgb [B,H,W,3], depth, mask [B,H,W], + requested taps).
-    ray_features: padded [B,H,W,48] per-ray view-direction features (decoder_pack_viewdir image)."""
+    ray_features: padded [B,H,W,48] per-ray view-direction features (decoder_pack_viewdir image).
+    fast_termination: 0 = exact; eps in (0,1) = opt-in transmittance-threshold termination + sample compaction (NOT
+    parity: rgb/mask change by O(eps), see include/nfi_hip.h)."""
     cam2world = _f32c(cam2world, 'tform_cam2world')
     B = cam2world.shape[0]
     dev = cam2world.device
@@ -374,7 +377,8 @@ def render_fwd(cam2world, focal, height, width, num_samples, texels, decoder_ima
             noise_fine=u, noise_fine_row_stride=ustride, rgb=out['rgb'], depth=out['depth'], mask=out['mask'],
             workspace=workspace, workspace_bytes=workspace.numel(), skip_missed_rays=int(skip_missed_rays),
             event_start=None if events is None else events[0], event_stop=None if events is None else events[1],
-            tuning=int(tuning), profile_cycles=profile_cycles, ray_features=ray_features, **tap_t)
+            tuning=int(tuning), profile_cycles=profile_cycles, ray_features=ray_features,
+            fast_termination=float(fast_termination), **tap_t)
     out.update(tap_t)
     out['_workspace'] = workspace
     return out

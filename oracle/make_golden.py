@@ -151,6 +151,14 @@ CASES = {
     'viewdir_density_rgb_coarse_only': dict(B=1, H=8, W=8, S=24, scene_range=0.55, radius=1.6, focal=1.0254,
                                             white=False, fine=False, randomize=True, sdf=False, A=0, alpha=1.0,
                                             beta=0.1, bbox=False, ortho=False, viewdir=True),
+    # principal-point shift (`center`, nerf_utils.py:42-46; only data/loaders.py:185 ever sets it)
+    'persp_center_fine_rand': dict(B=2, H=10, W=12, S=16, scene_range=0.55, radius=2.0, focal=1.0254,
+                                   white=True, fine=True, randomize=True, sdf=True, A=10, alpha=0.05,
+                                   beta=0.1, bbox=False, ortho=False, center=True),
+    # compute_coords (the query points composited in the semantics slot, run.py:337-338) + force_no_cam_grad
+    'persp_coords_black_fine_rand': dict(B=2, H=8, W=8, S=16, scene_range=0.55, radius=1.6, focal=1.0254,
+                                         white=False, fine=True, randomize=True, sdf=True, A=10, alpha=0.05,
+                                         beta=0.1, bbox=False, ortho=False, coords=True),
     'persp_s96_black_fine_det': dict(B=1, H=6, W=6, S=96, scene_range=0.55, radius=1.3, focal=1.0254,
                                      white=False, fine=True, randomize=False, sdf=True, A=10, alpha=0.02,
                                      beta=0.1, bbox=False, ortho=False),
@@ -209,6 +217,10 @@ def run_case(name, c, planes_all):
         start = -0.8 + 0.2 * torch.rand(B, 2, generator=g)
         extent = 1.4 + 0.4 * torch.rand(B, 2, generator=g)
         bbox = torch.stack((start, extent), dim=1)           # [B,2,2]
+    center = None
+    if c.get('center'):
+        center = 0.5 + 0.15 * (torch.rand(B, 2, generator=g) - 0.5)       # principal point around the image centre
+    coords = bool(c.get('coords', False))
     num_ws = 15 if A > 0 else 14
     ws = torch.randn(B, num_ws, 512, generator=g)
     att = None
@@ -241,8 +253,9 @@ def run_case(name, c, planes_all):
     noise_gen = torch.Generator().manual_seed(4321)
     with torch.no_grad(), NoiseTap(noise_gen) as tap:
         rgb, depth, mask, normals, sem, _ = render(
-            gen, H, W, cam, focal, None, bbox, ws, S, randomize=c['randomize'],
-            compute_semantics=(A > 0), extra_model_inputs=extra_in)
+            gen, H, W, cam, focal, center, bbox, ws, S, randomize=c['randomize'],
+            compute_semantics=(A > 0 and not coords), compute_coords=coords, extra_model_inputs=extra_in,
+            force_no_cam_grad=coords)
     rec.restore()
     noise_c = tap.draws[0] if c['randomize'] else None
     noise_f = tap.draws[1] if (c['randomize'] and c['fine']) else None
@@ -259,8 +272,8 @@ def run_case(name, c, planes_all):
     # ---- oracle must reproduce the reference bit for bit -------------------
     with torch.no_grad():
         o = orc.render(planes, w1, b1, w2, b2, cam, focal, H, W, S, c['scene_range'],
-                       white_background=c['white'], fine_sampling=c['fine'], bbox=bbox,
-                       noise_coarse=noise_c, noise_fine=noise_f, use_sdf=c['sdf'], beta=beta,
+                       white_background=c['white'], fine_sampling=c['fine'], bbox=bbox, center=center,
+                       want_coords=coords, noise_coarse=noise_c, noise_fine=noise_f, use_sdf=c['sdf'], beta=beta,
                        alpha=alpha, attention_values=att, want_semantics=(A > 0), viewdir=viewdir)
 
     def same(a, b, what):
@@ -269,8 +282,8 @@ def run_case(name, c, planes_all):
     same(o['rgb'], rgb, 'rgb')
     same(o['depth'], depth, 'depth')
     same(o['mask'], mask, 'mask')
-    if A > 0:
-        same(o['semantics'], sem, 'semantics')
+    if A > 0 or coords:
+        same(o['semantics'], sem, 'semantics / coords map')
     same(o['ro'], rec.log['ro'][0].expand_as(o['ro']), 'ro')
     same(o['near'], rec.log['near'][0], 'near')
     same(o['far'], rec.log['far'][0], 'far')
@@ -294,9 +307,11 @@ def run_case(name, c, planes_all):
         out['focal'] = focal
     if bbox is not None:
         out['bbox'] = bbox
+    if center is not None:
+        out['center'] = center
     if att is not None:
         out['attention_values'] = att
-        out['ref_semantics'] = sem
+        out['ref_coords_map' if coords else 'ref_semantics'] = sem
     if c['sdf']:
         out['beta'] = beta
         out['alpha'] = alpha
@@ -315,7 +330,51 @@ def run_case(name, c, planes_all):
     return out, meta
 
 
+def check_cfg1():
+    """BASELINE cfg1 at its exact shape on the CPU: the REAL Generator (StyleGAN2 synthesis network and all, random
+    init, seed 1234) renders 4 scenes at 64x64 with 32 coarse samples (and once more with 32 + 32) through the live
+    run.py::render; the oracle, fed the planes / colour table the generator produced and the same two noise draws,
+    must reproduce rgb, depth and mask bit for bit.  Nothing is written."""
+    B, R, S = 4, 64, 32
+    for fine in (False, True):
+        cfg_args = types.SimpleNamespace(use_viewdir=False, use_sdf=True, attention_values=10, fine_sampling=fine)
+        dataset_config = {'scene_range': 0.55, 'white_background': True}
+        render, _ = load_reference_render(cfg_args, dataset_config)
+        torch.manual_seed(1234)
+        gen = ref_gen.Generator(512, 0.55, attention_values=10, use_sdf=True, disable_stylegan_noise=True).eval()
+        g = torch.Generator().manual_seed(5)
+        cam = look_at_cameras(B, 2.0, g)
+        focal = torch.full((B,), 1.0254)
+        z = torch.randn(B, 512, generator=g)
+        with torch.no_grad():
+            # the random-init field is almost empty (SURVEY 8(d)): centre the distance output so that surfaces exist
+            probe = (torch.rand(B, 2048, 3, generator=g) * 2 - 1) * 0.55
+            d = gen(None, z, ['sampler'])['sampler'](probe, ['sdf_distance'])['sdf_distance']
+            gen.decoder.net[2].bias[0] -= d.median()
+            gen.alpha.fill_(0.05)
+        seen = {}
+        hook = gen.synthesis_network.register_forward_hook(lambda m, i, o_: seen.__setitem__('planes', o_.detach()))
+        noise_gen = torch.Generator().manual_seed(4321)
+        with torch.no_grad(), NoiseTap(noise_gen) as tap:
+            rgb, depth, mask, _, _, extra = render(gen, R, R, cam, focal, None, None, z, S,
+                                                   extra_model_outputs=['attention_values'])
+        hook.remove()
+        planes = seen['planes'].view(B, 3, 32, 256, 256)
+        dec = gen.decoder.net
+        with torch.no_grad():
+            o = orc.render(planes, dec[0].weight, dec[0].bias, dec[2].weight, dec[2].bias, cam, focal, R, R, S, 0.55,
+                           white_background=True, fine_sampling=fine, noise_coarse=tap.draws[0],
+                           noise_fine=tap.draws[1] if fine else None, use_sdf=True, beta=gen.beta, alpha=gen.alpha,
+                           attention_values=extra['attention_values'])
+        for k, ref in (('rgb', rgb), ('depth', depth), ('mask', mask)):
+            assert torch.equal(o[k], ref), ('cfg1', fine, k, (o[k] - ref).abs().max().item())
+        print('cfg1 (B=4, 64x64, 32%s samples, real Generator): oracle == reference bit for bit; mask mean %.3f' % (
+            '+32' if fine else '', mask.mean().item()))
+
+
 def main():
+    if '--cfg1' in sys.argv:
+        return check_cfg1()
     import json
     gold = os.path.join(ROOT, 'tests', 'golden')
     os.makedirs(gold, exist_ok=True)

@@ -350,8 +350,11 @@ def composite(sigma, rgb, rd, t, semantics=None, white_background=True):
 def render(planes, w1, b1, w2, b2, cam2world, focal, height, width, num_samples,
            scene_range, white_background=True, fine_sampling=True, bbox=None, center=None,
            noise_coarse=None, noise_fine=None, use_sdf=True, beta=None, alpha=None,
-           attention_values=None, want_semantics=False, viewdir=None):
+           attention_values=None, want_semantics=False, viewdir=None, want_coords=False):
     """Oracle restatement of run.py:176-350 given precomputed planes.
+
+    want_coords: run.py's compute_coords - the query points themselves are composited in the semantics slot
+    (run.py:337-338; the sampler returns coords = x_in, generator.py:643-644).
 
     noise_coarse [B,H,W,S] / noise_fine [B*H*W,S] in [0,1) or None (deterministic:
     no jitter, linspace u).  Returns a dict with every stage boundary."""
@@ -368,6 +371,8 @@ def render(planes, w1, b1, w2, b2, cam2world, focal, height, width, num_samples,
     sigma = q['sigma'].view(*shp)
     rgb = q['rgb'].view(*shp, 3)
     sem = q['semantics'].view(*shp, -1) if (want_semantics and 'semantics' in q) else None
+    if want_coords:
+        sem = x_c
     o.update(t_coarse=t_c, sigma_coarse=sigma, rgb_coarse=rgb, outside_coarse=q['outside'].view(*shp),
              sdf_coarse=q['sdf'].view(*shp))
     t = t_c
@@ -389,7 +394,7 @@ def render(planes, w1, b1, w2, b2, cam2world, focal, height, width, num_samples,
         sigma = torch.cat((sigma, sigma_f), dim=-1).gather(-1, perm)
         rgb = torch.cat((rgb, rgb_f), dim=-2).gather(-2, perm.unsqueeze(-1).expand(-1, -1, -1, -1, 3))
         if sem is not None:
-            sem_f = qf['semantics'].view(*shp[:3], -1, sem.shape[-1])
+            sem_f = x_f if want_coords else qf['semantics'].view(*shp[:3], -1, sem.shape[-1])
             sem = torch.cat((sem, sem_f), dim=-2).gather(
                 -2, perm.unsqueeze(-1).expand(-1, -1, -1, -1, sem.shape[-1]))
     rgb_map, depth_map, acc, sem_map, wts = composite(sigma, rgb, rd, t, sem, white_background)

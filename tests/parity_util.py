@@ -12,7 +12,8 @@ def oracle_render(meta, t, device='cpu'):
         return orc.render(
             g['planes'], g['w1'], g['b1'], g['w2'], g['b2'], g['cam2world'], g.get('focal'),
             meta['H'], meta['W'], meta['S'], meta['scene_range'], white_background=meta['white'],
-            fine_sampling=meta['fine'], bbox=g.get('bbox'), noise_coarse=g.get('noise_coarse'),
+            fine_sampling=meta['fine'], bbox=g.get('bbox'), center=g.get('center'),
+            want_coords=bool(meta.get('coords')), noise_coarse=g.get('noise_coarse'),
             noise_fine=g.get('noise_fine'), use_sdf=meta['sdf'], beta=g.get('beta'), alpha=g.get('alpha'),
             attention_values=g.get('attention_values'), want_semantics=meta['A'] > 0, viewdir=viewdir_of(g))
 
@@ -37,7 +38,7 @@ def hip_render(meta, t, dev, taps=(), skip_missed_rays=False, texel_dtype=ops.TE
     return ops.render_fwd(
         g('cam2world'), g('focal'), meta['H'], meta['W'], meta['S'], texels, image, meta['scene_range'], meta['A'],
         attention_values=g('attention_values'), use_sdf=meta['sdf'], beta=g('beta'), alpha=g('alpha'),
-        bbox=g('bbox'), noise_coarse=g('noise_coarse'), noise_fine=g('noise_fine'), fine_sampling=meta['fine'],
+        bbox=g('bbox'), center=g('center'), noise_coarse=g('noise_coarse'), noise_fine=g('noise_fine'), fine_sampling=meta['fine'],
         white_background=meta['white'], taps=taps, skip_missed_rays=skip_missed_rays,
         ray_features=ops.pad_ray_features(t['viewdir_x'].to(dev)) if 'viewdir_x' in t else None)
 

@@ -21,15 +21,52 @@ def _last_json(out):
 
 
 def test_bench_single_process(gpu_device):
-    r = subprocess.run([sys.executable, 'bench.py', '--steps', '3', '--warmup', '1', '--no-cpu-baseline',
+    r = subprocess.run([sys.executable, 'bench.py', '--steps', '3', '--warmup', '1', '--no-cpu-baseline', '--no-extras',
                         '--images-per-gpu', '2'], cwd=ROOT, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     j = _last_json(r.stdout)
     for k in REQUIRED:
         assert k in j, k
     assert j['n_gpus'] == 1 and j['steps'] == 3 and j['value'] > 1e6 and j['dtype'] == 'f32'
+    assert 'split-fp16' in j['config']['mlp']
+    assert j['ms_per_step_stats']['min'] <= j['ms_per_step_stats']['median'] <= j['ms_per_step_stats']['max']
     rf = j['roofline']
-    assert rf['bound'] in ('hbm', 'mfma') and abs(rf['frac'] - rf['achieved'] / rf['peak']) < 1e-9
+    # a roofline is a bound: the kernel's binding resource is instruction issue, and the fraction cannot exceed 1
+    assert rf['bound'] == 'valu-issue' and rf['source'] and 0.0 < rf['frac'] <= 1.0
+    assert abs(rf['frac'] - rf['achieved'] / rf['peak']) < 1e-9
+    lv = rf['levels']
+    for k in ('l2_requests', 'fabric', 'hbm_compulsory'):
+        assert 0.0 < lv[k]['frac'] <= 1.0, (k, lv[k])
+    assert lv['gather_stream_algorithmic']['x_hbm_peak'] > 0
+
+
+def test_bench_parity_figure(gpu_device):
+    """The bench line carries its own parity check: one image of the timed workload against the CPU oracle."""
+    r = subprocess.run([sys.executable, 'bench.py', '--steps', '3', '--warmup', '1', '--no-extras'], cwd=ROOT,
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    j = _last_json(r.stdout)
+    assert j['parity']['ok'] and max(j['parity'][k] for k in ('rgb', 'depth', 'mask')) <= 1e-4, j['parity']
+    assert j['parity']['mask_mean'] > 0.05
+    assert j['cpu_baseline']['kind'] == 'port' and j['cpu_baseline']['value'] > 0
+
+
+def test_bench_train_mode_single_rank_rccl(gpu_device):
+    """--mode train under torch.distributed.run with one rank and --force-dist: the RCCL process group, the bucketed
+    gradient all-reduce launched from backward hooks and the per-rank timing report."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0')
+    r = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '1',
+                        '--master-addr', '127.0.0.1', '--master-port', '29519', 'bench.py', '--gpus', '1', '--mode', 'train',
+                        '--steps', '3', '--warmup', '2', '--force-dist'],
+                       cwd=ROOT, capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, (r.stdout[-1000:], r.stderr[-3000:])
+    j = _last_json(r.stdout)
+    assert j['n_gpus'] == 1 and j['value'] > 1e5 and 'RCCL all_reduce' in j['config']['collective']
+    assert j['config']['gradient_bytes_per_step'] > 120e6
+    pr = j['per_rank'][0]
+    assert pr['fwd_bwd_ms'] > 0 and pr['allreduce_exposed_ms'] >= 0 and pr['buckets_launched_in_backward'] >= 1
+    import math
+    assert math.isfinite(pr['loss'])
 
 
 def test_bench_distributed_code_path(gpu_device):

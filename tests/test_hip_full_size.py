@@ -121,6 +121,51 @@ def test_cfg2_batch_properties(gpu_device):
         assert torch.equal(torch.cat((lo[k], hi[k])), a[k]), 'image sharding changed ' + k
 
 
+@pytest.mark.parametrize('radius,seed', [(2.0, 1234), (1.3, 77)])
+def test_cfg2_full_batch_against_gpu_oracle(gpu_device, radius, seed):
+    """The headline configuration itself (8 images x 128x128 x (64+64)), chairs-like (44 % of the rays miss the cube)
+    and with every ray crossing it, compared pixel by pixel and index by index with the oracle evaluated with
+    PyTorch-ROCm ops on the same GPU (the reference's own GPU path) on identical inputs and noise."""
+    d = make_inputs(8, gpu_device, radius=radius, seed=seed)
+    r = hip(d, taps=('perm', 't_fine'))
+    fast = hip(d)                                    # the no-tap kernel with the missed-ray skip = what bench.py times
+    o = oracle(d, gpu_device)
+    for k in ('rgb', 'depth', 'mask'):
+        e = err(r[k], o[k])
+        assert e['max'] <= 1e-4 and e['nonfinite'] == 0, (k, e)
+        assert torch.equal(fast[k], r[k]), k
+    flips = (r['perm'].long() != o['perm']).float().mean().item()
+    assert flips <= 1e-3, flips
+    assert err(r['t_fine'], o['t_fine'])['max'] <= 1e-4
+    assert o['mask'].mean() > 0.15
+
+
+def test_fast_termination_error_bound(gpu_device):
+    """Opt-in, non-parity fast mode (transmittance-threshold termination + sample compaction by wave ballot): the
+    deviation from the exact path is bounded by the threshold, for both kernels (S <= 64 and the wide one), and
+    eps = 0 is the exact path bit for bit."""
+    for R_, S_, B_ in ((128, 64, 2), (128, 128, 1)):
+        d = make_inputs(B_, gpu_device, radius=1.6, seed=5, R=R_, S=S_)
+        # a sharp, opaque scene: alpha = 0.01 -> sigma up to 100, the regime the mode is meant for
+        d['alpha'] = torch.tensor([0.01], device=gpu_device)
+        texels = ops.planes_to_texels(d['planes'])
+        image = ops.decoder_pack(d['w1'], d['b1'], d['w2'], d['b2'], A)
+
+        def run(eps):
+            return ops.render_fwd(d['cam'], d['focal'], R_, R_, S_, texels, image, 0.55, A, d['att'], True, d['beta'],
+                                  d['alpha'], noise_coarse=d['noise_c'], noise_fine=d['noise_f'], fast_termination=eps)
+        exact_, again = run(0.0), run(0.0)
+        assert torch.equal(exact_['rgb'], again['rgb'])
+        for eps in (1e-2, 1e-3, 1e-4):
+            f = run(eps)
+            e_rgb, e_mask = err(f['rgb'], exact_['rgb']), err(f['mask'], exact_['mask'])
+            # colours live in [-1,1] + white background: |d rgb| <= ~3 eps; in practice well below
+            assert e_rgb['max'] <= 4 * eps and e_mask['max'] <= 2 * eps and e_rgb['nonfinite'] == 0, (S_, eps, e_rgb, e_mask)
+    with pytest.raises(RuntimeError):
+        ops.render_fwd(d['cam'], d['focal'], R_, R_, S_, texels, image, 0.55, A, d['att'], True, d['beta'], d['alpha'],
+                       noise_coarse=d['noise_c'], noise_fine=d['noise_f'], fast_termination=1e-3, taps=('perm',))
+
+
 def test_all_rays_hit_geometry(gpu_device):
     """cars-like geometry (radius 1.3): every ray crosses the cube, nothing is skipped."""
     d = make_inputs(2, gpu_device, radius=1.3, seed=77)

@@ -57,11 +57,11 @@ def test_texel_layout_roundtrip(gpu_device):
 def test_rays_and_planes(case):
     name, meta, t, o, dev = case
     g = lambda k: t[k].to(dev) if k in t else None
-    ro, rd = ops.raygen(meta['H'], meta['W'], g('focal'), g('cam2world'), g('bbox'), None, normalize=True)
+    ro, rd = ops.raygen(meta['H'], meta['W'], g('focal'), g('cam2world'), g('bbox'), g('center'), normalize=True)
     exact(ro, o['ro'], 'ray origins')
     close(rd, o['rd'], 2e-7, 'ray directions')          # <= 1 ulp
-    ro_r, rd_r = ops.raygen(meta['H'], meta['W'], g('focal'), g('cam2world'), g('bbox'), None, normalize=False)
-    ro_o, rd_o = orc.ray_bundle(meta['H'], meta['W'], t.get('focal'), t['cam2world'], t.get('bbox'))
+    ro_r, rd_r = ops.raygen(meta['H'], meta['W'], g('focal'), g('cam2world'), g('bbox'), g('center'), normalize=False)
+    ro_o, rd_o = orc.ray_bundle(meta['H'], meta['W'], t.get('focal'), t['cam2world'], t.get('bbox'), t.get('center'))
     close(rd_r, rd_o, 2e-7, 'raw directions')
     near, far, hit = ops.near_far(o['ro'].contiguous().to(dev), o['rd'].to(dev), meta['scene_range'])
     exact(near, o['near'], 'near'); exact(far, o['far'], 'far'); exact(hit, o['hit'], 'hit')

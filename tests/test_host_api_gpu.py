@@ -121,6 +121,51 @@ def test_render_dropin_staged_semantics(setup):
     close(sem, o['semantics'], 1e-4, 'semantic map')
 
 
+def test_render_dropin_coords_and_force_no_cam_grad(setup):
+    """compute_coords: the query points are composited in the semantics slot (run.py:337-338); force_no_cam_grad
+    (run.py:211-214): same pixels, no gradient into the camera while the latent still gets one."""
+    model, cam, focal, z = setup
+    cfg = types.SimpleNamespace(use_viewdir=False, use_sdf=True, attention_values=10, fine_sampling=True)
+    dcfg = {'scene_range': 0.55, 'white_background': False}
+    render = nfi_render.make_render(cfg, dcfg)
+    H, W, S = 12, 20, 32
+    with torch.no_grad(), RandTap() as tap:
+        rgb, depth, mask, normals, coords_map, _ = render(model, H, W, cam, focal, None, None, z, S, compute_coords=True)
+    assert normals is None and coords_map.shape == (2, H, W, 3)
+    with torch.no_grad():
+        planes, att = model.planes_and_values(z)
+        dec = model.decoder.net
+        cpu = lambda t: t.detach().cpu()
+        o = orc.render(cpu(planes), cpu(dec[0].weight), cpu(dec[0].bias), cpu(dec[2].weight), cpu(dec[2].bias), cpu(cam),
+                       cpu(focal), H, W, S, 0.55, white_background=False, noise_coarse=tap.draws[0],
+                       noise_fine=tap.draws[1], use_sdf=True, beta=cpu(model.beta), alpha=cpu(model.alpha),
+                       attention_values=cpu(att), want_coords=True)
+    close(rgb, o['rgb'], 1e-4, 'rgb'); close(mask, o['mask'], 1e-4, 'mask')
+    close(coords_map, o['semantics'], 1e-4, 'composited coordinates')
+    # gradients: with force_no_cam_grad the camera and focal length get none, the latent does
+    cam_g, focal_g, z_g = cam.clone().requires_grad_(), focal.clone().requires_grad_(), z.clone().requires_grad_()
+    draws = iter(tap.draws)
+    real_rand = torch.rand
+    torch.rand = lambda *a, **k: next(draws).to(cam.device)
+    try:
+        rgb2, _, mask2, _, _, _ = render(model, H, W, cam_g, focal_g, None, None, z_g, S, force_no_cam_grad=True)
+    finally:
+        torch.rand = real_rand
+    close(rgb2, o['rgb'], 1e-4, 'rgb (force_no_cam_grad)')
+    g_cam, g_focal, g_z = torch.autograd.grad(rgb2.sum() + mask2.sum(), [cam_g, focal_g, z_g], allow_unused=True)
+    assert g_cam is None and g_focal is None
+    assert g_z is not None and torch.isfinite(g_z).all() and g_z.abs().sum() > 0
+    # and without it the camera does get one
+    draws = iter(tap.draws)
+    torch.rand = lambda *a, **k: next(draws).to(cam.device)
+    try:
+        rgb3, _, mask3, _, _, _ = render(model, H, W, cam_g, focal_g, None, None, z_g, S)
+    finally:
+        torch.rand = real_rand
+    g_cam, g_focal = torch.autograd.grad(rgb3.sum() + mask3.sum(), [cam_g, focal_g])
+    assert g_cam.abs().sum() > 0 and g_focal.abs().sum() > 0
+
+
 def test_nerf_utils_api(setup):
     model, cam, focal, z = setup
     H, W, S = 16, 16, 16
@@ -360,6 +405,52 @@ def test_regulariser_outputs(gpu_device):
     for name, a, b in zip(['basis', 'proj', 'w1', 'b1', 'w2', 'b2', 'beta'], got, ref_g):
         scale = b.abs().max().item()
         assert (a.cpu().double() - b).abs().max().item() <= 2e-3 * scale + 1e-9, (name, (a.cpu().double() - b).abs().max().item(), scale)
+
+
+def test_regulariser_outputs_with_view_direction_decoder(gpu_device):
+    """--use_viewdir models (33-output decoder): all four regulariser terms (the total-variation one used to fail on
+    the decoder shape) against the float64 oracle, which like the reference uses output row 0 only."""
+    import copy
+    torch.manual_seed(3)
+    model = StandInGenerator(0.55, attention_values=10, use_sdf=True, plane_res=32, use_viewdir=True).to(gpu_device).train()
+    nfi_gen.attach(model)
+    g = torch.Generator().manual_seed(5)
+    z = torch.randn(2, 512, generator=g).to(gpu_device)
+    names = ['sdf_eikonal_loss', 'sdf_distance_loss', 'total_variation_loss', 'entropy_loss']
+    draws = {}
+    real_rand_like, real_randn_like = torch.rand_like, torch.randn_like
+
+    def rand_like(t, **k):
+        draws['jitter'] = real_rand_like(t, **k).clamp_(1e-3, 1 - 1e-3)
+        return draws['jitter']
+
+    def randn_like(t, **k):
+        draws['perturb'] = real_randn_like(t, **k)
+        return draws['perturb']
+    torch.rand_like, torch.randn_like = rand_like, randn_like
+    try:
+        out = model(None, z, names)
+    finally:
+        torch.rand_like, torch.randn_like = real_rand_like, real_randn_like
+    assert set(out) == set(names)
+    dec = model.decoder.net
+    assert dec[2].weight.shape == (33, 64)
+    params = [model.synthesis_network.basis, dec[0].weight, dec[0].bias, dec[2].weight, dec[2].bias, model.beta]
+    weights = [1.0, 0.7, 3.0, 0.01]
+    got = torch.autograd.grad(sum(w * out[n].sum() for w, n in zip(weights, names)), params)
+    m64 = copy.deepcopy(model).cpu().double()
+    planes64, _ = m64.planes_and_values(z.cpu().double())
+    d64 = m64.decoder.net
+    p64 = [m64.synthesis_network.basis, d64[0].weight, d64[0].bias, d64[2].weight, d64[2].bias, m64.beta]
+    bins = orc.stratified_volume(2, 32, 0.55, draws['jitter'].cpu().double())
+    ref = orc.regularisers(planes64, *p64[1:5], bins, 0.55, True, m64.beta, draws['perturb'].cpu().double())
+    for n in names:
+        close(out[n], ref[n], 2e-4 * float(ref[n].detach().abs().max()) + 1e-6, n)
+    ref_g = torch.autograd.grad(sum(w * ref[n].sum() for w, n in zip(weights, names)), p64)
+    for name, a, b in zip(['basis', 'w1', 'b1', 'w2', 'b2', 'beta'], got, ref_g):
+        scale = b.abs().max().item()
+        assert (a.cpu().double() - b).abs().max().item() <= 2e-3 * scale + 1e-9, (name, (a.cpu().double() - b).abs().max().item(), scale)
+    assert got[3][1:].abs().max().item() == 0.0          # only the distance row of the 33-output layer is involved
 
 
 def test_wrapped_module_with_hip_regularisers(gpu_device):

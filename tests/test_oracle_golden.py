@@ -13,7 +13,8 @@ def run_oracle(meta, t):
     return orc.render(
         t['planes'], t['w1'], t['b1'], t['w2'], t['b2'], t['cam2world'], t.get('focal'),
         meta['H'], meta['W'], meta['S'], meta['scene_range'], white_background=meta['white'],
-        fine_sampling=meta['fine'], bbox=t.get('bbox'), noise_coarse=t.get('noise_coarse'),
+        fine_sampling=meta['fine'], bbox=t.get('bbox'), center=t.get('center'),
+        want_coords=bool(meta.get('coords')), noise_coarse=t.get('noise_coarse'),
         noise_fine=t.get('noise_fine'), use_sdf=meta['sdf'], beta=t.get('beta'), alpha=t.get('alpha'),
         attention_values=t.get('attention_values'), want_semantics=meta['A'] > 0,
         viewdir=dict(x=t['viewdir_x'], w3=t['w3'], b3=t['b3']) if 'viewdir_x' in t else None)
@@ -29,7 +30,10 @@ def test_oracle_matches_reference_vectors(name):
     if meta['fine']:
         keys += ['weights_coarse', 'weights_smooth', 'cdf', 'inds', 't_fine', 'sigma_fine', 'rgb_fine',
                  'perm', 't_sorted']
-    if meta['A'] > 0:
+    if meta.get('coords'):
+        keys += ['coords_map']
+        o['coords_map'] = o['semantics']
+    elif meta['A'] > 0:
         keys += ['semantics']
     for k in keys:
         ref = t['ref_' + k]

@@ -1,0 +1,33 @@
+#!/bin/bash
+# One GPU-box session: tests, parity report, bench (render + train), rocprofv3 stats + PMC of the render kernel.
+# usage (via gpurun): bash tools/gpu_session.sh <tag> [what...]   what: tests report bench train pmc bwd   (default: all)
+TAG=${1:-s}
+shift
+WHAT=${@:-tests report bench train pmc}
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+O=$R/gpurun_out/$TAG
+mkdir -p $O
+cd $R
+export HSA_ENABLE_IPC_MODE_LEGACY=0
+echo "reference checkout on the GPU box: $(ls -d /root/reference 2>&1)" > $O/env.txt
+rocm-smi --showproductname 2>/dev/null | head -8 >> $O/env.txt
+nproc >> $O/env.txt
+for w in $WHAT; do
+  case $w in
+    tests)
+      timeout 1500 python -m pytest tests -m gpu -q -x --durations=15 > $O/pytest.log 2>&1; echo "pytest rc=$?" >> $O/env.txt; tail -5 $O/pytest.log;;
+    report)
+      timeout 600 python tools/parity_report.py > $O/parity_report.json 2> $O/parity_report.err; echo "report rc=$?" >> $O/env.txt;;
+    bench)
+      timeout 900 python bench.py > $O/bench.json 2> $O/bench.err; echo "bench rc=$?" >> $O/env.txt; tail -c 600 $O/bench.json;;
+    train)
+      timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29541 \
+        bench.py --gpus 1 --mode train --steps 30 --warmup 5 --force-dist > $O/train.json 2> $O/train.err; echo "train rc=$?" >> $O/env.txt; tail -c 1500 $O/train.json;;
+    pmc)
+      timeout 1200 python tools/pmc_collect.py --kernel render_fwd_kernel --out $O/pmc_render_fwd.json --marched-from-bench -- \
+        python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras > $O/pmc.log 2>&1; echo "pmc rc=$?" >> $O/env.txt; tail -30 $O/pmc.log;;
+    bwd)
+      timeout 600 python tools/bench_backward.py > $O/bench_backward.log 2>&1; tail -20 $O/bench_backward.log;;
+  esac
+done
+cat $O/env.txt
