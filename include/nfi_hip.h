@@ -424,6 +424,40 @@ typedef struct nfi_render_args {
 size_t nfi_render_workspace_bytes(int64_t n_rays);
 int nfi_render_fwd(const nfi_render_args* a, nfi_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Neighbours of the renderer in the inversion loop.
+ *
+ * 2-D augmentation warp: the image part of augment_impl (run.py:720-769): mat = [[cos r, -sin r, tx], [sin r, cos r,
+ * -ty]], scaled by `scale`, translation column re-projected (run.py:745-752), F.affine_grid(align_corners=False) +
+ * F.grid_sample(bilinear, padding zeros, align_corners=False); white_background: (img - 1) is warped and 1 added
+ * back (run.py:755-764).  The inversion loss warps cat(prediction, target) 15 times per step (run.py:2216-2231).
+ *   image / warped [N,C,H,W]; rot [N], scale [N] or NULL (= 1), translation [N,2] (the host's random draws).
+ *   bwd: g_warped [N,C,H,W] -> g_image [N,C,H,W] (zeroed inside; the adjoint of the forward w.r.t. the image).
+ * ------------------------------------------------------------------------------------------ */
+typedef struct nfi_warp_args {
+  int n_images, channels, height, width;
+  const float* image; float* warped;            /* forward */
+  const float* g_warped; float* g_image;        /* backward */
+  const float* rot; const float* scale; const float* translation;
+  int white_background;
+} nfi_warp_args;
+int nfi_affine_warp_fwd(const nfi_warp_args* a, nfi_stream_t stream);
+int nfi_affine_warp_bwd(const nfi_warp_args* a, nfi_stream_t stream);
+
+/* Image metrics of the inversion / evaluation loops: lib/metrics.py psnr (30-45) and iou (79-94), per image.
+ *   pred / target: n_images x elements_per_image values in [0,1] (any layout, identical for both) -> psnr [n_images]
+ *   = min(60, -10 log10(mean((clamp(pred) - clamp(target))^2)));
+ *   mask_pred / mask_real: n_images x elements_per_mask -> iou [n_images] = (|a & b| + 1e-6) / (|a | b| + 1e-6) of
+ *   the masks thresholded at 0.5.  out_of_range (int, optional): set to 1 if any input violates the reference's
+ *   range_check (-0.1 < v < 1.1; lib/metrics.py:22-27), 0 otherwise.  Either metric may be skipped (NULL output). */
+typedef struct nfi_metrics_args {
+  int n_images;
+  const float* pred; const float* target; int64_t elements_per_image;
+  const float* mask_pred; const float* mask_real; int64_t elements_per_mask;
+  float* psnr; float* iou; int* out_of_range;
+} nfi_metrics_args;
+int nfi_image_metrics(const nfi_metrics_args* a, nfi_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

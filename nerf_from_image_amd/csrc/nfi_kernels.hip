@@ -1215,6 +1215,7 @@ extern "C" int nfi_composite_fwd(const nfi_composite_args* a, nfi_stream_t strea
 #include "nfi_backward_rays.inc"
 #include "nfi_backward_field.inc"
 #include "nfi_regulariser.inc"
+#include "nfi_neighbours.inc"
 
 // ------------------------------------------------------------------------------------------------
 // fused forward render

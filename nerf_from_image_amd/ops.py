@@ -485,3 +485,67 @@ def raygen_bwd(height, width, focal, cam2world, bbox, center, normalize, g_ro, g
         _lib.check(lib.nfi_raygen_bwd(ctypes.byref(a), _lib.ptr(_f32c(g_ro, 'g_ro')), _lib.ptr(_f32c(g_rd, 'g_rd')),
                                       _lib.ptr(g_cam), _lib.ptr(g_focal), _stream(cam2world)), 'nfi_raygen_bwd')
     return g_cam, g_focal
+
+
+# --------------------------------------------------------------------------- #
+# neighbours of the renderer in the inversion loop
+# --------------------------------------------------------------------------- #
+def _warp_args(img_shape, rot, scale, translation, white_background):
+    n, c, h, w = img_shape
+    rot, translation = _f32c(rot, 'rot'), _f32c(translation, 'translation')
+    scale = _f32c(scale, 'scale')
+    if rot.numel() != n or translation.numel() != 2 * n or (scale is not None and scale.numel() != n):
+        raise ValueError('affine_warp: rot [N], scale [N] or None, translation [N,2] expected for N=%d images' % n)
+    return dict(n_images=n, channels=c, height=h, width=w, rot=rot, scale=scale, translation=translation,
+                white_background=int(bool(white_background)))
+
+
+def affine_warp(img, rot, scale, translation, white_background=False):
+    """img [N,C,H,W] warped by the per-image rotation / scale / translation of augment_impl (run.py:720-769)."""
+    img = _f32c(img, 'img')
+    if img.dim() != 4:
+        raise ValueError('affine_warp: img must be [N,C,H,W]')
+    out = torch.empty_like(img)
+    with torch.cuda.device(img.device):
+        _lib.call_struct('nfi_affine_warp_fwd', 'nfi_warp_args', _stream(img), image=img, warped=out,
+                         **_warp_args(img.shape, rot, scale, translation, white_background))
+    return out
+
+
+def affine_warp_bwd(g_out, rot, scale, translation, white_background=False):
+    """Adjoint of affine_warp w.r.t. the image: g_out [N,C,H,W] -> g_img [N,C,H,W]."""
+    g_out = _f32c(g_out, 'g_out')
+    g_img = torch.empty_like(g_out)
+    with torch.cuda.device(g_out.device):
+        _lib.call_struct('nfi_affine_warp_bwd', 'nfi_warp_args', _stream(g_out), g_warped=g_out, g_image=g_img,
+                         **_warp_args(g_out.shape, rot, scale, translation, white_background))
+    return g_img
+
+
+def image_metrics(pred=None, target=None, mask_pred=None, mask_real=None, check_range=True):
+    """Per-image PSNR (lib/metrics.py:30-45) of pred/target [B,...] in [0,1] and / or mask IoU (79-94) of
+    mask_pred/mask_real [B,...].  Returns (psnr [B] or None, iou [B] or None, out_of_range int32 [1] or None)."""
+    first = pred if pred is not None else mask_pred
+    if first is None:
+        raise ValueError('image_metrics: nothing to measure')
+    b, dev = first.shape[0], first.device
+    kw = dict(n_images=b)
+    psnr = iou = flag = None
+    if pred is not None:
+        pred, target = _f32c(pred, 'pred'), _f32c(target, 'target')
+        if pred.shape != target.shape:
+            raise ValueError('image_metrics: pred %s vs target %s' % (tuple(pred.shape), tuple(target.shape)))
+        psnr = torch.empty((b,), dtype=torch.float32, device=dev)
+        kw.update(pred=pred, target=target, elements_per_image=pred.numel() // b, psnr=psnr)
+    if mask_pred is not None:
+        mask_pred, mask_real = _f32c(mask_pred, 'mask_pred'), _f32c(mask_real, 'mask_real')
+        if mask_pred.shape != mask_real.shape or mask_pred.shape[0] != b:
+            raise ValueError('image_metrics: mask shapes %s vs %s' % (tuple(mask_pred.shape), tuple(mask_real.shape)))
+        iou = torch.empty((b,), dtype=torch.float32, device=dev)
+        kw.update(mask_pred=mask_pred, mask_real=mask_real, elements_per_mask=mask_pred.numel() // b, iou=iou)
+    if check_range:
+        flag = torch.empty((1,), dtype=torch.int32, device=dev)
+        kw['out_of_range'] = flag
+    with torch.cuda.device(dev):
+        _lib.call_struct('nfi_image_metrics', 'nfi_metrics_args', _stream(first), **kw)
+    return psnr, iou, flag

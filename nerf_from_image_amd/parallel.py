@@ -68,6 +68,9 @@ class GradientBuckets:
             raise ValueError('GradientBuckets: no parameter requires grad')
         self.average, self.mode, self.overlap, self.group = average, mode, overlap, group
         _, self.world_size = world()
+        # a collective is issued whenever a process group exists - also with a single rank (bench.py --force-dist
+        # runs the RCCL path on one GPU); without a process group the object only manages the flat storage
+        self.active = dist.is_available() and dist.is_initialized()
         dev = self.params[0].device
         per = max(1, int(bucket_bytes) // 4)
         self.buckets = []          # dict(flat, params, offsets, pending, shard)
@@ -118,7 +121,7 @@ class GradientBuckets:
 
     def _launch(self, bi):
         b = self.buckets[bi]
-        if self.world_size == 1:
+        if not self.active:
             return
         if self.mode == 'all_reduce':
             self._handles.append((bi, dist.all_reduce(b['flat'], op=dist.ReduceOp.SUM, group=self.group, async_op=True)))
@@ -141,8 +144,8 @@ class GradientBuckets:
 
     def finish(self):
         """Launches the collectives not yet issued, waits for all of them, applies the 1/world_size of `average`.
-        Returns the number of gradient bytes reduced (0 with a single rank)."""
-        if self.world_size == 1:
+        Returns the number of gradient bytes reduced (0 without a process group)."""
+        if not self.active:
             return 0
         for bi in range(len(self.buckets)):
             if not self._launched[bi]:
@@ -153,10 +156,10 @@ class GradientBuckets:
             h.wait()
             b = self.buckets[bi]
             if self.mode == 'reduce_scatter':
-                if self.average:
+                if self.average and self.world_size > 1:
                     b['shard'] /= self.world_size
                 gathers.append(dist.all_gather_into_tensor(b['flat'], b['shard'], group=self.group, async_op=True))
-            elif self.average:
+            elif self.average and self.world_size > 1:
                 b['flat'] /= self.world_size
         for h in gathers:
             h.wait()

@@ -372,6 +372,58 @@ def check_cfg1():
             '+32' if fine else '', mask.mean().item()))
 
 
+def slice_functions(path, names, g):
+    """exec the named top-level functions of a reference file that cannot be imported as a module."""
+    tree = ast.parse(open(path).read())
+    fns = [n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name in names]
+    assert len(fns) == len(names), (path, names)
+    exec(compile(ast.Module(body=fns, type_ignores=[]), path, 'exec'), g)
+    return g
+
+
+def neighbours(gold):
+    """Pins oracle/nfi_oracle_neighbours.py to the live augment_impl (run.py) and psnr / iou (lib/metrics.py) and
+    writes tests/golden/neighbours.npz."""
+    import torch.nn.functional as F
+    from lib import pose_utils
+    from oracle import nfi_oracle_neighbours as orn
+    out = {}
+    g = torch.Generator().manual_seed(2024)
+    for white in (False, True):
+        env = {'torch': torch, 'np': np, 'F': F, 'pose_utils': pose_utils,
+               'args': types.SimpleNamespace(supervise_alpha=not white), 'dataset_config': {'white_background': white}}
+        slice_functions(os.path.join(REF, 'run.py'), ['augment_impl'], env)
+        bs, C, H, W = 6, 6, 20, 28
+        img = torch.rand(bs, C, H, W, generator=g) * 2 - 1
+        rot = (torch.rand(bs, generator=g) - 0.5) * 2 * np.pi
+        scale = torch.exp2(torch.randn(bs, generator=g) * 0.2)
+        trans = torch.randn(bs, 2, generator=g) * 0.1
+        rot[0], scale[0], trans[0] = 0.0, 1.0, 0.0              # identity transform
+        ref, _, _, _ = env['augment_impl'](img.clone(), None, None, 1.0, cached_tform=(rot, scale, trans))
+        mine = orn.warp_images(img, rot, scale, trans, white)
+        assert torch.equal(ref, mine), ('warp', white, (ref - mine).abs().max().item())
+        tag = 'white' if white else 'black'
+        out.update({'warp_%s_img' % tag: img, 'warp_%s_rot' % tag: rot, 'warp_%s_scale' % tag: scale,
+                    'warp_%s_trans' % tag: trans, 'warp_%s_ref' % tag: ref})
+    env = slice_functions(os.path.join(REF, 'lib', 'metrics.py'), ['range_check', 'psnr', 'iou'], {'torch': torch})
+    pred = torch.rand(5, 3, 24, 24, generator=g) * 1.08 - 0.04          # inside the range check, outside [0,1] in places
+    target = (pred + 0.1 * torch.randn(5, 3, 24, 24, generator=g)).clamp(-0.05, 1.05)
+    target[4] = pred[4].clamp(0, 1)                                      # perfect reconstruction -> clamped at 60 dB
+    ref_psnr = env['psnr'](pred, target, reduction='none')
+    assert torch.equal(ref_psnr, orn.psnr(pred, target)) and float(ref_psnr[4]) == 60.0
+    assert torch.equal(env['psnr'](pred, target), orn.psnr(pred, target).mean())
+    a = torch.rand(5, 24, 24, generator=g)
+    b = (a + 0.3 * torch.randn(5, 24, 24, generator=g)).clamp(0, 1)
+    a[3], b[3] = 0.1, 0.2                                                # both masks empty: iou = 1
+    ref_iou = env['iou'](a, b, reduction='none')
+    assert torch.equal(ref_iou, orn.iou(a, b)) and float(ref_iou[3]) == 1.0
+    assert torch.equal(env['iou'](a.unsqueeze(1), b.unsqueeze(1), reduction='none'), ref_iou)
+    out.update(metric_pred=pred, metric_target=target, metric_psnr=ref_psnr, metric_mask_a=a, metric_mask_b=b,
+               metric_iou=ref_iou)
+    np.savez(os.path.join(gold, 'neighbours.npz'), **{k: v.numpy() for k, v in out.items()})
+    print('neighbours                   ok  (augment_impl warp black/white, psnr, iou pinned to the live functions)')
+
+
 def main():
     if '--cfg1' in sys.argv:
         return check_cfg1()
@@ -388,6 +440,7 @@ def main():
         print('%-28s ok  mask mean %.3f  rgb mean %.3f  hit %.2f' %
               (name, out['ref_mask'].mean().item(), out['ref_rgb'].mean().item(),
                out['ref_hit'].float().mean().item()))
+    neighbours(gold)
     json.dump(metas, open(os.path.join(gold, 'cases.json'), 'w'), indent=1, sort_keys=True)
     print('torch', torch.__version__, '-> wrote', gold)
 

@@ -70,7 +70,7 @@ def test_cfg2_single_image_against_oracle(gpu_device):
     # index flip budget, end to end: <= 1e-3 of entries here (alpha = 0.05
     # amplifies sigma differences 100x more than the survey's probe scene)
     flips = (r['perm'].cpu().long() != o_cpu['perm']).float().mean().item()
-    assert flips <= 1e-3, flips
+    assert flips <= 5e-5, flips          # measured 1.9e-5
     assert err(r['t_fine'], o_cpu['t_fine'])['max'] <= 1e-4
 
 
@@ -84,7 +84,7 @@ def test_cfg5_single_image_against_oracle(gpu_device):
         assert e_gpu['max'] <= 1e-4 and e_gpu['nonfinite'] == 0, (k, 'vs PyTorch-ROCm reference numerics', e_gpu)
     assert o_gpu['mask'].mean() > 0.2, 'scene should not be empty'
     flips = (r['perm'].long() != o_gpu['perm']).float().mean().item()
-    assert flips <= 2e-3, flips
+    assert flips <= 1e-4, flips          # measured 3.3e-5
     assert err(r['t_fine'], o_gpu['t_fine'])['max'] <= 1e-4
     # the skip of missed rays stays exact, and the no-tap kernel gives the same image as the tap kernel
     r2 = hip(d)
@@ -122,22 +122,30 @@ def test_cfg2_batch_properties(gpu_device):
 
 
 @pytest.mark.parametrize('radius,seed', [(2.0, 1234), (1.3, 77)])
-def test_cfg2_full_batch_against_gpu_oracle(gpu_device, radius, seed):
+def test_cfg2_full_batch_against_oracles(gpu_device, radius, seed):
     """The headline configuration itself (8 images x 128x128 x (64+64)), chairs-like (44 % of the rays miss the cube)
-    and with every ray crossing it, compared pixel by pixel and index by index with the oracle evaluated with
-    PyTorch-ROCm ops on the same GPU (the reference's own GPU path) on identical inputs and noise."""
+    and with every ray crossing it, compared pixel by pixel with (a) the CPU oracle = the reference's CPU numerics,
+    the pinned one: budget 1e-4; (b) the oracle evaluated with PyTorch-ROCm ops on this GPU = the reference's own GPU
+    path, whose elementwise kernels contract a*b+c into FMAs: its points differ from the CPU path's by an ulp, which
+    moves individual samples across the cube faces / texel boundaries; the two oracles therefore differ from EACH OTHER
+    by more than 1e-4 on a handful of pixels, and the HIP result is required to be as close to the GPU oracle as the
+    CPU oracle is (+1e-4)."""
     d = make_inputs(8, gpu_device, radius=radius, seed=seed)
     r = hip(d, taps=('perm', 't_fine'))
     fast = hip(d)                                    # the no-tap kernel with the missed-ray skip = what bench.py times
-    o = oracle(d, gpu_device)
+    o_gpu = oracle(d, gpu_device)
+    o_cpu = oracle(d, 'cpu')
     for k in ('rgb', 'depth', 'mask'):
-        e = err(r[k], o[k])
-        assert e['max'] <= 1e-4 and e['nonfinite'] == 0, (k, e)
+        e = err(r[k], o_cpu[k])
+        assert e['max'] <= 1e-4 and e['nonfinite'] == 0, (k, 'vs CPU oracle', e)
+        gap = err(o_cpu[k], o_gpu[k])['max']
+        e_gpu = err(r[k], o_gpu[k])
+        assert e_gpu['max'] <= gap + 1e-4, (k, 'vs PyTorch-ROCm oracle', e_gpu, 'oracle CPU-vs-GPU gap', gap)
         assert torch.equal(fast[k], r[k]), k
-    flips = (r['perm'].long() != o['perm']).float().mean().item()
-    assert flips <= 1e-3, flips
-    assert err(r['t_fine'], o['t_fine'])['max'] <= 1e-4
-    assert o['mask'].mean() > 0.15
+    flips = (r['perm'].cpu().long() != o_cpu['perm']).float().mean().item()
+    assert flips <= 5e-5, flips                      # measured 1.6e-5 (vs the GPU oracle)
+    assert err(r['t_fine'], o_cpu['t_fine'])['max'] <= 1e-4
+    assert o_cpu['mask'].mean() > 0.15
 
 
 def test_fast_termination_error_bound(gpu_device):

@@ -5,9 +5,14 @@ Tolerances (fp32):
   * elementwise stages that ATen evaluates op by op (near/far, stratified depths, query points,
     smoothing): bit-exact on identical inputs;
   * rendered rgb / depth / mask and per-sample rgb: 1e-4 absolute (north star);
-  * sigma: 1e-4 * max(1, 1/alpha) absolute - sigma = laplace_cdf(-d/beta)/alpha amplifies the
-    decoder's 1e-7-level rounding differences by up to 0.5/(alpha*beta); the reference's own
-    CPU-vs-GPU difference is of the same size (see tools/gpu_diag.py output in DESIGN.md).
+  * sigma: RELATIVE bound |d sigma| <= 3e-5 * max(1, |sigma|) per sample (sigma reaches 1/alpha = 50; the
+    absolute 1e-4 of the north star holds wherever sigma <= 3.3).  sigma = laplace_cdf(-d/beta)/alpha amplifies
+    the decoder's 1e-7-level rounding differences by up to 0.5/(alpha*beta); measured on MI355X (tools/
+    parity_report.py, profiles/r2/parity_report.json): <= 1.5e-5 relative, <= 2.8e-4 absolute at sigma ~ 50; the
+    reference's own CPU-vs-GPU difference is of the same size (tools/gpu_diag.py);
+  * index flips against the reference END TO END (searchsorted on a cdf computed by a different summation order):
+    measured 0 on every randomised golden case, 2e-3 / 5.6e-3 on the two deterministic-u cases (linspace u lands
+    exactly on cdf break points of flat pdfs); the asserts are about twice the measured rates.
 """
 import pytest
 import torch
@@ -21,8 +26,14 @@ pytestmark = pytest.mark.gpu
 ATOL = 1e-4
 
 
-def sigma_tol(meta, t):
-    return ATOL * max(1.0, 1.0 / float(t['alpha'])) if meta['sdf'] else ATOL
+SIGMA_RTOL = 3e-5
+
+
+def sigma_close(a, b, what):
+    """|a - b| <= SIGMA_RTOL * max(1, |b|) elementwise (relative for large sigma, absolute below 1)."""
+    a, b = a.detach().float().cpu(), b.detach().float().cpu()
+    viol = (a - b).abs() / b.abs().clamp_min(1.0)
+    assert torch.isfinite(viol).all() and float(viol.max()) <= SIGMA_RTOL, (what, float(viol.max()), float((a - b).abs().max()))
 
 
 @pytest.fixture(scope='module', params=golden_case_names())
@@ -90,7 +101,7 @@ def test_field_query(case):
                         samples_per_ray=meta['S'])
     exact(q['outside'].float(), o['outside_coarse'].reshape(B, -1), 'outside mask')
     close(q['sdf'], o['sdf_coarse'].reshape(B, -1), 1e-5, 'sdf')
-    close(q['sigma'], o['sigma_coarse'].reshape(B, -1), sigma_tol(meta, t), 'sigma')
+    sigma_close(q['sigma'], o['sigma_coarse'].reshape(B, -1), 'sigma')
     close(q['rgb'], o['rgb_coarse'].reshape(B, -1, 3), ATOL, 'rgb')
     if meta['A'] > 0:
         ref = orc.field_query(t['planes'], t['w1'], t['b1'], t['w2'], t['b2'], x.view(B, -1, meta['S'], 3),
@@ -114,7 +125,7 @@ def test_field_query_ragged_and_far_points(gpu_device):
     ref = orc.field_query(t['planes'], t['w1'], t['b1'], t['w2'], t['b2'], x, r, True, t['beta'], t['alpha'],
                           t['attention_values'])
     exact(q['outside'].float(), ref['outside'], 'outside mask')
-    close(q['sigma'], ref['sigma'], sigma_tol(meta, t), 'sigma')
+    sigma_close(q['sigma'], ref['sigma'], 'sigma')
     close(q['rgb'], ref['rgb'], ATOL, 'rgb')
     close(q['sdf'], ref['sdf'], 1e-5, 'sdf')
 
@@ -138,7 +149,7 @@ def test_sampling_stages(case):
     # normalisation (a float sum whose order no two implementations share) flips the index while
     # the sample itself moves by an ulp; the budget is wider there and the samples are checked below.
     flips = (taps['inds'].cpu() != o['inds']).float().mean().item()
-    assert flips <= (1e-3 if meta['randomize'] else 2e-2), flips
+    assert flips <= (1e-4 if meta['randomize'] else 1.2e-2), flips      # measured: 0 / 5.6e-3 (see the module docstring)
     close(fine, o['t_fine'].flatten(0, 2), 1e-5, 'fine depths')
     # stand-alone sample_pdf on the oracle's exact inputs
     mid = (.5 * (o['t_coarse'][..., 1:] + o['t_coarse'][..., :-1])).flatten(0, 2)
@@ -189,13 +200,13 @@ def test_fused_render(case):
         close(r[k], o[k], ATOL, 'fused ' + k)
         close(r[k], t['ref_' + k], ATOL, 'fused %s vs committed reference output' % k)
     close(r['t_coarse'], o['t_coarse'], 1e-5, 't_coarse')
-    close(r['sigma_coarse'], o['sigma_coarse'], sigma_tol(meta, t), 'sigma_coarse')
+    sigma_close(r['sigma_coarse'], o['sigma_coarse'], 'sigma_coarse')
     exact((r['hit'] & 1).bool(), o['hit'], 'hit mask')
     if meta['fine']:
         close(r['t_fine'], o['t_fine'], 1e-4, 't_fine')
         close(r['t_sorted'], o['t_sorted'], 1e-4, 't_sorted')
         mism = (r['perm'].cpu().long() != o['perm']).float().mean().item()
-        assert mism <= 5e-3, ('sort permutation flip budget', mism)
+        assert mism <= 2e-4, ('sort permutation flip budget (measured: 0 on every golden case)', mism)
     # skipping rays that miss the cube is exact
     r2 = hip_render(meta, t, dev, skip_missed_rays=True)
     for k in ('rgb', 'depth', 'mask'):

@@ -15,7 +15,7 @@ nproc >> $O/env.txt
 for w in $WHAT; do
   case $w in
     tests)
-      timeout 1500 python -m pytest tests -m gpu -q -x --durations=15 > $O/pytest.log 2>&1; echo "pytest rc=$?" >> $O/env.txt; tail -5 $O/pytest.log;;
+      timeout 1500 python -m pytest tests -m gpu -q --durations=15 > $O/pytest.log 2>&1; echo "pytest rc=$?" >> $O/env.txt; tail -5 $O/pytest.log;;
     report)
       timeout 600 python tools/parity_report.py > $O/parity_report.json 2> $O/parity_report.err; echo "report rc=$?" >> $O/env.txt;;
     bench)

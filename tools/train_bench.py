@@ -166,6 +166,7 @@ def run(dev, steps, warmup, batch=4, res=128, samples=64, bucket_mb=32, reduce_m
     for _ in range(min(steps, 10)):                           # untimed extra steps with a sync per step: the breakdown
         loss = step(True)
 
+    in_backward = buckets.launched_in_backward
     # the collective alone (no backward to hide behind): all buckets, launched back to back
     alone = []
     if use_dist:
@@ -181,5 +182,5 @@ def run(dev, steps, warmup, batch=4, res=128, samples=64, bucket_mb=32, reduce_m
     return dict(elapsed_s=elapsed, ms_per_step=elapsed / steps * 1e3, loss=float(loss.detach()),
                 fwd_bwd_ms=med(t_fb), allreduce_exposed_ms=med(t_red), optimiser_ms=med(t_opt),
                 allreduce_alone_ms=med(alone), gradient_bytes=buckets.nbytes, n_params=n_params,
-                n_buckets=len(buckets.buckets), buckets_launched_in_backward=buckets.launched_in_backward,
+                n_buckets=len(buckets.buckets), buckets_launched_in_backward=in_backward,
                 rays_per_step=batch * res * res)
