@@ -45,6 +45,12 @@ enum { NFI_PLANE_CHANNELS = 32, NFI_HIDDEN = 64, NFI_MAX_ATTENTION = 14, NFI_MAX
 
 /* texel storage type of the channel-last plane image */
 enum { NFI_TEXEL_F32 = 0, NFI_TEXEL_BF16 = 1, NFI_TEXEL_F16 = 2 };
+/* texel layout (`texel_layout` fields; 0 = default).  A texel = the 32 channels of one plane at one (y,x):
+ *   PLANAR       [B,3,R,R,32]   written by nfi_planes_to_texels from the reference's NCHW planes;
+ *   INTERLEAVED  [B,R,R,3,32]   = a channels-last (NHWC) [B,96,R,R] image, i.e. what a producer that emits
+ *                               torch.channels_last - or nfi_torgb_texels_fwd - leaves in memory: read in place,
+ *                               no hand-off kernel; gradient images use the layout of their texels. */
+enum { NFI_TEXELS_PLANAR = 0, NFI_TEXELS_INTERLEAVED = 1 };
 
 const char* nfi_last_error(void);
 int nfi_version(void);
@@ -168,6 +174,7 @@ typedef struct nfi_field_args {
    * come from nfi_decoder_pack_viewdir and point p belongs to ray p / samples_per_ray (x_in [B,H,W,S,3]) */
   const float* ray_features;
   int samples_per_ray;
+  int texel_layout;              /* NFI_TEXELS_PLANAR (0) / NFI_TEXELS_INTERLEAVED */
 } nfi_field_args;
 int nfi_field_query_fwd(const nfi_field_args* a, nfi_stream_t stream);
 
@@ -330,6 +337,7 @@ typedef struct nfi_field_bwd_args {
    * sorted by texel cell per plane, and one half-wave per cell sums its points in registers before ONE set of
    * atomics per cell; needs nfi_field_bwd_workspace_bytes(a) of workspace.  Same result up to fp32 summation order. */
   int scatter_mode;
+  int texel_layout;              /* of texels AND g_texels */
 } nfi_field_bwd_args;
 size_t nfi_field_bwd_workspace_bytes(const nfi_field_bwd_args* a);  /* for the scatter_mode / decoder of *a */
 size_t nfi_decoder_bwd_image_floats(void);          /* workspace floats, plain decoder */
@@ -357,6 +365,7 @@ typedef struct nfi_sdf_gradient_args {
   float* sdf; float* gradient;                       /* forward outputs */
   const float* g_sdf; const float* g_gradient;       /* backward inputs */
   float* g_texels; float* g_w1; float* g_b1; float* g_w2; float* g_b2;
+  int texel_layout;              /* of texels AND g_texels */
 } nfi_sdf_gradient_args;
 int nfi_sdf_gradient_fwd(const nfi_sdf_gradient_args* a, nfi_stream_t stream);
 int nfi_sdf_gradient_bwd(const nfi_sdf_gradient_args* a, nfi_stream_t stream);
@@ -420,9 +429,32 @@ typedef struct nfi_render_args {
    * sample compaction").  Changes rgb / mask by O(eps); sample indices differ from the reference.  Not available
    * together with stage taps, the cycle profile, the view-direction decoder or the exact-fp32 MLP. */
   float fast_termination;
+  int texel_layout;              /* NFI_TEXELS_PLANAR (0) / NFI_TEXELS_INTERLEAVED */
 } nfi_render_args;
 size_t nfi_render_workspace_bytes(int64_t n_rays);
 int nfi_render_fwd(const nfi_render_args* a, nfi_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Plane-producer hand-off: the tail of the LAST StyleGAN2 synthesis block
+ * (models/stylegan.py:383-435: img = upsample2d(img_prev); y = torgb(x, w); img += y) fused into one kernel that
+ * writes the result as texels in the INTERLEAVED layout [B,R,R,3,32] (= a channels-last [B,96,R,R] tensor), so
+ * that neither nfi_planes_to_texels nor nfi_texels_to_planes is needed.
+ *   x [B,Cin,R,R] NCHW activations of conv1; styles [B,Cin] = torgb.affine(w) * torgb.weight_gain (stylegan.py:365);
+ *   weight [96,Cin] = torgb.weight (1x1, no demodulation); bias [96]; previous_image [B,96,R/2,R/2] or NULL.
+ *   fwd: texels [B,R,R,96].
+ *   bwd: g_texels [B,R,R,96] -> g_x [B,Cin,R,R], g_styles [B,Cin], optional g_weight [96,Cin] + g_bias [96] (both
+ *        or neither), optional g_previous_image [B,96,R/2,R/2]; all written (zeroed inside where accumulated).
+ * Cin: multiple of 16, <= 256; R: multiple of 8.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct nfi_torgb_args {
+  int n_scenes, in_channels, resolution;
+  const float* x; const float* styles; const float* weight; const float* bias; const float* previous_image;
+  float* texels;                                         /* forward output */
+  const float* g_texels;                                 /* backward input */
+  float* g_x; float* g_styles; float* g_weight; float* g_bias; float* g_previous_image;
+} nfi_torgb_args;
+int nfi_torgb_texels_fwd(const nfi_torgb_args* a, nfi_stream_t stream);
+int nfi_torgb_texels_bwd(const nfi_torgb_args* a, nfi_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Neighbours of the renderer in the inversion loop.

@@ -313,10 +313,18 @@ __device__ __forceinline__ void finish_planes(bool hit, float fill_near, float f
 }
 
 // ---- triplane field on 16-point tiles ---------------------------------------------------------
+// Texel layouts (one scene = 3*R*R texels of 32 channels either way):
+//   planar       [3][R][R][32]   what nfi_planes_to_texels writes from an NCHW producer
+//   interleaved  [R][R][3][32]   = a channels-last [96,R,R] image: a producer that emits NHWC (nfi_torgb_texels_fwd,
+//                                or any torch.channels_last synthesis output) is read in place, no hand-off kernel
+// Only the three strides below differ; every kernel takes them from here.
 struct FieldParams {
-  __amdgpu_buffer_rsrc_t rsrc;   // texels of ONE scene: [3][R][R][32]
-  uint32_t plane_bytes;          // R*R*texel_bytes
-  uint32_t row_bytes;            // R*texel_bytes
+  __amdgpu_buffer_rsrc_t rsrc;   // texels of ONE scene
+  uint32_t plane_bytes;          // distance between the three planes
+  uint32_t pix_bytes;            // distance between x-adjacent texels
+  uint32_t row_bytes;            // distance between y-adjacent texels = R * pix_bytes
+  uint32_t row_pix_bytes;        // row_bytes + pix_bytes (the diagonal neighbour)
+  uint32_t scene_bytes;          // 3*R*R*texel_bytes
   int res;                       // R
   float res_m1;                  // R-1
   int n_attention;               // A (0: direct rgb)
@@ -395,17 +403,17 @@ struct TileTex {
 // xi: packed integer texel coordinates of point j (x | y<<10 | z<<20)
 template <int TEX>
 __device__ __forceinline__ void tile_issue(const FieldParams& P, int g, uint32_t xi, TileTex<TEX>& T) {
-  constexpr int TB = (TEX == 0) ? 128 : 64;                 // texel bytes
   const uint32_t x0 = xi & 1023u, y0 = (xi >> 10) & 1023u, z0 = (xi >> 20) & 1023u;
 #pragma unroll
   for (int pl = 0; pl < 3; ++pl) {
     const uint32_t a0 = (pl == 2) ? y0 : x0;      // W index: x, x, y
     const uint32_t b0 = (pl == 0) ? y0 : z0;      // H index: y, z, z
-    const uint32_t voff = (uint32_t)pl * P.plane_bytes + (b0 * (uint32_t)P.res + a0) * TB + (uint32_t)g * 16u;
+    // (the x / y / diagonal neighbours ride on the scalar offset of the buffer instruction: no extra vector math)
+    const uint32_t voff = (uint32_t)pl * P.plane_bytes + __umul24(b0 * (uint32_t)P.res + a0, P.pix_bytes) + (uint32_t)g * 16u;
     load_texel8<TEX>(P, voff, 0, 0, T.v[pl][0]);
-    load_texel8<TEX>(P, voff, 0, TB, T.v[pl][1]);
+    load_texel8<TEX>(P, voff, P.pix_bytes, 0, T.v[pl][1]);
     load_texel8<TEX>(P, voff, P.row_bytes, 0, T.v[pl][2]);
-    load_texel8<TEX>(P, voff, P.row_bytes, TB, T.v[pl][3]);
+    load_texel8<TEX>(P, voff, P.row_pix_bytes, 0, T.v[pl][3]);
   }
 }
 

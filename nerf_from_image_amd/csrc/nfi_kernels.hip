@@ -488,6 +488,7 @@ struct FieldKernelParams {
   int use_sdf; const float* beta; const float* alpha; float scene_range;
   float* sigma; float* rgb; float* sdf; float* sem; uint8_t* outside;
   const float* xray; int spr;
+  int layout;
 };
 
 // stage the decoder image (+ this scene's attention values in accumulator layout) into LDS
@@ -504,12 +505,15 @@ __device__ __forceinline__ void stage_field_lds(float* lds, const float* image, 
 
 __device__ __forceinline__ FieldParams make_field_params(const void* texels_scene, int res, int tex, int A, int use_sdf,
                                                          const float* beta, const float* alpha, const float* lds,
-                                                         int n_image = kLdsImageFloats) {
+                                                         int n_image = kLdsImageFloats, int layout = 0) {
   FieldParams P;
   uint32_t tb = tex == 0 ? 128u : 64u;
-  P.plane_bytes = (uint32_t)res * (uint32_t)res * tb;
-  P.row_bytes = (uint32_t)res * tb;
-  P.rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(texels_scene), 0, (int)(3u * P.plane_bytes), 0x00020000);
+  P.scene_bytes = 3u * (uint32_t)res * (uint32_t)res * tb;
+  P.pix_bytes = layout ? 3u * tb : tb;
+  P.plane_bytes = layout ? tb : (uint32_t)res * (uint32_t)res * tb;
+  P.row_bytes = (uint32_t)res * P.pix_bytes;
+  P.row_pix_bytes = P.row_bytes + P.pix_bytes;
+  P.rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(texels_scene), 0, (int)P.scene_bytes, 0x00020000);
   P.res = res;
   P.res_m1 = (float)(res - 1);
   P.n_attention = A;
@@ -532,7 +536,7 @@ __global__ __launch_bounds__(256) void field_query_kernel(FieldKernelParams k) {
   __syncthreads();
   const size_t tb = TEX == 0 ? 128 : 64;
   const char* tex_scene = reinterpret_cast<const char*>(k.texels) + (size_t)scene * 3 * k.res * k.res * tb;
-  FieldParams P = make_field_params(tex_scene, k.res, TEX, k.A, k.use_sdf, k.beta, k.alpha, lds, kImg);
+  FieldParams P = make_field_params(tex_scene, k.res, TEX, k.A, k.use_sdf, k.beta, k.alpha, lds, kImg, k.layout);
   const int lane = lane_id();
   const int wave = threadIdx.x >> 6;
   const int64_t n_chunks = (k.P + 63) / 64;
@@ -557,7 +561,8 @@ __global__ __launch_bounds__(256) void field_query_kernel(FieldKernelParams k) {
 }
 
 static int check_field_common(const void* texels, int plane_res, int texel_dtype, const float* image, int A,
-                              const float* att, int use_sdf, const float* beta, const float* alpha) {
+                              const float* att, int use_sdf, const float* beta, const float* alpha, int layout = 0) {
+  REQUIRE(layout == NFI_TEXELS_PLANAR || layout == NFI_TEXELS_INTERLEAVED, "field: bad texel layout");
   REQUIRE(texels && image, "field: null texels / decoder image");
   REQUIRE(plane_res >= 2 && plane_res <= 1024, "field: plane_res must be in [2,1024]");
   REQUIRE(texel_dtype >= NFI_TEXEL_F32 && texel_dtype <= NFI_TEXEL_F16, "field: bad texel dtype");
@@ -571,13 +576,13 @@ extern "C" int nfi_field_query_fwd(const nfi_field_args* a, nfi_stream_t stream)
   REQUIRE(a && a->points && a->sigma && a->rgb, "field_query: null pointer");
   REQUIRE(a->n_scenes > 0 && a->points_per_scene > 0, "field_query: bad shape");
   int rc = check_field_common(a->texels, a->plane_res, a->texel_dtype, a->decoder_image, a->n_attention,
-                               a->attention_values, a->use_sdf, a->beta, a->alpha);
+                               a->attention_values, a->use_sdf, a->beta, a->alpha, a->texel_layout);
   if (rc) return rc;
   REQUIRE(!a->semantics || a->n_attention > 0, "field_query: semantics need attention_values > 0");
   // (semantics rows are stored per valid point only: field_wave guards them with the lane's valid flag)
   FieldKernelParams k{a->points, a->points_per_scene, a->texels, a->plane_res, a->texel_dtype, a->decoder_image,
                       a->n_attention, a->attention_values, a->use_sdf, a->beta, a->alpha, a->scene_range,
-                      a->sigma, a->rgb, a->sdf, a->semantics, a->outside, a->ray_features, a->samples_per_ray};
+                      a->sigma, a->rgb, a->sdf, a->semantics, a->outside, a->ray_features, a->samples_per_ray, a->texel_layout};
   REQUIRE(!a->ray_features || (a->samples_per_ray > 0 && a->points_per_scene % a->samples_per_ray == 0),
           "field_query: with ray_features, points_per_scene must be a multiple of samples_per_ray");
   int64_t chunks = (a->points_per_scene + 63) / 64;
@@ -1216,6 +1221,7 @@ extern "C" int nfi_composite_fwd(const nfi_composite_args* a, nfi_stream_t strea
 #include "nfi_backward_field.inc"
 #include "nfi_regulariser.inc"
 #include "nfi_neighbours.inc"
+#include "nfi_handoff.inc"
 
 // ------------------------------------------------------------------------------------------------
 // fused forward render
@@ -1235,7 +1241,7 @@ struct RenderKernelParams {
   int xcd_block_shift;     // log2 of the block side: 3, 4 or 5
   int fetch_batch;         // positions taken per atomic
   // field
-  const void* texels; int res;
+  const void* texels; int res; int layout;
   const float* image; int A; const float* att;
   int use_sdf; const float* beta; const float* alpha;
   // noise
@@ -1370,7 +1376,7 @@ __global__ __launch_bounds__(256, OCC) void render_fwd_kernel(RenderKernelParams
     return scene * (uint32_t)k.hw + ((ty << 3) + (in >> 3)) * (uint32_t)k.width + (tx << 3) + (in & 7u);
   };
 
-  FieldParams P = make_field_params(k.texels, k.res, TEX, k.A, k.use_sdf, k.beta, k.alpha, lds, kImg);
+  FieldParams P = make_field_params(k.texels, k.res, TEX, k.A, k.use_sdf, k.beta, k.alpha, lds, kImg, k.layout);
   P.vf = vf;
   int cur_scene = -1;
 
@@ -1411,7 +1417,7 @@ __global__ __launch_bounds__(256, OCC) void render_fwd_kernel(RenderKernelParams
       if (scene != cur_scene) {
         cur_scene = scene;
         const char* tex_scene = reinterpret_cast<const char*>(k.texels) + (size_t)scene * 3 * k.res * k.res * tb;
-        P.rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(tex_scene), 0, (int)(3u * P.plane_bytes), 0x00020000);
+        P.rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(tex_scene), 0, (int)P.scene_bytes, 0x00020000);
         wave_lds_fence();
         {
           int c = lane & 3, row = lane >> 2;
@@ -1580,7 +1586,7 @@ __global__ __launch_bounds__(256, 2) void render_fwd_wide_kernel(RenderKernelPar
     const uint32_t ty = tile / tiles_x, tx = tile - ty * tiles_x;
     return scene * (uint32_t)k.hw + ((ty << 3) + (in >> 3)) * (uint32_t)k.width + (tx << 3) + (in & 7u);
   };
-  FieldParams P = make_field_params(k.texels, k.res, TEX, k.A, k.use_sdf, k.beta, k.alpha, lds, kImg);
+  FieldParams P = make_field_params(k.texels, k.res, TEX, k.A, k.use_sdf, k.beta, k.alpha, lds, kImg, k.layout);
   P.vf = vf;
   int cur_scene = -1;
   RayQueue queue(k, lane);
@@ -1599,7 +1605,7 @@ __global__ __launch_bounds__(256, 2) void render_fwd_wide_kernel(RenderKernelPar
       if (scene != cur_scene) {
         cur_scene = scene;
         const char* tex_scene = reinterpret_cast<const char*>(k.texels) + (size_t)scene * 3 * k.res * k.res * tb;
-        P.rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(tex_scene), 0, (int)(3u * P.plane_bytes), 0x00020000);
+        P.rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(tex_scene), 0, (int)P.scene_bytes, 0x00020000);
         wave_lds_fence();
         {
           int c = lane & 3, row = lane >> 2;
@@ -1788,7 +1794,7 @@ extern "C" int nfi_render_fwd(const nfi_render_args* a, nfi_stream_t stream) {
   REQUIRE(!a->fine_sampling || a->noise_fine, "render: fine sampling needs u (noise_fine)");
   REQUIRE(!a->semantics, "render: composited semantics are produced by nfi_composite_fwd, not the fused kernel");
   int rc = check_field_common(a->texels, a->plane_res, a->texel_dtype, a->decoder_image, a->n_attention,
-                               a->attention_values, a->use_sdf, a->beta, a->alpha);
+                               a->attention_values, a->use_sdf, a->beta, a->alpha, a->texel_layout);
   if (rc) return rc;
   const int64_t n = (int64_t)a->n_scenes * a->height * a->width;
   if (a->workspace_bytes < nfi_render_workspace_bytes(n)) return fail(NFI_ERR_WORKSPACE_TOO_SMALL, "render: workspace too small");
@@ -1814,7 +1820,7 @@ extern "C" int nfi_render_fwd(const nfi_render_args* a, nfi_stream_t stream) {
   k.n_scenes = a->n_scenes; k.hw = a->height * a->width; k.S = a->n_samples;
   k.fine = a->fine_sampling; k.white = a->white_background; k.scene_range = a->scene_range;
   k.ro = ro; k.rd = rd; k.near_raw = near_raw; k.far_raw = far_raw; k.hit = hit; k.reduce = reduce;
-  k.texels = a->texels; k.res = a->plane_res; k.image = a->decoder_image; k.A = a->n_attention; k.att = a->attention_values;
+  k.texels = a->texels; k.res = a->plane_res; k.layout = a->texel_layout; k.image = a->decoder_image; k.A = a->n_attention; k.att = a->attention_values;
   k.use_sdf = a->use_sdf; k.beta = a->beta; k.alpha = a->alpha;
   k.noise_c = a->noise_coarse; k.noise_f = a->noise_fine; k.noise_f_stride = a->noise_fine_row_stride;
   k.rgb = a->rgb; k.depth = a->depth; k.mask = a->mask;

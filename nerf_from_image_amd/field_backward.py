@@ -53,7 +53,8 @@ def field_query_bwd(points, texels, decoder_image, w1, w2, scene_range, n_attent
         scatter_mode = 1 if (P >= BINNED_SCATTER_MIN_POINTS and not points_only) else 0
     fields = dict(
             n_scenes=B, points_per_scene=P,
-            points=points, texels=texels, plane_res=texels.shape[2], texel_dtype=ops.TEXEL_F32,
+            points=points, texels=texels, plane_res=ops.texel_res(texels), texel_dtype=ops.TEXEL_F32,
+            texel_layout=ops.texel_layout_of(texels),
             decoder_image=decoder_image, w1=f(w1, 'w1'), w2=f(w2, 'w2'), n_attention=n_attention,
             attention_values=f(attention_values, 'attention_values') if n_attention > 0 else None,
             use_sdf=int(use_sdf), beta=f(beta, 'beta') if use_sdf else None, alpha=f(alpha, 'alpha') if use_sdf else None,
@@ -92,7 +93,7 @@ def make_field_bwd(texels, decoder_image, scene_range, n_attention, use_sdf, wan
             g_sem = grads[i]
         g = field_query_bwd(pts, texels, decoder_image, w1, w2, scene_range, n_attention, att, use_sdf, be, al,
                             g_sigma, g_rgb, g_sdf, g_sem, want_points=bool(needs[0]), viewdir=vd)
-        g_planes = ops.texels_to_planes(g['g_texels']) if needs[1] else None
+        g_planes = ops.texel_grad_to_planes(g['g_texels']) if needs[1] else None
         base = (g.get('g_points'), g_planes, g['g_w1'], g['g_b1'], g['g_w2'], g['g_b2'],
                 g.get('g_attention_values'), g.get('g_beta'), g.get('g_alpha'))
         if vd is None:

@@ -77,6 +77,17 @@ class _distance_head:
         self.training = getattr(decoder, 'training', False)
 
 
+def texels_of(planes, texel_dtype=ops.TEXEL_F32):
+    """The hand-off (generator.py:475-477 -> the kernels): a producer whose [B,96,R,R] output is channels-last in memory
+    is read in place (interleaved texel layout, no kernel, no copy); an NCHW producer goes through the one transposition
+    launch nfi_planes_to_texels."""
+    p = planes.detach()
+    v = ops.planes_view_as_texels(p) if p.dtype == torch.float32 else None
+    if v is not None:
+        return v if texel_dtype == ops.TEXEL_F32 else v.to(ops._TEXEL_TORCH[texel_dtype])
+    return ops.planes_to_texels(p, texel_dtype)
+
+
 def make_sampler(planes, decoder, scene_range, n_attention, attention_values, use_sdf, beta, alpha,
                  texel_dtype=ops.TEXEL_F32, request_model_outputs=(), viewdir=None):
     """Builds the ``sampler(x_in, request_sampler_outputs)`` closure over HIP kernels.
@@ -85,7 +96,7 @@ def make_sampler(planes, decoder, scene_range, n_attention, attention_values, us
     viewdir (--use_viewdir): (ray_feature [B,H,W,1,32] = output of ViewDirectionMapper.fc6, output_layer =
     the mapper's `output` EqualizedLinear); the closure of generator.py:243-251 is then part of the kernels."""
     w1, b1, w2, b2 = decoder_parameters(decoder)
-    texels = ops.planes_to_texels(planes.detach(), texel_dtype)
+    texels = texels_of(planes, texel_dtype)
     ray_feature = w3 = b3 = ray_pad = None
     if viewdir is not None:
         ray_feature, out_layer = viewdir
@@ -181,7 +192,7 @@ def sdf_and_gradient(points, planes, decoder, scene_range):
     double backward lib/ops.grid_sample2d exists for.  Differentiable w.r.t. planes and the decoder parameters."""
     w1, b1, w2, b2 = decoder_parameters(decoder)
     pts = points.detach()
-    texels = ops.planes_to_texels(planes.detach())
+    texels = texels_of(planes)
 
     def fwd(pl, a_w1, a_b1, a_w2, a_b2):
         return ops.sdf_gradient_fwd(pts, texels, a_w1, a_b1, a_w2, a_b2, scene_range)
@@ -189,7 +200,7 @@ def sdf_and_gradient(points, planes, decoder, scene_range):
     def bwd(inputs, outputs, grads, needs):
         pl, a_w1, a_b1, a_w2, a_b2 = inputs
         g = ops.sdf_gradient_bwd(pts, texels, a_w1, a_b1, a_w2, a_b2, scene_range, grads[0], grads[1])
-        return (ops.texels_to_planes(g['g_texels']) if needs[0] else None, g['g_w1'], g['g_b1'], g['g_w2'], g['g_b2'])
+        return (ops.texel_grad_to_planes(g['g_texels']) if needs[0] else None, g['g_w1'], g['g_b1'], g['g_w2'], g['g_b2'])
     return differentiable('sdf_gradient', fwd, planes, w1, b1, w2, b2, bwd=bwd)
 
 
@@ -383,8 +394,11 @@ def wrapped_forward(self, viewdir, c, request_model_outputs=['sampler'], model_i
     return model_outputs
 
 
-def attach(model, texel_dtype=ops.TEXEL_F32, hip_regularisers=False):
+def attach(model, texel_dtype=ops.TEXEL_F32, hip_regularisers=False, fused_handoff=False):
     """Gives a reference-style Generator the HIP sampler.  Returns the same module.
+
+    fused_handoff: also fuse the tail of the last synthesis block (upsample + torgb + add, stylegan.py:424-433) into
+    the HIP kernel that writes texels directly (nerf_from_image_amd.handoff): no NCHW <-> channel-last pass remains.
 
     hip_regularisers: also serve sdf_eikonal / sdf_distance / total_variation / entropy losses of a module that has
     its own forward from the HIP kernels (bare containers always do).
@@ -397,6 +411,9 @@ def attach(model, texel_dtype=ops.TEXEL_F32, hip_regularisers=False):
         raise AttributeError('attach(): module lacks %s' % missing)
     model.nfi_texel_dtype = texel_dtype
     model.nfi_hip_regularisers = bool(hip_regularisers)
+    if fused_handoff:
+        from . import handoff
+        handoff.fuse_last_block(model.synthesis_network)
     if type(model).forward is not torch.nn.Module.forward and not hasattr(model, '_nfi_original_forward'):
         model._nfi_original_forward = model.forward          # bound method of the reference class
         model.forward = types.MethodType(wrapped_forward, model)

@@ -22,6 +22,43 @@ def texel_dtype_of(texels):
     raise TypeError('texels must be float32, bfloat16 or float16, got %s' % texels.dtype)
 
 
+TEXELS_PLANAR = 0          # [B,3,R,R,32]
+TEXELS_INTERLEAVED = 1     # [B,R,R,3,32] = channels-last [B,96,R,R]
+
+
+def texel_layout_of(texels):
+    """Layout of a texel tensor from its shape: [B,3,R,R,32] planar, [B,R,R,3,32] interleaved (R > 3)."""
+    if texels.dim() != 5 or texels.shape[4] != 32:
+        raise ValueError('texels must be [B,3,R,R,32] or [B,R,R,3,32], got %s' % (tuple(texels.shape),))
+    if texels.shape[1] == 3 and texels.shape[2] == texels.shape[3]:
+        return TEXELS_PLANAR
+    if texels.shape[3] == 3 and texels.shape[1] == texels.shape[2]:
+        return TEXELS_INTERLEAVED
+    raise ValueError('texels must be [B,3,R,R,32] or [B,R,R,3,32], got %s' % (tuple(texels.shape),))
+
+
+def texel_res(texels):
+    return texels.shape[2]          # R sits at index 2 in both layouts
+
+
+def planes_view_as_texels(planes):
+    """planes [B,3,32,R,R] (a view of the producer's [B,96,R,R] output): if that output is channels-last in memory
+    (torch.channels_last, or written by torgb_texels), returns the zero-copy interleaved texel view [B,R,R,3,32];
+    otherwise None (the caller then runs planes_to_texels)."""
+    if planes.dim() != 5 or planes.shape[1] != 3 or planes.shape[2] != 32 or planes.shape[3] <= 3:
+        return None
+    v = planes.permute(0, 3, 4, 1, 2)
+    return v if v.is_contiguous() else None
+
+
+def texel_grad_to_planes(g_texels):
+    """Gradient image in texel layout -> gradient of the [B,3,32,R,R] planes view (a kernel for the planar layout,
+    a zero-copy strided view for the interleaved one)."""
+    if texel_layout_of(g_texels) == TEXELS_INTERLEAVED:
+        return g_texels.permute(0, 3, 4, 1, 2)
+    return texels_to_planes(g_texels)
+
+
 def _stream(t):
     return torch.cuda.current_stream(t.device).cuda_stream
 
@@ -196,7 +233,8 @@ def field_query(points, texels, decoder_image, scene_range, n_attention, attenti
         out['outside'] = torch.empty((B, P), dtype=torch.uint8, device=dev)
     with torch.cuda.device(dev):
         _lib.call_struct('nfi_field_query_fwd', 'nfi_field_args', _stream(points), n_scenes=B, points_per_scene=P,
-                         points=points, texels=texels, plane_res=texels.shape[2], texel_dtype=tdt,
+                         points=points, texels=texels, plane_res=texel_res(texels), texel_dtype=tdt,
+                         texel_layout=texel_layout_of(texels),
                          decoder_image=decoder_image, n_attention=n_attention, attention_values=att,
                          use_sdf=int(use_sdf), beta=_f32c(beta, 'beta') if use_sdf else None,
                          alpha=_f32c(alpha, 'alpha') if use_sdf else None, scene_range=float(scene_range),
@@ -369,8 +407,8 @@ def render_fwd(cam2world, focal, height, width, num_samples, texels, decoder_ima
             'nfi_render_fwd', 'nfi_render_args', _stream(cam2world), n_scenes=B, height=height, width=width,
             n_samples=S, fine_sampling=int(fine_sampling), white_background=int(white_background),
             scene_range=float(scene_range), cam2world=cam2world, focal=_f32c(focal, 'focal_length'),
-            bbox=_f32c(bbox, 'bbox'), center=_f32c(center, 'center'), texels=texels, plane_res=texels.shape[2],
-            texel_dtype=tdt, decoder_image=decoder_image, n_attention=n_attention,
+            bbox=_f32c(bbox, 'bbox'), center=_f32c(center, 'center'), texels=texels, plane_res=texel_res(texels),
+            texel_layout=texel_layout_of(texels), texel_dtype=tdt, decoder_image=decoder_image, n_attention=n_attention,
             attention_values=_f32c(attention_values, 'attention_values') if n_attention > 0 else None,
             use_sdf=int(use_sdf), beta=_f32c(beta, 'beta') if use_sdf else None,
             alpha=_f32c(alpha, 'alpha') if use_sdf else None, noise_coarse=_f32c(noise_coarse, 'noise_coarse'),
@@ -397,7 +435,8 @@ def sdf_gradient_fwd(points, texels, w1, b1, w2, b2, scene_range):
     grad = torch.empty((B, P, 3), dtype=torch.float32, device=points.device)
     with torch.cuda.device(points.device):
         _lib.call_struct('nfi_sdf_gradient_fwd', 'nfi_sdf_gradient_args', _stream(points), n_scenes=B, points_per_scene=P,
-                         points=points, texels=texels, plane_res=texels.shape[2], scene_range=float(scene_range),
+                         points=points, texels=texels, plane_res=texel_res(texels), texel_layout=texel_layout_of(texels),
+                         scene_range=float(scene_range),
                          w1=_f32c(w1, 'w1'), b1=_f32c(b1, 'b1'), w2=_f32c(w2, 'w2'), b2=_f32c(b2, 'b2'), sdf=sdf,
                          gradient=grad)
     return sdf, grad
@@ -415,7 +454,8 @@ def sdf_gradient_bwd(points, texels, w1, b1, w2, b2, scene_range, g_sdf, g_gradi
            'g_b2': torch.zeros_like(b2)}
     with torch.cuda.device(dev):
         _lib.call_struct('nfi_sdf_gradient_bwd', 'nfi_sdf_gradient_args', _stream(points), n_scenes=B, points_per_scene=P,
-                         points=points, texels=texels, plane_res=texels.shape[2], scene_range=float(scene_range),
+                         points=points, texels=texels, plane_res=texel_res(texels), texel_layout=texel_layout_of(texels),
+                         scene_range=float(scene_range),
                          w1=_f32c(w1, 'w1'), b1=_f32c(b1, 'b1'), w2=w2, b2=b2, g_sdf=_f32c(g_sdf, 'g_sdf'),
                          g_gradient=_f32c(g_gradient, 'g_gradient'), **out)
     return out
@@ -549,3 +589,47 @@ def image_metrics(pred=None, target=None, mask_pred=None, mask_real=None, check_
     with torch.cuda.device(dev):
         _lib.call_struct('nfi_image_metrics', 'nfi_metrics_args', _stream(first), **kw)
     return psnr, iou, flag
+
+
+# --------------------------------------------------------------------------- #
+# plane-producer hand-off
+# --------------------------------------------------------------------------- #
+def torgb_texels(x, styles, weight, bias, previous_image=None):
+    """Tail of the last synthesis block (stylegan.py:383-435) written as texels: x [B,Cin,R,R], styles [B,Cin],
+    weight [96,Cin], bias [96], previous_image [B,96,R/2,R/2] or None -> a [B,96,R,R] tensor in channels-last memory
+    format (its storage IS the interleaved texel image [B,R,R,3,32])."""
+    x, styles, weight, bias = _f32c(x, 'x'), _f32c(styles, 'styles'), _f32c(weight, 'weight'), _f32c(bias, 'bias')
+    prev = _f32c(previous_image, 'previous_image')
+    B, Cin, R, R2 = x.shape
+    if R != R2 or tuple(styles.shape) != (B, Cin) or tuple(weight.shape) != (96, Cin) or tuple(bias.shape) != (96,) or \
+            (prev is not None and tuple(prev.shape) != (B, 96, R // 2, R // 2)):
+        raise ValueError('torgb_texels: shapes x %s styles %s weight %s bias %s prev %s' % (
+            tuple(x.shape), tuple(styles.shape), tuple(weight.shape), tuple(bias.shape),
+            None if prev is None else tuple(prev.shape)))
+    out = torch.empty((B, 96, R, R), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
+    with torch.cuda.device(x.device):
+        _lib.call_struct('nfi_torgb_texels_fwd', 'nfi_torgb_args', _stream(x), n_scenes=B, in_channels=Cin, resolution=R,
+                         x=x, styles=styles, weight=weight, bias=bias, previous_image=prev, texels=out)
+    return out
+
+
+def torgb_texels_bwd(g_out, x, styles, weight, previous_image=None, want_weight=True, want_prev=True):
+    """Backward of torgb_texels.  g_out: [B,96,R,R] (any strides; brought to channels-last).  Returns dict(g_x, g_styles,
+    g_weight?, g_bias?, g_previous_image?)."""
+    x, styles, weight = _f32c(x, 'x'), _f32c(styles, 'styles'), _f32c(weight, 'weight')
+    prev = _f32c(previous_image, 'previous_image')
+    B, Cin, R, _ = x.shape
+    if not g_out.is_cuda or g_out.dtype != torch.float32:
+        raise TypeError('torgb_texels_bwd: g_out must be a float32 GPU tensor')
+    g = g_out.contiguous(memory_format=torch.channels_last)
+    dev = x.device
+    out = {'g_x': torch.empty_like(x), 'g_styles': torch.empty((B, Cin), dtype=torch.float32, device=dev)}
+    if want_weight:
+        out['g_weight'] = torch.empty((96, Cin), dtype=torch.float32, device=dev)
+        out['g_bias'] = torch.empty((96,), dtype=torch.float32, device=dev)
+    if want_prev and prev is not None:
+        out['g_previous_image'] = torch.empty_like(prev)
+    with torch.cuda.device(dev):
+        _lib.call_struct('nfi_torgb_texels_bwd', 'nfi_torgb_args', _stream(x), n_scenes=B, in_channels=Cin, resolution=R,
+                         x=x, styles=styles, weight=weight, previous_image=prev, g_texels=g, **out)
+    return out

@@ -420,8 +420,27 @@ def neighbours(gold):
     assert torch.equal(env['iou'](a.unsqueeze(1), b.unsqueeze(1), reduction='none'), ref_iou)
     out.update(metric_pred=pred, metric_target=target, metric_psnr=ref_psnr, metric_mask_a=a, metric_mask_b=b,
                metric_iou=ref_iou)
+    # ---- the tail of the last synthesis block (stylegan.py:383-435) against the live SynthesisBlock ----
+    from models import stylegan as ref_sg
+    torch.manual_seed(77)
+    blk = ref_sg.SynthesisBlock(32, 32, w_dim=24, resolution=16, img_channels=96, is_last=True, use_noise=False).eval()
+    with torch.no_grad():
+        blk.torgb.bias.normal_()
+    x_in = torch.randn(2, 32, 8, 8, generator=g)
+    img_prev = torch.randn(2, 96, 8, 8, generator=g)
+    ws = torch.randn(2, 3, 24, generator=g)
+    seen = {}
+    hk = blk.conv1.register_forward_hook(lambda m, i, o_: seen.__setitem__('x', o_.detach().clone()))
+    with torch.no_grad():
+        _, img = blk(x_in, img_prev.clone(), ws)
+        styles = blk.torgb.affine(ws[:, 2]) * blk.torgb.weight_gain
+        mine = orn.torgb_upsample_add(seen['x'], styles, blk.torgb.weight, blk.torgb.bias, img_prev)
+    hk.remove()
+    assert torch.equal(img, mine), ('torgb tail', (img - mine).abs().max().item())
+    out.update(handoff_x=seen['x'], handoff_styles=styles.detach(), handoff_weight=blk.torgb.weight.detach().reshape(96, 32),
+               handoff_bias=blk.torgb.bias.detach(), handoff_prev=img_prev, handoff_ref=img)
     np.savez(os.path.join(gold, 'neighbours.npz'), **{k: v.numpy() for k, v in out.items()})
-    print('neighbours                   ok  (augment_impl warp black/white, psnr, iou pinned to the live functions)')
+    print('neighbours                   ok  (augment_impl warp black/white, psnr, iou, synthesis-block tail pinned to the live code)')
 
 
 def main():

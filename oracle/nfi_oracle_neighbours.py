@@ -6,7 +6,9 @@ Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import 
   warp_images   the image branch of run.py::augment_impl (run.py:745-766): 2x3 matrix from (rot, scale, translation),
                 F.affine_grid(align_corners=False) + F.grid_sample(bilinear, zeros, align_corners=False), with the
                 white-background adjustment;
-  psnr / iou    lib/metrics.py:30-45 / 79-94, per image.
+  psnr / iou    lib/metrics.py:30-45 / 79-94, per image;
+  torgb_upsample_add   the tail of the last synthesis block (models/stylegan.py:424-433): upsample2d (72-76) of the
+                previous image + OutputLayer (351-372: 1x1 modulated conv without demodulation + bias).
 
 Pinned: oracle/make_golden.py (neighbours()) drives the LIVE functions (AST-sliced out of run.py / lib/metrics.py,
 which are not importable as modules) and asserts bit-equality with these restatements before it writes
@@ -52,3 +54,20 @@ def iou(alpha_pred, alpha_real):
     inter = (a & b).float().sum(dim=[-2, -1])
     union = (a | b).float().sum(dim=[-2, -1])
     return ((inter + 1e-6) / (union + 1e-6)).flatten()
+
+
+def torgb_upsample_add(x, styles, weight, bias, previous_image):
+    """x [B,Cin,R,R], styles [B,Cin] (affine(w) * weight_gain), weight [96,Cin,1,1], bias [96], previous_image
+    [B,96,R/2,R/2] or None -> img [B,96,R,R]   (stylegan.py:132-133 modulation, 109 conv, 369-371 bias, 72-76 + 428-433)."""
+    bs = x.shape[0]
+    y = F.conv2d(x * styles.reshape(bs, -1, 1, 1), weight.reshape(weight.shape[0], -1, 1, 1), padding=0)
+    y = y + bias.view(1, -1, 1, 1)
+    if previous_image is None:
+        return y
+    h = torch.tensor([1., 3., 3., 1.], dtype=x.dtype, device=x.device)
+    h = h[:, None] * h[None, :]
+    h = h / h.sum()
+    nc = previous_image.shape[1]
+    up = F.conv_transpose2d(previous_image.flatten(0, 1).unsqueeze(1), h[None, None] * 4, padding=1, stride=2)
+    up = up.view(bs, nc, up.shape[2], up.shape[3])
+    return up + y

@@ -120,3 +120,101 @@ def look_at_cameras(n, radius, gen):
     cam[:, :3, 2] = -fwd
     cam[:, :3, 3] = eye
     return cam
+
+
+# ------------------------------------------------------------------------------------------------
+# a synthesis network with the reference's LAST-BLOCK structure (models/stylegan.py:383-435), small
+# ------------------------------------------------------------------------------------------------
+class _Affine(nn.Module):
+    def __init__(self, w_dim, out):
+        super().__init__()
+        self.lin = nn.Linear(w_dim, out)
+        nn.init.ones_(self.lin.bias)
+
+    def forward(self, w):
+        return self.lin(w)
+
+
+class _ModConv(nn.Module):
+    """Stand-in for SynthesisLayer: style-modulated 3x3 conv (+ optional 2x nearest upsampling), leaky ReLU."""
+
+    def __init__(self, cin, cout, w_dim, up, gen):
+        super().__init__()
+        self.up = up
+        self.affine = _Affine(w_dim, cin)
+        self.weight = nn.Parameter(torch.randn(cout, cin, 3, 3, generator=gen) / math.sqrt(cin * 9))
+        self.bias = nn.Parameter(torch.zeros(cout))
+
+    def forward(self, x, w, **kw):
+        x = x * self.affine(w)[:, :, None, None]
+        if self.up:
+            x = torch.nn.functional.interpolate(x, scale_factor=2, mode='nearest')
+        return torch.nn.functional.leaky_relu(torch.nn.functional.conv2d(x, self.weight, self.bias, padding=1), 0.2)
+
+
+class _OutputLayer(nn.Module):
+    """Same attributes as the reference OutputLayer (stylegan.py:351-372): affine, weight [96,Cin,1,1], bias, weight_gain."""
+
+    def __init__(self, cin, w_dim, gen):
+        super().__init__()
+        self.affine = _Affine(w_dim, cin)
+        self.weight = nn.Parameter(torch.randn(96, cin, 1, 1, generator=gen))
+        self.bias = nn.Parameter(0.1 * torch.randn(96, generator=gen))
+        self.weight_gain = 1 / math.sqrt(cin)
+
+    def forward(self, x, w):
+        styles = self.affine(w) * self.weight_gain
+        y = torch.nn.functional.conv2d(x * styles[:, :, None, None], self.weight)
+        return y + self.bias.view(1, -1, 1, 1)
+
+
+class _Block(nn.Module):
+    def __init__(self, cin, cout, w_dim, res, gen):
+        super().__init__()
+        self.in_channels, self.resolution = cin, res
+        f = torch.tensor([1., 3., 3., 1.])
+        f = f[:, None] * f[None, :]
+        self.register_buffer('resample_filter', f / f.sum())
+        if cin == 0:
+            self.const = nn.Parameter(torch.randn(cout, res, res, generator=gen))
+        else:
+            self.conv0 = _ModConv(cin, cout, w_dim, True, gen)
+        self.conv1 = _ModConv(cout, cout, w_dim, False, gen)
+        self.torgb = _OutputLayer(cout, w_dim, gen)
+        self.num_conv = 1 if cin == 0 else 2
+
+    def forward(self, x, img, ws, **kw):
+        """The reference block (stylegan.py:416-435) in plain tensor ops."""
+        w_iter = iter(ws.unbind(dim=1))
+        if self.in_channels == 0:
+            x = self.const.unsqueeze(0).repeat([ws.shape[0], 1, 1, 1])
+        else:
+            x = self.conv0(x, next(w_iter))
+        x = self.conv1(x, next(w_iter))
+        if img is not None:
+            nc = img.shape[1]
+            up = torch.nn.functional.conv_transpose2d(img.flatten(0, 1).unsqueeze(1), self.resample_filter[None, None] * 4,
+                                                      padding=1, stride=2)
+            img = up.view(img.shape[0], nc, up.shape[2], up.shape[3])
+        y = self.torgb(x, next(w_iter))
+        img = img + y if img is not None else y
+        return x, img
+
+
+class StyleLikeSynthesis(nn.Module):
+    """Two blocks (res/2 with a learned constant, res = the LAST block) driven like SynthesisNetwork.forward
+    (stylegan.py:477-492): ws [B,4,w_dim]: b(res/2) uses ws[0..1] (conv1, torgb), b(res) uses ws[1..3]."""
+
+    def __init__(self, res, channels=32, w_dim=512, seed=3):
+        super().__init__()
+        gen = torch.Generator().manual_seed(seed)
+        self.img_resolution, self.img_channels, self.w_dim = res, 96, w_dim
+        self.block_resolutions = [res // 2, res]
+        setattr(self, 'b%d' % (res // 2), _Block(0, channels, w_dim, res // 2, gen))
+        setattr(self, 'b%d' % res, _Block(channels, channels, w_dim, res, gen))
+
+    def forward(self, ws, **kw):
+        ws = ws[:, :4]
+        x, img = getattr(self, 'b%d' % (self.img_resolution // 2))(None, None, ws[:, 0:2])
+        x, img = getattr(self, 'b%d' % self.img_resolution)(x, img, ws[:, 1:4])
+        return img
