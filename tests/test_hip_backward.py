@@ -373,3 +373,32 @@ def test_binned_scatter_matches_atomic_scatter(gpu_device, P, res):
     assert a['g_texels'].abs().max() > 0
     for k in a:
         rel_close(b[k], a[k], 'binned vs atomic ' + k, 2e-5)
+
+
+def test_backward_outputs_without_atomics_are_bit_reproducible(gpu_device):
+    """g_points (and the normals path) involve no atomics, so repeated launches must agree bit for bit.  Regression
+    test for a gfx950 hazard found in round 2: a wide ds_write fetches its data registers late (lane groups 48..63
+    last); without draining the LDS queue before the registers are reused, rows 12..15 of the kernel's 16-row LDS
+    tiles were corrupted once in a few launches, depending on timing (tools/dbg_gpoints2.py; nfi_device.hpp,
+    wave_lds_fence)."""
+    from nerf_from_image_amd import field_backward as fb, ops as hops
+    dev = gpu_device
+    g = torch.Generator().manual_seed(70500)
+    B, A, r, P, res = 2, 10, 0.55, 70000, 64
+    planes = torch.randn(B, 3, 32, res, res, generator=g).to(dev)
+    dec = _Decoder(1 + A, g).to(dev)
+    w1, b1, w2, b2 = dec.net[0].weight, dec.net[0].bias, dec.net[2].weight, dec.net[2].bias
+    x = ((torch.rand(B, P, 3, generator=g) * 2 - 1) * r * 1.15).to(dev)
+    att = (torch.rand(B, A, 3, generator=g) * 2 - 1).to(dev)
+    beta, alpha = torch.tensor([0.12], device=dev), torch.tensor([0.3], device=dev)
+    gs, gr = torch.randn(B, P, generator=g).to(dev), torch.randn(B, P, 3, generator=g).to(dev)
+    texels, image = hops.planes_to_texels(planes), hops.decoder_pack(w1, b1, w2, b2, A)
+
+    def run(mode, **kw):
+        return fb.field_query_bwd(x, texels, image, w1, w2, r, A, att, True, beta, alpha, gs, gr, scatter_mode=mode, **kw)
+    ref = run(0, want_points=True)['g_points'].clone()
+    ref_n = run(0, points_only=True, normalize_points=True)['g_points'].clone()
+    for _ in range(8):
+        assert torch.equal(run(1, want_points=True)['g_points'], ref)
+        assert torch.equal(run(0, want_points=True)['g_points'], ref)
+        assert torch.equal(run(0, points_only=True, normalize_points=True)['g_points'], ref_n)

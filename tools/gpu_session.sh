@@ -28,6 +28,32 @@ for w in $WHAT; do
         python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras > $O/pmc.log 2>&1; echo "pmc rc=$?" >> $O/env.txt; tail -30 $O/pmc.log;;
     bwd)
       timeout 600 python tools/bench_backward.py > $O/bench_backward.log 2>&1; tail -20 $O/bench_backward.log;;
+    handoff)
+      timeout 600 python tools/bench_handoff.py > $O/bench_handoff.log 2>&1; tail -6 $O/bench_handoff.log;;
+    prof_inv)
+      (cd /tmp && export TMPDIR=/tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_inv -o inv -- python $R/tools/inversion_synthetic.py > $O/prof_inv.log 2>&1); tail -3 $O/prof_inv.log
+      python - <<PY
+import csv, glob
+for f in glob.glob("$O/prof_inv/**/*kernel_stats.csv", recursive=True):
+    rows = list(csv.DictReader(open(f)))
+    tot = sum(float(r['TotalDurationNs']) for r in rows)
+    print('total kernel ms', tot / 1e6, 'launches', sum(int(r['Calls']) for r in rows))
+    for r in rows[:22]:
+        print('%8.3f ms %6s calls %8.1f us  %s' % (float(r['TotalDurationNs']) / 1e6, r['Calls'], float(r['AverageNs']) / 1e3, r['Name'][:90]))
+PY
+      ;;
+    prof_train)
+      (cd /tmp && export TMPDIR=/tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_train -o tr -- python $R/bench.py --mode train --steps 20 --warmup 5 > $O/prof_train.log 2>&1); tail -c 400 $O/prof_train.log
+      python - <<PY
+import csv, glob
+for f in glob.glob("$O/prof_train/**/*kernel_stats.csv", recursive=True):
+    rows = list(csv.DictReader(open(f)))
+    tot = sum(float(r['TotalDurationNs']) for r in rows)
+    print('total kernel ms', tot / 1e6, 'launches', sum(int(r['Calls']) for r in rows))
+    for r in rows[:22]:
+        print('%8.3f ms %6s calls %8.1f us  %s' % (float(r['TotalDurationNs']) / 1e6, r['Calls'], float(r['AverageNs']) / 1e3, r['Name'][:90]))
+PY
+      ;;
   esac
 done
 cat $O/env.txt
