@@ -41,11 +41,11 @@ class _Mapping(nn.Module):
 class _Synthesis(nn.Module):
     """ws[:, :14] -> [B,96,R,R]: a fixed smooth basis modulated by the latents."""
 
-    def __init__(self, res, gen):
+    def __init__(self, res, gen, n_basis=16):
         super().__init__()
         self.res = res
-        self.basis = nn.Parameter(torch.randn(16, 96, res, res, generator=gen))
-        self.proj = nn.Linear(512, 16)
+        self.basis = nn.Parameter(torch.randn(16, 96, res, res, generator=gen)[:n_basis].clone())
+        self.proj = nn.Linear(512, n_basis)
 
     def forward(self, ws, **kw):
         coef = self.proj(ws.mean(dim=1))
@@ -78,7 +78,7 @@ class _ViewDirMapper(nn.Module):
 
 
 class StandInGenerator(nn.Module):
-    def __init__(self, scene_range, attention_values=10, use_sdf=True, plane_res=64, seed=5, use_viewdir=False):
+    def __init__(self, scene_range, attention_values=10, use_sdf=True, plane_res=64, seed=5, use_viewdir=False, n_basis=16):
         super().__init__()
         gen = torch.Generator().manual_seed(seed)
         self.scene_range = scene_range
@@ -88,7 +88,7 @@ class StandInGenerator(nn.Module):
         self.use_encoder = False
         self.num_classes = None
         self.mapping_network = _Mapping(15 if attention_values > 0 else 14, gen)
-        self.synthesis_network = _Synthesis(plane_res, gen)
+        self.synthesis_network = _Synthesis(plane_res, gen, n_basis)
         self.decoder = _Decoder(33 if use_viewdir else (1 + attention_values if attention_values > 0 else 4), gen)
         if use_viewdir:
             self.viewdir_mapper = _ViewDirMapper(attention_values if attention_values > 0 else 3, gen)
