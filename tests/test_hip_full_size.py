@@ -37,7 +37,7 @@ def make_inputs(B, dev, radius=2.0, seed=1234, R=R, S=S):
     return {k: v.to(dev) for k, v in d.items()}
 
 
-def hip(d, white=True, skip=True, att=None, sl=slice(None), taps=()):
+def hip(d, white=True, skip=True, att=None, sl=slice(None), taps=(), tuning=0):
     R, S = d['noise_c'].shape[1], d['noise_c'].shape[3]
     texels = ops.planes_to_texels(d['planes'][sl].contiguous())
     image = ops.decoder_pack(d['w1'], d['b1'], d['w2'], d['b2'], A)
@@ -45,7 +45,7 @@ def hip(d, white=True, skip=True, att=None, sl=slice(None), taps=()):
     return ops.render_fwd(d['cam'][sl].contiguous(), d['focal'][sl].contiguous(), R, R, S, texels, image, 0.55, A,
                           (d['att'] if att is None else att)[sl].contiguous(), True, d['beta'], d['alpha'],
                           noise_coarse=d['noise_c'][sl].contiguous(), noise_fine=nf, white_background=white,
-                          skip_missed_rays=skip, taps=taps)
+                          skip_missed_rays=skip, taps=taps, tuning=tuning)
 
 
 def oracle(d, dev, white=True):
@@ -102,6 +102,9 @@ def test_cfg2_batch_properties(gpu_device):
     full = hip(d, white=True, skip=False)
     for k in ('rgb', 'depth', 'mask'):
         assert torch.equal(a[k], full[k]), 'skipping missed rays changed ' + k
+    per_scene = hip(d, tuning=512)                                # work hand-out experiment: one scene per XCD
+    for k in ('rgb', 'depth', 'mask'):
+        assert torch.equal(a[k], per_scene[k]), 'scene-per-XCD queues changed ' + k
     hit_frac = (a['mask'] > 0).float().mean().item()
     assert 0.2 < hit_frac < 0.9, hit_frac                       # chairs-like geometry: many rays miss
     assert float(a['mask'].min()) >= 0.0 and float(a['mask'].max()) <= 1.0 + 1e-5
