@@ -42,6 +42,10 @@ typedef enum nfi_status {
 } nfi_status;
 
 enum { NFI_PLANE_CHANNELS = 32, NFI_HIDDEN = 64, NFI_MAX_ATTENTION = 14, NFI_MAX_SAMPLES = 128 };
+/* NFI_MAX_SAMPLES: samples per ray and PASS of the two-pass (coarse + fine) pipeline and of the fused kernel.  A single
+ * pass without fine sampling (run.py:512-514: 128 samples; the inversion loop asks for ray_multiplier = 4, run.py:2271)
+ * can hold up to NFI_MAX_SAMPLES_SINGLE_PASS samples in nfi_ray_weights / nfi_composite_fwd / nfi_composite_bwd. */
+enum { NFI_MAX_SAMPLES_SINGLE_PASS = 512 };
 
 /* texel storage type of the channel-last plane image */
 enum { NFI_TEXEL_F32 = 0, NFI_TEXEL_BF16 = 1, NFI_TEXEL_F16 = 2 };
@@ -191,7 +195,7 @@ int nfi_bbox_overlay(const float* points, int64_t n_points, float scene_range, f
  * ------------------------------------------------------------------------------------------ */
 typedef struct nfi_weights_args {
   int64_t n_rays;
-  int n_samples;               /* <= NFI_MAX_SAMPLES */
+  int n_samples;               /* <= NFI_MAX_SAMPLES_SINGLE_PASS */
   const float* sigma;          /* [N,S] */
   const float* ray_directions; /* [N,3] */
   const float* depth;          /* [N,S] */
@@ -248,7 +252,7 @@ int nfi_resample(const nfi_resample_args* a, nfi_stream_t stream);
  * ------------------------------------------------------------------------------------------ */
 typedef struct nfi_composite_args {
   int64_t n_rays;
-  int n_a;                      /* samples in list a (<= 128 total with n_b) */
+  int n_a;                      /* samples in list a (n_b == 0: <= 512; merged lists: <= 128 each) */
   int n_b;                      /* 0: plain compositing of list a, assumed in ray order */
   const float* ray_directions;  /* [N,3] */
   const float* depth_a; const float* sigma_a; const float* rgb_a;  /* [N,n_a], [N,n_a], [N,n_a,3] */

@@ -991,22 +991,23 @@ __device__ __forceinline__ CompositeOut composite_slab(const Slab& slab, int n, 
 // ------------------------------------------------------------------------------------------------
 // stand-alone stage kernels (one wave per ray)
 // ------------------------------------------------------------------------------------------------
+template <int NS>
 __global__ __launch_bounds__(256) void ray_weights_kernel(nfi_weights_args a) {
   const int lane = lane_id();
   const int64_t ray = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (ray >= a.n_rays) return;
   const int S = a.n_samples;
-  float sig[2], t[2], w[2];
+  float sig[NS], t[NS], w[NS];
 #pragma unroll
-  for (int j = 0; j < 2; ++j) {
+  for (int j = 0; j < NS; ++j) {
     int e = j * 64 + lane;
     sig[j] = e < S ? a.sigma[ray * S + e] : 0.0f;
     t[j] = e < S ? a.depth[ray * S + e] : 0.0f;
   }
   float dn = norm3(a.ray_directions[ray * 3], a.ray_directions[ray * 3 + 1], a.ray_directions[ray * 3 + 2]);
-  ray_weights<2>(sig, t, S, dn, lane, w);
+  ray_weights<NS>(sig, t, S, dn, lane, w);
 #pragma unroll
-  for (int j = 0; j < 2; ++j) {
+  for (int j = 0; j < NS; ++j) {
     int e = j * 64 + lane;
     if (e < S) a.weights[ray * S + e] = w[j];
   }
@@ -1014,8 +1015,10 @@ __global__ __launch_bounds__(256) void ray_weights_kernel(nfi_weights_args a) {
 
 extern "C" int nfi_ray_weights(const nfi_weights_args* a, nfi_stream_t stream) {
   REQUIRE(a && a->sigma && a->ray_directions && a->depth && a->weights, "ray_weights: null pointer");
-  REQUIRE(a->n_rays > 0 && a->n_samples > 0 && a->n_samples <= NFI_MAX_SAMPLES, "ray_weights: n_samples must be in [1,128]");
-  hipLaunchKernelGGL(ray_weights_kernel, dim3((unsigned)((a->n_rays + 3) / 4)), dim3(256), 0, (hipStream_t)stream, *a);
+  REQUIRE(a->n_rays > 0 && a->n_samples > 0 && a->n_samples <= NFI_MAX_SAMPLES_SINGLE_PASS, "ray_weights: n_samples must be in [1,512]");
+  const dim3 grid((unsigned)((a->n_rays + 3) / 4));
+  if (a->n_samples <= 128) hipLaunchKernelGGL(ray_weights_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, *a);
+  else hipLaunchKernelGGL(ray_weights_kernel<8>, grid, dim3(256), 0, (hipStream_t)stream, *a);
   return check_launch("ray_weights");
 }
 
@@ -1207,13 +1210,15 @@ __global__ __launch_bounds__(256) void composite_kernel(nfi_composite_args a) {
 extern "C" int nfi_composite_fwd(const nfi_composite_args* a, nfi_stream_t stream) {
   REQUIRE(a && a->ray_directions && a->depth_a && a->sigma_a && a->rgb_a && a->rgb_map && a->depth_map && a->mask,
           "composite: null pointer");
-  REQUIRE(a->n_rays > 0 && a->n_a > 0 && a->n_b >= 0 && a->n_a + a->n_b <= 2 * NFI_MAX_SAMPLES,
-          "composite: need 1 <= n_a + n_b <= 256");
+  REQUIRE(a->n_rays > 0 && a->n_a > 0 && a->n_b >= 0 && a->n_a + a->n_b <= NFI_MAX_SAMPLES_SINGLE_PASS,
+          "composite: need 1 <= n_a + n_b <= 512");
+  REQUIRE(a->n_b == 0 || (a->n_a <= NFI_MAX_SAMPLES && a->n_b <= NFI_MAX_SAMPLES), "composite: merged lists hold at most 128 samples each");
   REQUIRE(a->n_b == 0 || (a->depth_b && a->sigma_b && a->rgb_b), "composite: list b missing");
   REQUIRE(a->n_extra == 0 || (a->extra_a && (a->n_b == 0 || a->extra_b)), "composite: extra attribute missing");
   const dim3 grid((unsigned)((a->n_rays + 3) / 4));
   if (a->n_a + a->n_b <= 128) hipLaunchKernelGGL(composite_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, *a);
-  else hipLaunchKernelGGL(composite_kernel<4>, grid, dim3(256), 0, (hipStream_t)stream, *a);
+  else if (a->n_a + a->n_b <= 256) hipLaunchKernelGGL(composite_kernel<4>, grid, dim3(256), 0, (hipStream_t)stream, *a);
+  else hipLaunchKernelGGL(composite_kernel<8>, grid, dim3(256), 0, (hipStream_t)stream, *a);
   return check_launch("composite_fwd");
 }
 

@@ -57,8 +57,9 @@ def _render(cfg, dcfg, target_model, height, width, tform_cam2world, focal_lengt
             depth_samples_per_ray, randomize=True, compute_normals=False, compute_semantics=False,
             compute_coords=False, extra_model_outputs=[], extra_model_inputs={}, force_no_cam_grad=False):
     S = depth_samples_per_ray
-    if S > 128:
-        raise NotImplementedError('depth_samples_per_ray > 128 per pass is not supported by the HIP kernels')
+    if S > 512 or (S > 128 and cfg.fine_sampling):
+        raise NotImplementedError('depth_samples_per_ray: at most 128 per pass with fine sampling, 512 without '
+                                  '(run.py asks for 64 + 64, or 128 / 512 in one pass), got %d' % S)
     scene_range = dcfg['scene_range']
     white = dcfg['white_background']
     if compute_normals:
@@ -87,7 +88,7 @@ def _render(cfg, dcfg, target_model, height, width, tform_cam2world, focal_lengt
     del model_outputs['sampler']
     fused = getattr(sampler, 'fused', None)
 
-    if fused is not None and plain and not cam_grad and not fused.requires_grad:
+    if fused is not None and plain and not cam_grad and not fused.requires_grad and S <= 128:
         # ---------------- fused inference path (the kernel generates the rays itself) ----------------
         noise_f = None
         if cfg.fine_sampling and randomize:

@@ -159,6 +159,10 @@ CASES = {
     'persp_coords_black_fine_rand': dict(B=2, H=8, W=8, S=16, scene_range=0.55, radius=1.6, focal=1.0254,
                                          white=False, fine=True, randomize=True, sdf=True, A=10, alpha=0.05,
                                          beta=0.1, bbox=False, ortho=False, coords=True),
+    # one pass without fine sampling at the inversion loop's sample count (run.py:512-514 x ray_multiplier 4, run.py:2271)
+    'persp_s512_coarse_only_rand': dict(B=1, H=5, W=4, S=512, scene_range=0.55, radius=1.3, focal=1.0254,
+                                        white=False, fine=False, randomize=True, sdf=True, A=10, alpha=0.02,
+                                        beta=0.1, bbox=False, ortho=False),
     'persp_s96_black_fine_det': dict(B=1, H=6, W=6, S=96, scene_range=0.55, radius=1.3, focal=1.0254,
                                      white=False, fine=True, randomize=False, sdf=True, A=10, alpha=0.02,
                                      beta=0.1, bbox=False, ortho=False),

@@ -276,8 +276,8 @@ def test_field_query_backward_viewdir(gpu_device, A, use_sdf, N, S):
         rel_close(a, b, 'grad ' + n, 5e-4)
 
 
-@pytest.mark.parametrize('fine,ortho', [(True, False), (False, False), (True, True)])
-def test_render_backward_end_to_end(gpu_device, fine, ortho):
+@pytest.mark.parametrize('fine,ortho,S', [(True, False, 32), (False, False, 32), (True, True, 32), (False, False, 512)])
+def test_render_backward_end_to_end(gpu_device, fine, ortho, S):
     """d(rgb, mask)/d(planes producer params, decoder, beta, alpha, attention values, camera, focal) through
     nfi_render.render (staged HIP path) against autograd of the oracle with the same noise."""
     from test_host_api_gpu import RandTap
@@ -288,7 +288,7 @@ def test_render_backward_end_to_end(gpu_device, fine, ortho):
         model.alpha.fill_(0.2)
     nfi_gen.attach(model)
     g = torch.Generator().manual_seed(21)
-    B, H, W, S = 2, 12, 10, 32
+    B, H, W = 2, 12, 10                # S = 512: one pass at the inversion loop's sample count without fine sampling
     cam0 = look_at_cameras(B, 1.5, g)
     focal0 = None if ortho else torch.full((B,), 1.1)
     if ortho:
