@@ -315,7 +315,7 @@ typedef struct nfi_field_bwd_args {
   int n_scenes;
   int64_t points_per_scene;
   const float* points;
-  const void* texels; int plane_res; int texel_dtype;   /* fp32 texels only */
+  const void* texels; int plane_res; int texel_dtype;   /* any storage type; g_texels is fp32 (view-direction decoder: fp32 texels only) */
   const float* decoder_image;                            /* forward operand image */
   const float* w1; const float* w2;                      /* raw decoder weights (backward operands) */
   int n_attention; const float* attention_values;

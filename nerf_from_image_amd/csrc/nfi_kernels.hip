@@ -2,6 +2,7 @@
 // See include/nfi_hip.h for the contract and nfi_device.hpp for the building blocks.
 #include "nfi_device.hpp"
 #include "../../include/nfi_hip.h"
+#include "nfi_host.hpp"
 
 #include <algorithm>
 #include <cstdio>
@@ -9,31 +10,11 @@
 
 using namespace nfi;
 
-// ------------------------------------------------------------------------------------------------
-// error plumbing
-// ------------------------------------------------------------------------------------------------
-static thread_local char g_err[256] = "";
-static int fail(int code, const char* msg) {
-  snprintf(g_err, sizeof(g_err), "%s", msg);
-  return code;
-}
-static int check_launch(const char* what) {
-  hipError_t e = hipGetLastError();
-  if (e != hipSuccess) {
-    snprintf(g_err, sizeof(g_err), "%s: %s", what, hipGetErrorString(e));
-    return NFI_ERR_LAUNCH;
-  }
-  return NFI_OK;
-}
-extern "C" const char* nfi_last_error(void) { return g_err; }
+// error plumbing, argument checks and the LDS staging helpers shared with nfi_backward_field.hip: nfi_host.hpp
+thread_local char nfi_err_buf[256] = "";
+extern "C" const char* nfi_last_error(void) { return nfi_err_buf; }
 extern "C" int nfi_version(void) { return 100; }
 
-#define REQUIRE(cond, msg) \
-  do {                     \
-    if (!(cond)) return fail(NFI_ERR_INVALID_ARGUMENT, msg); \
-  } while (0)
-
-static inline int texel_bytes(int dtype) { return dtype == NFI_TEXEL_F32 ? 128 : 64; }
 
 // ------------------------------------------------------------------------------------------------
 // planes [B,3,32,R,R] <-> texels [B,3,R,R,32]
@@ -491,41 +472,6 @@ struct FieldKernelParams {
   int layout;
 };
 
-// stage the decoder image (+ this scene's attention values in accumulator layout) into LDS
-__device__ __forceinline__ void stage_field_lds(float* lds, const float* image, const float* att_scene, int A,
-                                                int n_image = kLdsImageFloats) {
-  for (int i = threadIdx.x; i < n_image; i += blockDim.x) lds[i] = image[i];
-  for (int i = threadIdx.x; i < 64; i += blockDim.x) {
-    int c = i & 3, row = i >> 2;  // row = 4g + r; value for feature row-1
-    float v = 0.0f;
-    if (att_scene && c < 3 && row >= 1 && row <= A) v = att_scene[(row - 1) * 3 + c];
-    lds[n_image + i] = v;
-  }
-}
-
-__device__ __forceinline__ FieldParams make_field_params(const void* texels_scene, int res, int tex, int A, int use_sdf,
-                                                         const float* beta, const float* alpha, const float* lds,
-                                                         int n_image = kLdsImageFloats, int layout = 0) {
-  FieldParams P;
-  uint32_t tb = tex == 0 ? 128u : 64u;
-  P.scene_bytes = 3u * (uint32_t)res * (uint32_t)res * tb;
-  P.pix_bytes = layout ? 3u * tb : tb;
-  P.plane_bytes = layout ? tb : (uint32_t)res * (uint32_t)res * tb;
-  P.row_bytes = (uint32_t)res * P.pix_bytes;
-  P.row_pix_bytes = P.row_bytes + P.pix_bytes;
-  P.rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(texels_scene), 0, (int)P.scene_bytes, 0x00020000);
-  P.res = res;
-  P.res_m1 = (float)(res - 1);
-  P.n_attention = A;
-  P.use_sdf = use_sdf;
-  P.inv_alpha = use_sdf ? 1.0f / alpha[0] : 1.0f;
-  P.beta = use_sdf ? beta[0] : 1.0f;
-  P.neg_log2e_over_beta = -kLog2e / P.beta;
-  P.lds = lds;
-  P.vf = lds + n_image;
-  return P;
-}
-
 template <int TEX, bool ATT, bool VD = false>
 __global__ __launch_bounds__(256) void field_query_kernel(FieldKernelParams k) {
   constexpr int kImg = VD ? kVdImageFloats : kLdsImageFloats;
@@ -558,18 +504,6 @@ __global__ __launch_bounds__(256) void field_query_kernel(FieldKernelParams k) {
       if (k.outside) k.outside[gi] = out ? 1 : 0;
     }
   }
-}
-
-static int check_field_common(const void* texels, int plane_res, int texel_dtype, const float* image, int A,
-                              const float* att, int use_sdf, const float* beta, const float* alpha, int layout = 0) {
-  REQUIRE(layout == NFI_TEXELS_PLANAR || layout == NFI_TEXELS_INTERLEAVED, "field: bad texel layout");
-  REQUIRE(texels && image, "field: null texels / decoder image");
-  REQUIRE(plane_res >= 2 && plane_res <= 1024, "field: plane_res must be in [2,1024]");
-  REQUIRE(texel_dtype >= NFI_TEXEL_F32 && texel_dtype <= NFI_TEXEL_F16, "field: bad texel dtype");
-  REQUIRE(A >= 0 && A <= NFI_MAX_ATTENTION, "field: attention_values must be in [0,14]");
-  REQUIRE(A == 0 || att, "field: attention_values tensor missing");
-  REQUIRE(!use_sdf || (beta && alpha), "field: use_sdf needs beta and alpha");
-  return NFI_OK;
 }
 
 extern "C" int nfi_field_query_fwd(const nfi_field_args* a, nfi_stream_t stream) {
@@ -1223,7 +1157,7 @@ extern "C" int nfi_composite_fwd(const nfi_composite_args* a, nfi_stream_t strea
 }
 
 #include "nfi_backward_rays.inc"
-#include "nfi_backward_field.inc"
+// nfi_backward_field.inc is its own translation unit (nfi_backward_field.hip: built without SLP vectorisation)
 #include "nfi_regulariser.inc"
 #include "nfi_neighbours.inc"
 #include "nfi_handoff.inc"

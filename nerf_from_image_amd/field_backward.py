@@ -18,8 +18,8 @@ def field_query_bwd(points, texels, decoder_image, w1, w2, scene_range, n_attent
     points = f(points, 'points')
     B, P = points.shape[0], points.shape[1]
     dev = points.device
-    if texels.dtype != torch.float32:
-        raise TypeError('field_query_bwd: gradients need fp32 texels')
+    if texels.dtype != torch.float32 and viewdir is not None:
+        raise NotImplementedError('field_query_bwd: the view-direction decoder needs fp32 texels')
     n_out = 1 + n_attention if n_attention > 0 else 4
     n3 = n_attention if n_attention > 0 else 3
     if viewdir is not None:
@@ -27,7 +27,8 @@ def field_query_bwd(points, texels, decoder_image, w1, w2, scene_range, n_attent
     lib = _lib.load()
     out = {}
     if not points_only:
-        out = {'g_texels': torch.zeros_like(texels),
+        # fp32 gradient image in the texels' layout (16-bit texel storage: the gradient w.r.t. the rounded planes)
+        out = {'g_texels': torch.zeros(texels.shape, dtype=torch.float32, device=dev),
                'g_w1': torch.zeros((64, 32), dtype=torch.float32, device=dev),
                'g_b1': torch.zeros((64,), dtype=torch.float32, device=dev),
                'g_w2': torch.zeros((n_out, 64), dtype=torch.float32, device=dev),
@@ -53,7 +54,7 @@ def field_query_bwd(points, texels, decoder_image, w1, w2, scene_range, n_attent
         scatter_mode = 1 if (P >= BINNED_SCATTER_MIN_POINTS and not points_only) else 0
     fields = dict(
             n_scenes=B, points_per_scene=P,
-            points=points, texels=texels, plane_res=ops.texel_res(texels), texel_dtype=ops.TEXEL_F32,
+            points=points, texels=texels, plane_res=ops.texel_res(texels), texel_dtype=ops.texel_dtype_of(texels),
             texel_layout=ops.texel_layout_of(texels),
             decoder_image=decoder_image, w1=f(w1, 'w1'), w2=f(w2, 'w2'), n_attention=n_attention,
             attention_values=f(attention_values, 'attention_values') if n_attention > 0 else None,

@@ -117,8 +117,6 @@ def make_sampler(planes, decoder, scene_range, n_attention, attention_values, us
         if want_normals:
             # generator.py:599-602: SDF only, eval only; every other output is then detached
             assert use_sdf and not getattr(decoder, 'training', False)
-            if texel_dtype != ops.TEXEL_F32:
-                raise NotImplementedError('sampler: normals need fp32 texels')
         bs = x_in.shape[0]
         pts = x_in.reshape(bs, -1, 3)
         spr = 0
@@ -137,7 +135,7 @@ def make_sampler(planes, decoder, scene_range, n_attention, attention_values, us
             return tuple(q[k] for k in ('sigma', 'rgb') + (('sdf',) if want_sdf else ()) +
                          (('semantics',) if want_sem else ()))
         bwd = None
-        if texel_dtype == ops.TEXEL_F32:
+        if texel_dtype == ops.TEXEL_F32 or ray_pad is None:      # (the view-direction decoder's backward is fp32-texel only)
             bwd = make_field_bwd(texels, image, scene_range, n_attention, use_sdf, want_sdf, want_sem, ray_pad, spr)
         args = (pts, planes, w1, b1, w2, b2, attention_values if n_attention > 0 else None,
                 beta if use_sdf else None, alpha if use_sdf else None)

@@ -163,7 +163,20 @@ import nerf_from_image_amd.render as nfi_render  # noqa: E402
 
 @pytest.mark.parametrize('A,use_sdf,P', [(10, True, 200), (0, False, 70), (10, True, 64)])
 def test_field_query_backward(gpu_device, A, use_sdf, P):
-    dev = gpu_device
+    _field_query_backward_case(gpu_device, A, use_sdf, P, None)
+
+
+@pytest.mark.parametrize('scale', [1e-7, 3e4, 'mixed'])
+def test_field_query_backward_at_any_gradient_scale(gpu_device, scale):
+    """The backward is linear in the upstream gradient, whose scale is the caller's business (the inversion loop's
+    mean-squared error over 10^4 pixels hands down 1e-6 per sample).  The kernel's split-fp16 MFMA operands resolve
+    2^-24 ABSOLUTE, so without the per-point power-of-two normalisation tiny upstream gradients lost most of their bits
+    (found in round 2: 3-8 % gradient error in tools/inversion_synthetic.py while every unit-scale test passed).
+    'mixed': every point its own scale over 13 decades; g_points is then checked per point."""
+    _field_query_backward_case(gpu_device, 10, True, 200, scale)
+
+
+def _field_query_backward_case(dev, A, use_sdf, P, scale):
     g = torch.Generator().manual_seed(100 + A + P)
     B, R = 2, 24
     r = float(torch.tensor(0.55, dtype=torch.float32))      # the fp32 value the kernels divide by (face points!)
@@ -178,6 +191,10 @@ def test_field_query_backward(gpu_device, A, use_sdf, P):
     w_sig, w_rgb = torch.randn(B, P, generator=g), torch.randn(B, P, 3, generator=g)
     w_sdf = torch.randn(B, P, generator=g)
     w_sem = torch.randn(B, P, A, generator=g) if A > 0 else None
+    if scale is not None:
+        ps = 10.0 ** (torch.rand(B, P, generator=g) * 13 - 9) if scale == 'mixed' else torch.full((B, P), float(scale))
+        w_sig, w_rgb, w_sdf = w_sig * ps, w_rgb * ps[..., None], w_sdf * ps
+        w_sem = w_sem * ps[..., None] if A > 0 else None
 
     # ---- oracle in float64
     dd = lambda t: None if t is None else t.double().requires_grad_()
@@ -213,6 +230,12 @@ def test_field_query_backward(gpu_device, A, use_sdf, P):
             (['beta', 'alpha'] if use_sdf else [])
     for n, a, b in zip(names, got, ref):
         rel_close(a, b, 'grad ' + n, 5e-4)
+    if scale == 'mixed':
+        # per point: the coordinate gradient relative to that point's own magnitude
+        a, b = got[0].double().cpu(), ref[0]
+        err = (a - b).norm(dim=-1) / b.norm(dim=-1).clamp_min(1e-300)
+        live = b.norm(dim=-1) > 0
+        assert float(err[live].max()) < 2e-3, float(err[live].max())
 
 
 @pytest.mark.parametrize('A,use_sdf,N,S', [(10, True, 12, 16), (0, False, 7, 10), (10, True, 5, 64)])
@@ -377,10 +400,11 @@ def test_binned_scatter_matches_atomic_scatter(gpu_device, P, res):
 
 def test_backward_outputs_without_atomics_are_bit_reproducible(gpu_device):
     """g_points (and the normals path) involve no atomics, so repeated launches must agree bit for bit.  Regression
-    test for a gfx950 hazard found in round 2: a wide ds_write fetches its data registers late (lane groups 48..63
-    last); without draining the LDS queue before the registers are reused, rows 12..15 of the kernel's 16-row LDS
-    tiles were corrupted once in a few launches, depending on timing (tools/dbg_gpoints2.py; nfi_device.hpp,
-    wave_lds_fence)."""
+    test for a round-2 finding: with the coordinate-gradient arithmetic compiled to packed fp32 (v_pk_mul_f32 /
+    v_pk_add_f32 with cross-half op_sel, LLVM's SLP vectoriser) one product of the last plane came out as zero for
+    the wave's lanes 48..63 once in about 1e5 tiles, depending on timing - points 12..15 of a 16-point tile, z
+    component only.  nfi_backward_field.hip is therefore built without SLP vectorisation (tools/determinism_probe.py
+    counts events over thousands of launches: 54 in 1500 before, 0 in 3000 after)."""
     from nerf_from_image_amd import field_backward as fb, ops as hops
     dev = gpu_device
     g = torch.Generator().manual_seed(70500)

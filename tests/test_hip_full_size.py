@@ -124,6 +124,26 @@ def test_cfg2_batch_properties(gpu_device):
         assert torch.equal(torch.cat((lo[k], hi[k])), a[k]), 'image sharding changed ' + k
 
 
+def test_render_is_bit_reproducible_over_many_launches(gpu_device):
+    """300 launches of the fused render on the B=8 workload must agree bit for bit.  The kernel is compiled with packed
+    fp32 arithmetic, which in the field BACKWARD kernel produced a rare timing-dependent wrong product on MI355X
+    (test_hip_backward.py::test_backward_outputs_without_atomics_are_bit_reproducible); two launches would not see an
+    event of that rate, a few hundred full-size launches (3 x 10^7 tiles) would."""
+    d = make_inputs(8, gpu_device, radius=1.3, seed=5)           # every ray marches
+    texels = ops.planes_to_texels(d['planes'])
+    image = ops.decoder_pack(d['w1'], d['b1'], d['w2'], d['b2'], A)
+
+    def run():
+        return ops.render_fwd(d['cam'], d['focal'], R, R, S, texels, image, 0.55, A, d['att'], True, d['beta'], d['alpha'],
+                              noise_coarse=d['noise_c'], noise_fine=d['noise_f'], white_background=True)
+    ref = {k: v.clone() for k, v in run().items() if k in ('rgb', 'depth', 'mask')}
+    bad = 0
+    for _ in range(300):
+        out = run()
+        bad += sum(int(not torch.equal(out[k], ref[k])) for k in ref)
+    assert bad == 0, '%d of 900 outputs differed from the first launch' % bad
+
+
 @pytest.mark.parametrize('radius,seed', [(2.0, 1234), (1.3, 77)])
 def test_cfg2_full_batch_against_oracles(gpu_device, radius, seed):
     """The headline configuration itself (8 images x 128x128 x (64+64)), chairs-like (44 % of the rays miss the cube)

@@ -197,21 +197,63 @@ def test_nerf_utils_api(setup):
 
 
 def test_gradient_request_without_a_backward_fails_loudly(setup):
-    """bf16 texels have no backward kernel: asking for a gradient must raise, never fall back."""
+    """An op without a HIP backward must raise when a gradient is asked for, never fall back to ATen."""
     model, cam, focal, z = setup
+    sigma = (torch.rand(2, 4, 4, 16, device=cam.device) * 5).requires_grad_()
+    ro, rd = nu.get_ray_bundle_normalized(4, 4, focal, cam, None)
+    t = torch.sort(torch.rand(2, 4, 4, 16, device=cam.device), dim=-1)[0] + 0.5
+    w = nu.render_volume_density_weights_only(sigma, ro, rd, t)          # run.py calls it under no_grad only
+    with pytest.raises(NotImplementedError):
+        w.sum().backward()
+    # a view-direction decoder with 16-bit texels has no backward either
     import copy
     from nerf_from_image_amd import ops
-    m2 = nfi_gen.attach(copy.deepcopy(model), texel_dtype=ops.TEXEL_BF16)
-    cfg = types.SimpleNamespace(use_viewdir=False, use_sdf=True, attention_values=10, fine_sampling=True)
+    torch.manual_seed(5)
+    vd = StandInGenerator(0.55, attention_values=10, use_sdf=True, plane_res=32, use_viewdir=True).to(cam.device).eval()
+    nfi_gen.attach(vd, texel_dtype=ops.TEXEL_BF16)
+    cfg = types.SimpleNamespace(use_viewdir=True, use_sdf=True, attention_values=10, fine_sampling=True)
     render = nfi_render.make_render(cfg, {'scene_range': 0.55, 'white_background': True})
     zz = z.clone().requires_grad_()
-    rgb, *_ = render(m2, 8, 8, cam, focal, None, None, zz, 16)
+    rgb, *_ = render(vd, 8, 8, cam, focal, None, None, zz, 16)
     with pytest.raises(NotImplementedError):
         rgb.sum().backward()
-    # fp32 texels: the same call differentiates
-    rgb, *_ = render(model, 8, 8, cam, focal, None, None, zz, 16)
-    rgb.sum().backward()
-    assert zz.grad is not None and torch.isfinite(zz.grad).all() and zz.grad.abs().sum() > 0
+
+
+@pytest.mark.parametrize('tdt_name', ['bf16', 'fp16'])
+def test_gradients_with_16_bit_texel_storage(setup, tdt_name):
+    """BASELINE cfg2 'bf16' / cfg5 'fp16' plane storage in training: forward and gradients equal the oracle evaluated
+    on the ROUNDED planes (arithmetic stays fp32; the gradient passes through the rounding unchanged)."""
+    import copy
+    from nerf_from_image_amd import ops
+    model, cam, focal, z = setup
+    tdt, tt = (ops.TEXEL_BF16, torch.bfloat16) if tdt_name == 'bf16' else (ops.TEXEL_F16, torch.float16)
+    m2 = nfi_gen.attach(copy.deepcopy(model), texel_dtype=tdt)
+    cfg = types.SimpleNamespace(use_viewdir=False, use_sdf=True, attention_values=10, fine_sampling=True)
+    dcfg = {'scene_range': 0.55, 'white_background': True}
+    render = nfi_render.make_render(cfg, dcfg)
+    H, W, S = 10, 12, 32
+    g = torch.Generator().manual_seed(8)
+    w_rgb = torch.randn(2, H, W, 3, generator=g)
+    cam_g = cam.clone().requires_grad_()
+    params = [m2.synthesis_network.basis, m2.decoder.net[0].weight, m2.decoder.net[2].weight, m2.beta, cam_g]
+    with RandTap() as tap:
+        rgb, _, mask, _, _, _ = render(m2, H, W, cam_g, focal, None, None, z, S)
+    got = torch.autograd.grad((rgb * w_rgb.to(cam.device)).sum() + mask.sum(), params)
+    # oracle in float64 on planes rounded to the storage type, straight-through gradient into the producer
+    m64 = copy.deepcopy(model).cpu().double()
+    planes, att = m64.planes_and_values(z.cpu().double())
+    rounded = planes + (planes.detach().float().to(tt).double() - planes.detach())
+    dec = m64.decoder.net
+    cam64 = cam.detach().cpu().double().requires_grad_()
+    o = orc.render(rounded, dec[0].weight, dec[0].bias, dec[2].weight, dec[2].bias, cam64, focal.cpu().double(), H, W, S,
+                   0.55, white_background=True, noise_coarse=tap.draws[0].double(), noise_fine=tap.draws[1].double(),
+                   use_sdf=True, beta=m64.beta, alpha=m64.alpha, attention_values=att)
+    close(rgb, o['rgb'].float(), 2e-4, 'rgb on rounded planes')
+    ref = torch.autograd.grad((o['rgb'] * w_rgb.double()).sum() + o['mask'].sum(),
+                              [m64.synthesis_network.basis, dec[0].weight, dec[2].weight, m64.beta, cam64])
+    for name, a, b in zip(('plane producer', 'w1', 'w2', 'beta', 'camera'), got, ref):
+        scale = b.abs().max().item()
+        assert (a.cpu().double() - b).abs().max().item() <= 2e-3 * scale, (name, (a.cpu().double() - b).abs().max().item(), scale)
 
 
 def test_normals_sampler_and_render(setup):
