@@ -417,9 +417,7 @@ typedef struct nfi_render_args {
    * split-fp16 (hi+lo, 22 significand bits) MFMA; both meet the 1e-4 parity budget.  bit 4: ONE device-wide work
    * counter instead of the per-XCD queues over 16x16-pixel blocks (results identical; the per-XCD queues need image
    * sides that are multiples of 16 and fall back to the single counter otherwise).  bits 5-8: measurement knobs of
-   * those queues (5-6: block side 1 -> 8, 2 -> 32 pixels; 7 / 8: 4 / 2 positions per atomic), results identical.
-   * bit 9 (experiment, slower on MI355X): with >= 8 scenes every XCD marches whole scenes of its own instead of all
-   * XCDs sharing each scene; results identical. */
+   * those queues (5-6: block side 1 -> 8, 2 -> 32 pixels; 7 / 8: 4 / 2 positions per atomic), results identical. */
   int tuning;
   /* optional uint64[12] device array: per-phase shader-cycle sums over all waves (profiling build of
    * the kernel; NULL = off): field tile {issue, wait+interp, mlp, count}, ray set-up, coarse field,

@@ -1179,7 +1179,6 @@ struct RenderKernelParams {
   uint32_t* xcd_counter;   // 8 counters, 64 bytes apart
   int xcd_block_shift;     // log2 of the block side: 3, 4 or 5
   int fetch_batch;         // positions taken per atomic
-  int xcd_scenes;          // 1: queue q holds the blocks of scenes q, q+8, ... (every XCD works on its own scene)
   // field
   const void* texels; int res; int layout;
   const float* image; int A; const float* att;
@@ -1244,14 +1243,8 @@ struct RayQueue {
     q_cur = xcd; pos_next = 0; pos_end = 0; dry = false;
     batch = (uint32_t)k.fetch_batch;
   }
-  // block id of queue q's i-th block: interleaved over the XCDs (all XCDs on one scene), or scene-major per queue
-  __device__ __forceinline__ uint32_t block_of(uint32_t q, uint32_t i) const {
-    if (!k.xcd_scenes) return i * 8u + q;
-    const uint32_t round = i / bps;
-    return (round * 8u + q) * bps + (i - round * bps);
-  }
   __device__ __forceinline__ uint32_t ray_at(uint32_t q, uint32_t pos) const {
-    const uint32_t b = block_of(q, pos >> (2 * bsh));
+    const uint32_t b = (pos >> (2 * bsh)) * 8u + q;
     const uint32_t in = pos & ((1u << (2 * bsh)) - 1u), scene = b / bps, bb = b - scene * bps;
     const uint32_t by = bb / bw, bx = bb - by * bw;
     const uint32_t st = in >> 6, sty = st >> (bsh - 3), stx = st & ((1u << (bsh - 3)) - 1u);   // 8x8 sub-tile of the block
@@ -1270,7 +1263,7 @@ struct RayQueue {
         uint32_t base = 0;
         if (lane == 0) base = atomicAdd(k.xcd_counter + q_cur * 16, batch);
         base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
-        if (block_of(q_cur, base >> (2 * bsh)) < n_blocks) { pos_next = base; pos_end = base + batch; dry = false; break; }
+        if ((base >> (2 * bsh)) * 8u + q_cur < n_blocks) { pos_next = base; pos_end = base + batch; dry = false; break; }
         q_cur = (q_cur + 1) & 7u;        // this queue is empty: steal from the next XCD's
       }
     }
@@ -1789,12 +1782,10 @@ extern "C" int nfi_render_fwd(const nfi_render_args* a, nfi_stream_t stream) {
     k.xcd_block_shift = sel == 1 ? 3 : (sel == 2 ? 5 : 4);
     const int side = 1 << k.xcd_block_shift;
     k.xcd_blocks = (((a->tuning >> 4) & 1) == 0 && (a->width % side == 0) && (a->height % side == 0)) ? 1 : 0;
-    // experiment (tuning bit 9, results identical): with >= 8 scenes every XCD marches whole scenes of its own, so that
-    // its L2 holds ONE scene's texels instead of a share of the scene all eight XCDs are streaming.  Measured on MI355X
-    // (tools/quick_bench.py, 8 x 128^2 x (64+64)): 1.148 ms against 1.095 ms with all XCDs on one scene, 1.732 against
-    // 1.664 ms when every ray hits - the shared scene keeps the eight L2s' misses on lines another XCD has just pulled
-    // into the Infinity Cache, which matters more than the L2 footprint.  Off by default.
-    k.xcd_scenes = (k.xcd_blocks && a->n_scenes >= 8 && ((a->tuning >> 9) & 1) != 0) ? 1 : 0;
+    // (A scene-per-XCD hand-out - queue q holding the blocks of scenes q, q+8, ... so that every XCD's L2 holds one
+    // scene's texels - was tried in round 2 and is slower: the shared scene keeps the eight L2s' misses on lines another
+    // XCD has just pulled into the Infinity Cache.  Even as a run-time option it cost the default path 13 %, the extra
+    // division in the per-ray position decode; removed, DESIGN.md "negative results".)
   }
   k.xcd_counter = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(a->workspace) + 64 + (size_t)n * 32 +
                                               (((size_t)n + 63) & ~(size_t)63));

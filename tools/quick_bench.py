@@ -34,7 +34,7 @@ def main():
         image = ops.decoder_pack(w1, b1, w2, b2, A)
         texels = ops.planes_to_texels(planes)
         ws = None
-        for skip, tuning in ((True, 0), (True, 512), (True, 8), (True, 16)):      # default / one scene per XCD / fp32 MLP / single work counter
+        for skip, tuning in ((True, 0), (True, 8), (True, 16)):      # default / fp32 MLP / single work counter
             def step():
                 return ops.render_fwd(cam, focal, R, R, S, texels, image, 0.55, A, att, True, beta, alpha,
                                       noise_coarse=noise_c, noise_fine=noise_f, skip_missed_rays=skip, workspace=ws,
