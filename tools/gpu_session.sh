@@ -27,8 +27,8 @@ for w in $WHAT; do
       timeout 1200 python tools/pmc_collect.py --kernel render_fwd_kernel --out $O/pmc_render_fwd.json --marched-from-bench -- \
         python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras > $O/pmc.log 2>&1; echo "pmc rc=$?" >> $O/env.txt; tail -30 $O/pmc.log;;
     pmc_bwd)
-      # the field backward kernel inside the training step (4 images x 128x128 rays x 128 samples per launch)
-      timeout 1200 python tools/pmc_collect.py --kernel field_query_bwd_kernel --out $O/pmc_backward.json --units 8388608 -- \
+      # the field backward kernel inside the training step (4 images x 128x128 rays x 64 samples per launch: the coarse and the fine half are separate launches)
+      timeout 1200 python tools/pmc_collect.py --kernel field_query_bwd_kernel --out $O/pmc_backward.json --units 4194304 -- \
         python $R/bench.py --mode train --steps 4 --warmup 2 > $O/pmc_bwd.log 2>&1; echo "pmc_bwd rc=$?" >> $O/env.txt; tail -30 $O/pmc_bwd.log;;
     bwd)
       timeout 600 python tools/bench_backward.py > $O/bench_backward.log 2>&1; tail -20 $O/bench_backward.log;;
