@@ -4,9 +4,14 @@ Same attribute names and call conventions as models/generator.py:336-405 for eve
 path touches (mapping_network(.backbone.num_ws), synthesis_network, texture_mapper, decoder.net[0|2],
 beta, alpha); the producers themselves are tiny so tests stay fast."""
 import math
+import os
+import sys
 
 import torch
 from torch import nn
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tools'))
+from basis_mix import basis_mix  # noqa: E402
 
 
 class _Lin(nn.Module):
@@ -49,7 +54,7 @@ class _Synthesis(nn.Module):
 
     def forward(self, ws, **kw):
         coef = self.proj(ws.mean(dim=1))
-        return torch.einsum('bk,kchw->bchw', coef, self.basis)
+        return basis_mix(coef, self.basis)
 
 
 class _Texture(nn.Module):
