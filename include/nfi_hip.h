@@ -179,6 +179,8 @@ typedef struct nfi_field_args {
   const float* ray_features;
   int samples_per_ray;
   int texel_layout;              /* NFI_TEXELS_PLANAR (0) / NFI_TEXELS_INTERLEAVED */
+  int mlp_precision;             /* 0: exact fp32 MFMA (default); 1: split-fp16 operands with fp32 accumulation, the fused
+                                  * renderer's decoder arithmetic (sigma within 3e-5 relative of mode 0) */
 } nfi_field_args;
 int nfi_field_query_fwd(const nfi_field_args* a, nfi_stream_t stream);
 

@@ -472,13 +472,21 @@ struct FieldKernelParams {
   int layout;
 };
 
-template <int TEX, bool ATT, bool VD = false>
+// PREC: 0 = exact fp32 MFMA (the sampler closure's default: bitwise an fmaf chain), 1 = split-fp16 operands as in the
+// fused renderer (render()'s differentiable path: the same decoder arithmetic in both of its paths, and what the
+// backward kernel recomputes)
+template <int TEX, bool ATT, bool VD = false, int PREC = 0>
 __global__ __launch_bounds__(256) void field_query_kernel(FieldKernelParams k) {
   constexpr int kImg = VD ? kVdImageFloats : kLdsImageFloats;
   __shared__ __attribute__((aligned(16))) float lds[kImg + 64];
   __shared__ __attribute__((aligned(16))) float stages[4][16 * 36];
   const int scene = blockIdx.y;
   stage_field_lds(lds, k.image, k.att ? k.att + (size_t)scene * k.A * 3 : nullptr, k.A, kImg);
+  if (PREC == 1) {
+    // fp16 fragments overlay the fp32 fragment area; biases stay where they are
+    __syncthreads();
+    for (int i = threadIdx.x; i < kB1F; i += blockDim.x) lds[i] = k.image[kW1H + i];
+  }
   __syncthreads();
   const size_t tb = TEX == 0 ? 128 : 64;
   const char* tex_scene = reinterpret_cast<const char*>(k.texels) + (size_t)scene * 3 * k.res * k.res * tb;
@@ -495,7 +503,7 @@ __global__ __launch_bounds__(256) void field_query_kernel(FieldKernelParams k) {
     if (valid) { px = k.points[gi * 3]; py = k.points[gi * 3 + 1]; pz = k.points[gi * 3 + 2]; }
     bool out;
     float* sem = k.sem ? k.sem + ((size_t)scene * k.P + chunk * 64) * k.A : nullptr;
-    SampleOut so = field_wave<TEX, ATT, false, 0, VD>(P, k.scene_range, lane, px, py, pz, valid, sem, &out, stages[wave],
+    SampleOut so = field_wave<TEX, ATT, false, PREC, VD>(P, k.scene_range, lane, px, py, pz, valid, sem, &out, stages[wave],
                                                       nullptr, xray_scene, VD && valid ? (int)(p / k.spr) : 0);
     if (valid) {
       k.sigma[gi] = so.sigma;
@@ -519,6 +527,8 @@ extern "C" int nfi_field_query_fwd(const nfi_field_args* a, nfi_stream_t stream)
                       a->sigma, a->rgb, a->sdf, a->semantics, a->outside, a->ray_features, a->samples_per_ray, a->texel_layout};
   REQUIRE(!a->ray_features || (a->samples_per_ray > 0 && a->points_per_scene % a->samples_per_ray == 0),
           "field_query: with ray_features, points_per_scene must be a multiple of samples_per_ray");
+  REQUIRE(a->mlp_precision == 0 || (a->mlp_precision == 1 && !a->ray_features),
+          "field_query: mlp_precision must be 0 (exact fp32) or 1 (split fp16; not with the view-direction decoder)");
   int64_t chunks = (a->points_per_scene + 63) / 64;
   int64_t blocks = (chunks + 3) / 4;
   if (blocks > 2048) blocks = 2048;
@@ -530,6 +540,9 @@ extern "C" int nfi_field_query_fwd(const nfi_field_args* a, nfi_stream_t stream)
     if (a->ray_features) {                                                                            \
       if (att) hipLaunchKernelGGL((field_query_kernel<TEX, true, true>), grid, dim3(256), 0, s, k);   \
       else hipLaunchKernelGGL((field_query_kernel<TEX, false, true>), grid, dim3(256), 0, s, k);      \
+    } else if (a->mlp_precision == 1) {                                                               \
+      if (att) hipLaunchKernelGGL((field_query_kernel<TEX, true, false, 1>), grid, dim3(256), 0, s, k);  \
+      else hipLaunchKernelGGL((field_query_kernel<TEX, false, false, 1>), grid, dim3(256), 0, s, k);     \
     } else {                                                                                          \
       if (att) hipLaunchKernelGGL((field_query_kernel<TEX, true>), grid, dim3(256), 0, s, k);         \
       else hipLaunchKernelGGL((field_query_kernel<TEX, false>), grid, dim3(256), 0, s, k);            \

@@ -110,7 +110,9 @@ def make_sampler(planes, decoder, scene_range, n_attention, attention_values, us
                        planes=planes, decoder_params=(w1, b1, w2, b2) + ((ray_feature, w3, b3) if viewdir is not None else ()))
     fused.ray_features = ray_pad
 
-    def sampler(x_in, request_sampler_outputs=['sigma', 'rgb']):
+    def sampler(x_in, request_sampler_outputs=['sigma', 'rgb'], mlp_split_fp16=False):
+        # mlp_split_fp16 (not in the reference's signature; render() sets it): the decoder arithmetic of the fused
+        # renderer instead of exact fp32 - the same in both of render()'s paths, and what the backward recomputes
         for output in request_sampler_outputs:
             assert output in _SAMPLER_OUTPUTS
         want_normals = 'normals' in request_sampler_outputs
@@ -131,7 +133,8 @@ def make_sampler(planes, decoder, scene_range, n_attention, attention_values, us
 
         def fwd(p, pl, a_w1, a_b1, a_w2, a_b2, att, be, al, *vd_unused):
             q = ops.field_query(p, texels, image, scene_range, n_attention, att, use_sdf, be, al,
-                                want_sdf=want_sdf, want_semantics=want_sem, ray_features=ray_pad, samples_per_ray=spr)
+                                want_sdf=want_sdf, want_semantics=want_sem, ray_features=ray_pad, samples_per_ray=spr,
+                                mlp_precision=1 if (mlp_split_fp16 and ray_pad is None) else 0)
             return tuple(q[k] for k in ('sigma', 'rgb') + (('sdf',) if want_sdf else ()) +
                          (('semantics',) if want_sem else ()))
         bwd = None

@@ -209,8 +209,9 @@ def points_on_rays(ray_origins, ray_directions, depth):
 # --------------------------------------------------------------------------- #
 def field_query(points, texels, decoder_image, scene_range, n_attention, attention_values=None, use_sdf=True,
                 beta=None, alpha=None, want_sdf=False, want_semantics=False, want_outside=False,
-                ray_features=None, samples_per_ray=0):
+                ray_features=None, samples_per_ray=0, mlp_precision=0):
     """points [B,P,3] -> dict(sigma [B,P], rgb [B,P,3], sdf?, semantics?, outside?).
+    mlp_precision: 0 exact fp32 MFMA, 1 split-fp16 operands (the fused renderer's arithmetic; not with ray_features).
     ray_features: padded [B, P/samples_per_ray, 48] (pad_ray_features) with a decoder_pack_viewdir image."""
     points = _f32c(points, 'points')
     B, P = points.shape[0], points.shape[1]
@@ -239,7 +240,8 @@ def field_query(points, texels, decoder_image, scene_range, n_attention, attenti
                          use_sdf=int(use_sdf), beta=_f32c(beta, 'beta') if use_sdf else None,
                          alpha=_f32c(alpha, 'alpha') if use_sdf else None, scene_range=float(scene_range),
                          sigma=out['sigma'], rgb=out['rgb'], sdf=out.get('sdf'), semantics=out.get('semantics'),
-                         outside=out.get('outside'), ray_features=ray_features, samples_per_ray=int(samples_per_ray))
+                         outside=out.get('outside'), ray_features=ray_features, samples_per_ray=int(samples_per_ray),
+                         mlp_precision=int(mlp_precision))
     return out
 
 

@@ -131,7 +131,9 @@ def _render(cfg, dcfg, target_model, height, width, tform_cam2world, focal_lengt
         sem = o['semantics'].view(*shp, -1) if compute_semantics else None
         coo = o['coords'].view(*shp, -1) if compute_coords else None
         return sig, col, nor, sem, coo
-    sigma, rgb, normals, semantics, coords = unpack(sampler(query_points, req))
+    # our own closure (it carries .fused): the fused renderer's split-fp16 decoder arithmetic in this path too
+    hip_kw = {'mlp_split_fp16': True} if hasattr(sampler, 'fused') else {}
+    sigma, rgb, normals, semantics, coords = unpack(sampler(query_points, req, **hip_kw))
 
     extra = coords if coords is not None else semantics      # run.py:337-338: coords hijack the semantics slot
     if cfg.fine_sampling:
@@ -145,7 +147,7 @@ def _render(cfg, dcfg, target_model, height, width, tform_cam2world, focal_lengt
         query_fine = nerf_utils.points_on_rays(ray_origins, ray_directions, z_samples)
         if force_no_cam_grad:
             query_fine = query_fine.detach()
-        sigma_f, rgb_f, normals_f, semantics_f, coords_f = unpack(sampler(query_fine, req))
+        sigma_f, rgb_f, normals_f, semantics_f, coords_f = unpack(sampler(query_fine, req, **hip_kw))
         extra_f = coords_f if coords_f is not None else semantics_f
         rgb_map, depth_map, mask, normal_map, extra_map = nerf_utils.merge_and_composite(
             ray_directions, depth_values, sigma, rgb, z_samples, sigma_f, rgb_f, normals, normals_f, extra, extra_f,

@@ -52,7 +52,7 @@ def pose_matrix(cam0, delta):
     return M
 
 
-def run(dev, res=32, samples=32, batch=2, steps=10, plane_res=48, seed=0, verbose=False, teacher=False):
+def run(dev, res=32, samples=32, batch=2, steps=10, plane_res=48, seed=0, verbose=False, teacher=False, hip_only=False):
     from stand_in import StandInGenerator, look_at_cameras
     import nerf_from_image_amd.generator as nfi_gen
     import nerf_from_image_amd.render as nfi_render
@@ -148,6 +148,9 @@ def run(dev, res=32, samples=32, batch=2, steps=10, plane_res=48, seed=0, verbos
 
     shadow_hist = []
     h_hip, t_hip = optimise('hip')
+    if hip_only:                                             # profiling: the HIP loop alone
+        print('render fwd+bwd per step (median): HIP %.2f ms' % (t_hip * 1e3))
+        return h_hip, None, t_hip, None
     h_ref, t_ref = optimise('oracle', shadow='hip' if teacher else None)
     if teacher:
         # conditioning of the problem itself: the oracle's gradient at the start point in float64 against float32
@@ -194,5 +197,6 @@ if __name__ == '__main__':
     ap.add_argument('--batch', type=int, default=4)
     ap.add_argument('--steps', type=int, default=30)
     ap.add_argument('--plane-res', type=int, default=256)
+    ap.add_argument('--hip-only', action='store_true')
     a = ap.parse_args()
-    run(torch.device('cuda:0'), a.res, a.samples, a.batch, a.steps, a.plane_res, verbose=True)
+    run(torch.device('cuda:0'), a.res, a.samples, a.batch, a.steps, a.plane_res, verbose=True, hip_only=a.hip_only)
