@@ -63,7 +63,7 @@ if __name__ == '__main__':
     main()
 
 
-def phase_profile():
+def phase_profile(radius=1.3):
     """Per-phase shader-cycle breakdown of the render kernel (profiling instantiation)."""
     dev = torch.device('cuda:0')
     g = torch.Generator().manual_seed(1234)
@@ -73,7 +73,7 @@ def phase_profile():
     w2 = torch.randn(1 + A, 64, generator=g).to(dev); b2 = torch.zeros(1 + A, device=dev)
     att = (torch.rand(B, A, 3, generator=g) * 2 - 1).to(dev)
     beta = torch.tensor([0.1], device=dev); alpha = torch.tensor([0.05], device=dev)
-    cam = cameras(B, 1.3, g).to(dev); focal = torch.full((B,), 1.0254, device=dev)
+    cam = cameras(B, radius, g).to(dev); focal = torch.full((B,), 1.0254, device=dev)
     noise_c = torch.rand(B, R, R, S, device=dev); noise_f = torch.rand(B * R * R, S, device=dev)
     image = ops.decoder_pack(w1, b1, w2, b2, A); texels = ops.planes_to_texels(planes)
     prof = torch.zeros(12, dtype=torch.int64, device=dev)
@@ -86,14 +86,16 @@ def phase_profile():
     names = ['tile issue', 'tile wait+interp', 'tile transpose+mlp+epilogue', 'tiles', 'ray set-up', 'coarse field',
              'resample', 'fine field', 'merge', 'composite+store', 'rays', 'wave lifetime']
     rays, tiles = max(p[10], 1), max(p[3], 1)
-    print('phase profile (B=8, all rays hit): cycles per ray per wave')
+    print('phase profile (B=8, camera radius %.1f, %d of %d rays marched): cycles per marched ray per wave' % (radius, rays, B * R * R))
     for i in (4, 5, 6, 7, 8, 9):
         print('   %-30s %9.0f' % (names[i], p[i] / rays))
-    print('   %-30s %9.0f  (sum of wave lifetimes / rays)' % ('total', p[11] / rays))
+    print('   %-30s %9.0f  (sum of wave lifetimes / rays marched; phases above sum to %.0f)' % (
+        'total', p[11] / rays, sum(p[i] for i in (4, 5, 6, 7, 8, 9)) / rays))
     for i in (0, 1, 2):
         print('   per tile: %-20s %9.0f' % (names[i], p[i] / tiles))
     print('   tiles/ray %.2f' % (tiles / rays))
 
 
 if __name__ == '__main__' and os.environ.get('NFI_PHASES'):
-    phase_profile()
+    for radius in (1.3, 2.0):
+        phase_profile(radius)
