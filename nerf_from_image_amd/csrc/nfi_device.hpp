@@ -543,17 +543,6 @@ __device__ __forceinline__ void pow2_normaliser(float amax, float& s, float& inv
   inv = bits2f((int)(e << 23));
 }
 
-typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ void split_f16x4(const f32x4& x, f16x4& hi, f16x4& lo) {
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    auto h = __builtin_amdgcn_cvt_pkrtz(x[2 * i], x[2 * i + 1]);
-    auto l = __builtin_amdgcn_cvt_pkrtz(x[2 * i] - (float)h[0], x[2 * i + 1] - (float)h[1]);
-    hi[2 * i] = h[0]; hi[2 * i + 1] = h[1];
-    lo[2 * i] = l[0]; lo[2 * i + 1] = l[1];
-  }
-}
-
 // PREC 0: exact fp32 MFMA (v_mfma_f32_16x16x4_f32, 48 per tile).
 // PREC 1: split fp16 (v_mfma_f32_16x16x32_f16, 18 per tile): every operand is hi + lo in fp16 and the
 //         products hi*hi + hi*lo + lo*hi are accumulated in fp32 - 2^-21 relative per product instead of

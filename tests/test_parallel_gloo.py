@@ -159,3 +159,16 @@ def test_gradient_buckets_single_process():
     assert gb.finish() == 0 and torch.equal(w.grad, torch.ones(4, 3))
     gb.zero_grad()
     assert torch.equal(w.grad, torch.zeros(4, 3)) and w.grad.data_ptr() == gb._ptr[id(w)]
+
+
+def test_stand_in_basis_mix_matches_einsum():
+    """tools/basis_mix.py (the stand-in plane producers' only heavy op): values and both gradients against einsum."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tools'))
+    from basis_mix import basis_mix
+    torch.manual_seed(3)
+    c = torch.randn(3, 4, dtype=torch.float64, requires_grad=True)
+    b = torch.randn(4, 5, 6, 7, dtype=torch.float64, requires_grad=True)
+    assert torch.allclose(basis_mix(c, b), torch.einsum('bk,kchw->bchw', c, b))
+    assert torch.autograd.gradcheck(basis_mix, (c, b))
