@@ -417,9 +417,10 @@ typedef struct nfi_render_args {
   /* tuning knob, 0 = default.  bit 2: hand rays out in scanline order instead of 8x8 pixel tiles
    * (results identical).  bit 3: evaluate the decoder MLP with exact-fp32 MFMA instead of the
    * split-fp16 (hi+lo, 22 significand bits) MFMA; both meet the 1e-4 parity budget.  bit 4: ONE device-wide work
-   * counter instead of the per-XCD queues over 16x16-pixel blocks (results identical; the per-XCD queues need image
-   * sides that are multiples of 16 and fall back to the single counter otherwise).  bits 5-8: measurement knobs of
-   * those queues (5-6: block side 1 -> 8, 2 -> 32 pixels; 7 / 8: 4 / 2 positions per atomic), results identical. */
+   * counter instead of the per-XCD queues over square pixel blocks (results identical; the per-XCD queues take the
+   * largest of 32 / 16 / 8 pixels that divides both image sides, two positions per atomic, and fall back to the single
+   * counter when not even 8 does).  bits 5-8: measurement knobs of those queues (5-6: block side 1 -> 8, 2 -> 32,
+   * 3 -> 16 pixels; bit 7: 4, bit 8: 1 position per atomic), results identical. */
   int tuning;
   /* optional uint64[12] device array: per-phase shader-cycle sums over all waves (profiling build of
    * the kernel; NULL = off): field tile {issue, wait+interp, mlp, count}, ray set-up, coarse field,

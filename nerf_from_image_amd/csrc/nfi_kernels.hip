@@ -1784,15 +1784,20 @@ extern "C" int nfi_render_fwd(const nfi_render_args* a, nfi_stream_t stream) {
 
   k.counter = reduce + 3;
   k.width = a->width;
-  // per-XCD queues (tuning bit 4): 16x16-pixel blocks, needs image sides that are multiples of 16
+  // per-XCD queues (tuning bit 4 switches them off): square pixel blocks, needs image sides that are multiples of 8
   {
-    // defaults: 16x16-pixel blocks, one position per atomic (MI355X, 8 x 128^2 x (64+64): 1.00 ms chairs-like /
-    // 1.36 ms every-ray-hits; 8x8 blocks 0.94-1.01 / 1.39-1.49; 4 positions per atomic 1.06-1.10 / 1.44-1.51; one
-    // device-wide counter 1.82 / 2.10).  Experiment knobs: bits 5-6 = 1 -> 8x8, 2 -> 32x32 blocks; bit 7 -> 4,
-    // bit 8 -> 2 positions per atomic.
-    k.fetch_batch = ((a->tuning >> 7) & 1) ? 4 : (((a->tuning >> 8) & 1) ? 2 : 1);
+    // defaults: the largest of 32 / 16 / 8-pixel blocks that divides both image sides, TWO positions per atomic.
+    // MI355X, 8 x 128^2 x (64+64), ms per launch chairs-like / every ray hits / one image (tools/quick_bench.py with
+    // NFI_TUNING, warm clocks): 32x32 + 2: 0.854 / 1.299 / 0.164; 8x8 + 2: 0.848 / 1.328 / 0.167; 16x16 + 2:
+    // 0.891 / 1.301 / 0.170; 16x16 + 1 (the round-1 default): 0.933 / 1.311 / 0.185; 32x32 + 1: 0.882 / 1.317 / 0.174;
+    // 4 per atomic: 0.88-0.90 / 1.33-1.38; one device-wide counter 1.82 / 2.10.  Halving the atomics matters on every
+    // workload (the wave waits for each one's result); the block side mostly through the balance of the chairs-like
+    // images, whose rays that cross the cube are clustered.  Experiment knobs: bits 5-6 = 1 -> 8x8, 2 -> 32x32,
+    // 3 -> 16x16 blocks; bit 7 -> 4, bit 8 -> 1 position per atomic.
+    k.fetch_batch = ((a->tuning >> 7) & 1) ? 4 : (((a->tuning >> 8) & 1) ? 1 : 2);
     const int sel = (a->tuning >> 5) & 3;
-    k.xcd_block_shift = sel == 1 ? 3 : (sel == 2 ? 5 : 4);
+    const int both = a->width | a->height;
+    k.xcd_block_shift = sel == 1 ? 3 : (sel == 2 ? 5 : (sel == 3 ? 4 : ((both & 31) == 0 ? 5 : ((both & 15) == 0 ? 4 : 3))));
     const int side = 1 << k.xcd_block_shift;
     k.xcd_blocks = (((a->tuning >> 4) & 1) == 0 && (a->width % side == 0) && (a->height % side == 0)) ? 1 : 0;
     // (A scene-per-XCD hand-out - queue q holding the blocks of scenes q, q+8, ... so that every XCD's L2 holds one

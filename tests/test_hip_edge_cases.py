@@ -116,7 +116,7 @@ def test_work_queues_cover_every_ray_exactly_once(gpu_device, H, W, S, B):
     noise_c = torch.rand(B, H, W, S, generator=g).to(dev)
     noise_f = torch.rand(B * H * W, S, generator=g).to(dev)
     outs = []
-    for tuning in (0, 16, 32, 64 + 128):
+    for tuning in (0, 16, 32, 64 + 128, 96 + 256):
         r = ops.render_fwd(cam, focal, H, W, S, texels, image, 0.55, 10, d['att'].to(dev), True, d['beta'].to(dev),
                            d['alpha'].to(dev), noise_coarse=noise_c, noise_fine=noise_f, tuning=tuning)
         # poison check: outputs are torch.empty - a ray nobody marched would leave garbage / NaN behind

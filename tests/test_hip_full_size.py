@@ -223,7 +223,7 @@ def test_mlp_precision_modes(gpu_device):
         return ops.render_fwd(d['cam'], d['focal'], R, R, S, texels, image, 0.55, A, d['att'], True, d['beta'], d['alpha'],
                               noise_coarse=d['noise_c'], noise_fine=d['noise_f'], tuning=tuning)
     split, strict, scan, xcd = run(0), run(8), run(4 + 16), run(16)
-    for tuning in (32, 64, 128, 256 + 32):        # block sizes / fetch batches of the per-XCD queues
+    for tuning in (32, 64, 96, 128, 256 + 32, 256 + 96):   # block sizes / fetch batches of the per-XCD queues
         v = run(tuning)
         for k in ('rgb', 'depth', 'mask'):
             assert torch.equal(v[k], split[k]), (tuning, k)

@@ -34,7 +34,8 @@ def main():
         image = ops.decoder_pack(w1, b1, w2, b2, A)
         texels = ops.planes_to_texels(planes)
         ws = None
-        for skip, tuning in ((True, 0), (True, 8), (True, 16)):      # default / fp32 MLP / single work counter
+        knobs = [int(v) for v in os.environ['NFI_TUNING'].split(',')] if os.environ.get('NFI_TUNING') else (0, 8, 16)
+        for skip, tuning in [(True, t) for t in knobs]:      # default / fp32 MLP / single work counter (NFI_TUNING=a,b,.. overrides)
             def step():
                 return ops.render_fwd(cam, focal, R, R, S, texels, image, 0.55, A, att, True, beta, alpha,
                                       noise_coarse=noise_c, noise_fine=noise_f, skip_missed_rays=skip, workspace=ws,
@@ -43,7 +44,7 @@ def main():
                 out = step(); ws = out['_workspace']
             torch.cuda.synchronize()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            K = 20
+            K = int(os.environ.get("NFI_ITERS", 20))
             e0.record()
             for _ in range(K):
                 out = step()
