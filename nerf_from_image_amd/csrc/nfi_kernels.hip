@@ -1188,7 +1188,7 @@ struct RenderKernelParams {
   uint32_t* counter;   // work counter (zeroed with reduce[])
   int width;           // image width (tile order of the work queue)
   int tile_order;      // 1: hand rays out in 8x8 pixel tiles instead of scanlines
-  int xcd_blocks;      // 1: every XCD marches its own 16x16-pixel blocks (own queue, steals when it runs dry)
+  int xcd_blocks;      // 1: every XCD marches its own square pixel blocks (own queue, steals when it runs dry)
   uint32_t* xcd_counter;   // 8 counters, 64 bytes apart
   int xcd_block_shift;     // log2 of the block side: 3, 4 or 5
   int fetch_batch;         // positions taken per atomic
