@@ -340,8 +340,9 @@ typedef struct nfi_field_bwd_args {
   float* g_ray_features; float* g_w3; float* g_b3;
   /* plane-gradient scatter.  0: fp32 atomics straight from the backward kernel (384 atomic dwords per point).
    * 1: binned - the kernel writes the per-point feature gradient (128 B) to the workspace, the points are counting-
-   * sorted by texel cell per plane, and one half-wave per cell sums its points in registers before ONE set of
-   * atomics per cell; needs nfi_field_bwd_workspace_bytes(a) of workspace.  Same result up to fp32 summation order. */
+   * sorted by texel cell per plane (by 16x16-texel tile through global memory, by cell inside LDS), and the sorted
+   * entries are reduced in registers with one set of line-coalesced atomics per run of a cell; needs
+   * nfi_field_bwd_workspace_bytes(a) of workspace (177 B per point).  Same result up to fp32 summation order. */
   int scatter_mode;
   int texel_layout;              /* of texels AND g_texels */
 } nfi_field_bwd_args;
