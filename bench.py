@@ -285,7 +285,7 @@ def roofline(kernel_ms, marched, n_images):
          'unit': 'Gcycle/s', 'source': src, 'levels': levels}
     if prof is None:
         r.update(achieved=None, peak=None, frac=None, traffic=None,
-                 note='no PMC profile with issue_cycles_per_marched_ray under profiles/: run tools/gpu_pmc_render.sh')
+                 note='no PMC profile with issue_cycles_per_marched_ray under profiles/: run tools/gpu_session.sh <tag> pmc (tools/pmc_collect.py)')
         return r
     clk = prof['shader_clock_hz']
     ach = prof['issue_cycles_per_marched_ray'] * marched / t

@@ -84,3 +84,22 @@ def test_product_path_has_no_cpu_fallback():
     for fn in os.listdir(pkg):
         if fn.endswith('.py'):
             assert 'oracle' not in open(os.path.join(pkg, fn)).read().replace('no oracle', ''), fn
+
+
+def test_bench_roofline_is_reproducible_from_the_committed_profile():
+    """bench.py's roofline object (no GPU needed for the arithmetic): issue cycles per marched ray and the shader clock
+    come from the committed rocprofv3 PMC profile it names, kernel time and ray count are the live inputs; the
+    fraction is a fraction (round 1 printed 1.97 against HBM), the byte-side levels each have their own peak."""
+    import json
+    import bench
+    prof = json.load(open(os.path.join(ROOT, 'profiles', 'r2', 'pmc_render_fwd.json')))
+    kernel_ms, marched = prof['kernel_ns_in_clock_pass'] * 1e-6, prof['rays_marched_per_launch']
+    r = bench.roofline(kernel_ms, marched, 8)
+    assert r['source'] == 'profiles/r2/pmc_render_fwd.json' and r['bound'] == 'valu-issue'
+    assert abs(r['frac'] - r['achieved'] / r['peak']) < 1e-12 and 0.3 < r['frac'] <= 1.0
+    # at the profile's own kernel time the fraction is the profile's issue fraction
+    assert abs(r['frac'] - prof['issue_frac']) < 0.01 * prof['issue_frac']
+    assert r['traffic'] == prof['fabric_bytes_per_launch']
+    for level in ('hbm_compulsory', 'l2_requests', 'fabric'):
+        assert 0.0 < r['levels'][level]['frac'] < 1.0, level
+    assert r['levels']['gather_stream_algorithmic']['x_hbm_peak'] > 1.0      # cache-served: why HBM is not the bound
