@@ -4,7 +4,7 @@ same random draws in the same order (torch.rand / torch.randn of [bs] tensors on
 The image part - F.affine_grid + F.grid_sample over [bs,C,H,W], 15 augmented copies of cat(prediction, target) per
 inversion step (run.py:2216-2231) - is ONE HIP launch forward and one backward (nfi_affine_warp_fwd/bwd build the
 2x3 matrix from the draws themselves).  The pose part is 4x4 matrix algebra on [bs] poses and stays tensor
-expressions (lib/pose_utils.invert_space restated below).
+expressions.
 
     import nerf_from_image_amd.augment as nfi_aug
     nfi_aug.configure(args, dataset_config)        # reads dataset_config['white_background'], args.supervise_alpha
@@ -26,12 +26,16 @@ def configure(new_args, new_dataset_config):
 
 
 def invert_space(mat):
-    """lib/pose_utils.py:20-27: cam2world <-> world2cam for [B,4,4] matrices with a scale in [3,3]."""
-    out_mat = torch.zeros_like(mat)
-    out_mat[:, :3, :3] = mat[:, :3, :3].transpose(-2, -1) / mat[:, 3:4, 3:4]
-    out_mat[:, 3, 3] = 1
-    out_mat[:, :3, 3] = -torch.sum(mat[:, :3, :3] / mat[:, 3:4, 3:4] * mat[:, :3, None, 3], dim=-2)
-    return out_mat
+    """cam2world <-> world2cam for [B,4,4] similarity matrices [[R, t], [0, s]] (what lib/pose_utils.py:20-27 computes):
+    the inverse is [[(R/s)^T, -(R/s)^T t], [0, 1]].  Same elementwise operations as the reference (division by s,
+    product with t, sum over the row index), so the result is bit-identical."""
+    s = mat[:, 3:4, 3:4]
+    rot_over_s = mat[:, :3, :3] / s
+    shift = -(rot_over_s * mat[:, :3, 3].unsqueeze(-1)).sum(dim=1)
+    top = torch.cat([rot_over_s.transpose(1, 2), shift.unsqueeze(-1)], dim=2)
+    bottom = torch.zeros_like(mat[:, 3:4, :])
+    bottom[:, 0, 3] = 1
+    return torch.cat([top, bottom], dim=1)
 
 
 def warp_images(img, rot, scale, translation, white_background):
@@ -78,26 +82,33 @@ def augment_pose(pose, focal, rot, scale, translation):
     return out, focal
 
 
+def draw_transform(bs, device, p, disable_scale):
+    """The random in-plane rotation / zoom / shift of one augmentation (run.py:724-741), each applied with probability
+    p.  The DRAW ORDER is the reference's - rand (angle), rand (coin), [randn (zoom), rand (coin)], randn (shift),
+    rand (coin) - so a seeded run consumes the generator exactly like run.py; a coin that comes up tails selects the
+    identity value (torch.where gives the same bits as the reference's lerp with weights 0 / 1)."""
+    def coin(*shape):
+        return torch.rand(shape, device=device) < p
+
+    angle = (torch.rand((bs,), device=device) - 0.5) * 2 * np.pi
+    angle = angle * coin(bs).float()
+    zoom = torch.ones((bs,), device=device)
+    if not disable_scale:
+        drawn = torch.exp2(torch.randn((bs,), device=device) * 0.2)
+        zoom = torch.where(coin(bs), drawn, zoom)
+    drawn = torch.randn((bs, 2), device=device) * 0.1
+    shift = torch.where(coin(bs, 1), drawn, torch.zeros_like(drawn))
+    return angle, zoom, shift
+
+
 def augment_impl(img, pose, focal, p, disable_scale=False, cached_tform=None):
     if dataset_config is None:
         raise RuntimeError('nerf_from_image_amd.augment.configure(args, dataset_config) has not been called')
     bs = img.shape[0] if img is not None else pose.shape[0]
     device = img.device if img is not None else pose.device
 
-    if cached_tform is None:
-        rot = (torch.rand((bs,), device=device) - 0.5) * 2 * np.pi
-        rot = rot * (torch.rand((bs,), device=device) < p).float()
-        if disable_scale:
-            scale = torch.ones((bs,), device=device)
-        else:
-            scale = torch.exp2(torch.randn((bs,), device=device) * 0.2)
-            scale = torch.lerp(torch.ones_like(scale), scale, (torch.rand((bs,), device=device) < p).float())
-        translation = torch.randn((bs, 2), device=device) * 0.1
-        translation = torch.lerp(torch.zeros_like(translation), translation,
-                                 (torch.rand((bs, 1), device=device) < p).float())
-        cached_tform = rot, scale, translation
-    else:
-        rot, scale, translation = cached_tform
+    rot, scale, translation = draw_transform(bs, device, p, disable_scale) if cached_tform is None else cached_tform
+    cached_tform = rot, scale, translation
 
     if img is not None:
         white = bool(dataset_config['white_background'])
@@ -114,10 +125,11 @@ def augment_impl(img, pose, focal, p, disable_scale=False, cached_tform=None):
 
 
 def augment(img, pose, focal, p, disable_scale=False, cached_tform=None, return_tform=False):
-    if p == 0 and cached_tform is None:
+    """run.py:798-815: identity when nothing is to be drawn or replayed; otherwise augment_impl, with the drawn
+    transform appended on request."""
+    if cached_tform is None and p == 0:
         return img, pose, focal
-    assert img is None or pose is None or img.shape[0] == pose.shape[0]
-    img_new, pose_new, focal_new, tform = augment_impl(img, pose, focal, p, disable_scale, cached_tform)
-    if return_tform:
-        return img_new, pose_new, focal_new, tform
-    return img_new, pose_new, focal_new
+    if img is not None and pose is not None:
+        assert img.shape[0] == pose.shape[0]
+    result = augment_impl(img, pose, focal, p, disable_scale, cached_tform)
+    return result if return_tform else result[:3]

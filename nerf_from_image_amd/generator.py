@@ -178,13 +178,18 @@ def make_sampler(planes, decoder, scene_range, n_attention, attention_values, us
 
 
 def sample_volume_stratified(batch_size, nstrata, scene_range, device=None):
-    """lib/ops.sample_volume_stratified (20-26): one jittered point per cell of an (nstrata-1)^3 grid over the cube;
-    same draw (torch.rand_like of the [B,n,n,n,3] cell indices) as the reference."""
-    bins = torch.arange(nstrata - 1, device=device)
-    bins = torch.stack(torch.meshgrid(bins, bins, bins, indexing='xy'), dim=-1).float().unsqueeze(0).expand(
-        batch_size, -1, -1, -1, -1)
-    bins = (bins + torch.rand_like(bins)) / (nstrata - 1) * 2 - 1
-    return bins.flatten(1, 3) * scene_range
+    """One jittered point per cell of an n^3 grid (n = nstrata - 1) over the scene cube, as lib/ops.py:20-26 draws them:
+    cell (i, j, k) of the [n,n,n] index grid holds (x, y, z) = (j, i, k) (the reference's 'xy' meshgrid), the jitter is
+    ONE uniform draw of shape [B,n,n,n,3] (what its rand_like of the expanded index grid consumes), and the point is
+    ((cell + jitter) / n * 2 - 1) * scene_range."""
+    n = nstrata - 1
+    idx = torch.arange(n, device=device).float()
+    cell = torch.empty((n, n, n, 3), dtype=torch.float32, device=device)
+    cell[..., 0] = idx.view(1, n, 1)
+    cell[..., 1] = idx.view(n, 1, 1)
+    cell[..., 2] = idx.view(1, 1, n)
+    jitter = torch.rand((batch_size, n, n, n, 3), dtype=torch.float32, device=device)
+    return ((cell + jitter) / n * 2 - 1).reshape(batch_size, n ** 3, 3) * scene_range
 
 
 def sdf_and_gradient(points, planes, decoder, scene_range):

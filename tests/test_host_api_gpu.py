@@ -410,24 +410,25 @@ def test_regulariser_outputs(gpu_device):
     z = torch.randn(2, 512, generator=g).to(gpu_device)
     names = ['sdf_eikonal_loss', 'sdf_distance_loss', 'total_variation_loss', 'entropy_loss']
     draws = {}
-    real_rand_like, real_randn_like = torch.rand_like, torch.randn_like
+    real_rand, real_randn_like = torch.rand, torch.randn_like
 
-    def rand_like(t, **k):
+    def rand(*a, **k):
+        # the stratified jitter is the one uniform draw of the branch (generator.sample_volume_stratified).
         # plane_res 32 and 31 strata: the texel coordinate of a point is (cell index + jitter), so keeping the jitter
         # off 0 and 1 keeps every point off the texel boundaries, where d sdf/dx jumps and an fp32 kernel and a
         # float64 oracle may legitimately pick different cells
-        draws['jitter'] = real_rand_like(t, **k).clamp_(1e-3, 1 - 1e-3)
+        draws['jitter'] = real_rand(*a, **k).clamp_(1e-3, 1 - 1e-3)
         return draws['jitter']
 
     def randn_like(t, **k):
         draws['perturb'] = real_randn_like(t, **k)
         return draws['perturb']
-    torch.rand_like, torch.randn_like = rand_like, randn_like
+    torch.rand, torch.randn_like = rand, randn_like
     try:
         out = model(None, z, names)
     finally:
-        torch.rand_like, torch.randn_like = real_rand_like, real_randn_like
-    assert set(out) == set(names)
+        torch.rand, torch.randn_like = real_rand, real_randn_like
+    assert set(out) == set(names) and tuple(draws['jitter'].shape) == (2, 31, 31, 31, 3)
     dec = model.decoder.net
     params = [model.synthesis_network.basis, model.synthesis_network.proj.weight, dec[0].weight, dec[0].bias,
               dec[2].weight, dec[2].bias, model.beta]
@@ -460,20 +461,20 @@ def test_regulariser_outputs_with_view_direction_decoder(gpu_device):
     z = torch.randn(2, 512, generator=g).to(gpu_device)
     names = ['sdf_eikonal_loss', 'sdf_distance_loss', 'total_variation_loss', 'entropy_loss']
     draws = {}
-    real_rand_like, real_randn_like = torch.rand_like, torch.randn_like
+    real_rand, real_randn_like = torch.rand, torch.randn_like
 
-    def rand_like(t, **k):
-        draws['jitter'] = real_rand_like(t, **k).clamp_(1e-3, 1 - 1e-3)
+    def rand(*a, **k):
+        draws['jitter'] = real_rand(*a, **k).clamp_(1e-3, 1 - 1e-3)
         return draws['jitter']
 
     def randn_like(t, **k):
         draws['perturb'] = real_randn_like(t, **k)
         return draws['perturb']
-    torch.rand_like, torch.randn_like = rand_like, randn_like
+    torch.rand, torch.randn_like = rand, randn_like
     try:
         out = model(None, z, names)
     finally:
-        torch.rand_like, torch.randn_like = real_rand_like, real_randn_like
+        torch.rand, torch.randn_like = real_rand, real_randn_like
     assert set(out) == set(names)
     dec = model.decoder.net
     assert dec[2].weight.shape == (33, 64)

@@ -3,6 +3,9 @@ import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch
+from nerf_from_image_amd import _lib
+if os.environ.get('NFI_PROBE_LIBRARY'):          # variant builds of tools/probes/bwd_variants.py
+    _lib.LIBRARY = os.environ['NFI_PROBE_LIBRARY']
 from nerf_from_image_amd import ops
 from nerf_from_image_amd.field_backward import field_query_bwd
 

@@ -1,0 +1,224 @@
+"""Variant builds of the field backward kernel for the packed-fp32 wrong-product hunt (DESIGN.md "Determinism").
+
+    python tools/probes/bwd_variants.py build        # here (no GPU): build/variants/libnfi_<name>.so
+    python tools/probes/bwd_variants.py run [N]      # on the GPU box: N launches per variant, events in g_points
+
+Every variant is the product source with ONE change to how the coordinate-gradient block of field_query_bwd_kernel
+(nfi_backward_field.inc, "coordinate gradients in the load layout") is compiled:
+
+    product      nerf_from_image_amd/libnfi_hip.so as built by __graft_entry__ (SLP on + tools/gfx950_pk_legalize.py)
+    noslp        the round-2 product build (-fno-slp-vectorize)
+    slp          SLP vectoriser on: the arithmetic becomes v_pk_add/mul_f32 with op_sel (the failing build of round 2)
+    slp_nop_dpp  slp + s_nop 7 between the DPP quad reductions and the corner differences
+    slp_nop_mul  slp + s_nop 7 between the corner differences and the products
+    slp_scalar   slp, but the four products and two sums of g_fa / g_fb forced to scalar v_mul_f32 / v_add_f32
+    slp_bperm    slp, the quad reduction through ds_swizzle instead of DPP
+    slp_waitcnt  slp + s_waitcnt vmcnt(0) lgkmcnt(0) in front of the corner differences
+    slp_nop_only / slp_nop1 / slp_nop2   slp + s_nop 7 x2 / s_nop 0 / s_nop 1 between the differences and the products,
+                 the packed code itself unchanged (slp_nop_mul also hides the differences from the vectoriser)
+"""
+import os
+import shutil
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+CSRC = os.path.join(ROOT, 'nerf_from_image_amd', 'csrc')
+OUT = os.path.join(ROOT, 'build', 'variants')
+FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-ffp-contract=off', '-fPIC']
+
+G_FA = '            const float g_fa = gb * (dcorner[1] - dcorner[0]) + fb * (dcorner[3] - dcorner[2]);\n'
+G_FB = '            const float g_fb = ga * (dcorner[2] - dcorner[0]) + fa * (dcorner[3] - dcorner[1]);\n'
+NOP = ('            __builtin_amdgcn_sched_barrier(0); asm volatile("s_nop 7\\n\\ts_nop 7"); '
+       '__builtin_amdgcn_sched_barrier(0);\n')
+QUAD1 = '              acc += dpp_f32<kDppQuadXor1>(0.0f, acc);\n'
+QUAD2 = '              acc += dpp_f32<kDppQuadXor2>(0.0f, acc);\n'
+
+
+def patch(src, name):
+    assert G_FA in src and G_FB in src and QUAD1 in src and QUAD2 in src, 'coordinate-gradient block not found'
+    if name in ('noslp', 'slp'):
+        return src
+    if name == 'slp_nop_dpp':
+        return src.replace(G_FA, NOP + G_FA)
+    if name == 'slp_waitcnt':
+        w = ('            __builtin_amdgcn_sched_barrier(0); asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); '
+             '__builtin_amdgcn_sched_barrier(0);\n')
+        return src.replace(G_FA, w + G_FA)
+    if name == 'slp_nop_mul':
+        new = ('            float d10 = dcorner[1] - dcorner[0], d32 = dcorner[3] - dcorner[2], d20 = dcorner[2] - dcorner[0], '
+               'd31 = dcorner[3] - dcorner[1];\n'
+               '            asm volatile("" : "+v"(d10), "+v"(d32), "+v"(d20), "+v"(d31));\n' + NOP +
+               '            const float g_fa = gb * d10 + fb * d32;\n'
+               '            const float g_fb = ga * d20 + fa * d31;\n')
+        return src.replace(G_FA + G_FB, new)
+    if name in ('slp_nop_only', 'slp_nop1', 'slp_nop2'):
+        # the same packed code as `slp` (nothing hidden from the vectoriser), only wait states between the differences
+        # and the products
+        nop = {'slp_nop_only': NOP, 'slp_nop1': NOP.replace('s_nop 7\\n\\ts_nop 7', 's_nop 0'),
+               'slp_nop2': NOP.replace('s_nop 7\\n\\ts_nop 7', 's_nop 1')}[name]
+        new = ('            const float d10 = dcorner[1] - dcorner[0], d32 = dcorner[3] - dcorner[2], d20 = dcorner[2] - dcorner[0], '
+               'd31 = dcorner[3] - dcorner[1];\n' + nop +
+               '            const float g_fa = gb * d10 + fb * d32;\n'
+               '            const float g_fb = ga * d20 + fa * d31;\n')
+        return src.replace(G_FA + G_FB, new)
+    if name == 'slp_scalar':
+        new = ('            float g_fa, g_fb;\n'
+               '            {\n'
+               '              const float d10 = dcorner[1] - dcorner[0], d32 = dcorner[3] - dcorner[2], d20 = dcorner[2] - dcorner[0], '
+               'd31 = dcorner[3] - dcorner[1];\n'
+               '              float p0, p1, p2, p3;\n'
+               '              asm volatile("v_mul_f32 %0, %1, %2" : "=v"(p0) : "v"(gb), "v"(d10));\n'
+               '              asm volatile("v_mul_f32 %0, %1, %2" : "=v"(p1) : "v"(fb), "v"(d32));\n'
+               '              asm volatile("v_mul_f32 %0, %1, %2" : "=v"(p2) : "v"(ga), "v"(d20));\n'
+               '              asm volatile("v_mul_f32 %0, %1, %2" : "=v"(p3) : "v"(fa), "v"(d31));\n'
+               '              asm volatile("v_add_f32 %0, %1, %2" : "=v"(g_fa) : "v"(p0), "v"(p1));\n'
+               '              asm volatile("v_add_f32 %0, %1, %2" : "=v"(g_fb) : "v"(p2), "v"(p3));\n'
+               '            }\n')
+        return src.replace(G_FA + G_FB, new)
+    if name == 'slp_bperm':
+        s = src.replace(QUAD1, '              acc += __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, acc), 0x041F));\n')
+        return s.replace(QUAD2, '              acc += __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, acc), 0x081F));\n')
+    raise KeyError(name)
+
+
+VARIANTS = ['noslp', 'slp', 'slp_nop_dpp', 'slp_nop_mul', 'slp_scalar', 'slp_bperm', 'slp_waitcnt', 'slp_nop_only', 'slp_nop1',
+            'slp_nop2']
+
+
+def build(names=None):
+    hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
+    main_obj = os.path.join(ROOT, 'build', 'nfi_kernels.o')
+    assert os.path.exists(main_obj), 'run python __graft_entry__.py first (build/nfi_kernels.o)'
+    src = open(os.path.join(CSRC, 'nfi_backward_field.inc')).read()
+    procs = []
+    for name in (names or VARIANTS):
+        d = os.path.join(OUT, name)
+        shutil.rmtree(d, ignore_errors=True)
+        os.makedirs(os.path.join(d, 'nerf_from_image_amd', 'csrc'))
+        os.makedirs(os.path.join(d, 'include'))
+        for f in os.listdir(CSRC):
+            shutil.copy(os.path.join(CSRC, f), os.path.join(d, 'nerf_from_image_amd', 'csrc', f))
+        shutil.copy(os.path.join(ROOT, 'include', 'nfi_hip.h'), os.path.join(d, 'include', 'nfi_hip.h'))
+        open(os.path.join(d, 'nerf_from_image_amd', 'csrc', 'nfi_backward_field.inc'), 'w').write(patch(src, name))
+        extra = ['-fno-slp-vectorize'] if name == 'noslp' else []
+        obj = os.path.join(d, 'bwd.o')
+        procs.append((name, obj, subprocess.Popen(
+            [hipcc] + FLAGS + extra + ['-c', os.path.join(d, 'nerf_from_image_amd', 'csrc', 'nfi_backward_field.hip'), '-o', obj])))
+    for name, obj, p in procs:
+        assert p.wait() == 0, name
+        subprocess.check_call([hipcc, '--offload-arch=gfx950', '-fPIC', '-shared', main_obj, obj, '-o',
+                               os.path.join(OUT, 'libnfi_%s.so' % name)])
+        shutil.rmtree(os.path.join(OUT, name))
+        print('built', name)
+
+
+def explain(planes, w1, b1, w2, b2, att, beta, alpha, x, gs, gr, r, s, p, got, exp):
+    """Float64 re-derivation of the z component of one point's coordinate gradient, term by term:
+    z = sc * sum over plane 1 (x,z) and plane 2 (y,z) of [ga (dc2 - dc0) + fa (dc3 - dc1)],  dc_i = <d loss / d feature, corner_i>.
+    Reports which subset of the four terms reproduces the value the kernel returned."""
+    import itertools
+    import torch
+    P = planes[s].double()
+    res = P.shape[-1]
+    q = x[s, p].double() / r
+    u = ((q + 1) / 2 * (res - 1)).clamp(0, res - 1)
+    i0 = u.floor().clamp(max=res - 2).long()
+    f = u - i0
+    axes = ((0, 1), (0, 2), (1, 2))
+    corners = []
+    feat = torch.zeros(32, dtype=torch.float64, device=P.device)
+    for pl, (a, b) in enumerate(axes):
+        ia, ib, fa, fb = int(i0[a]), int(i0[b]), f[a], f[b]
+        c = [P[pl, :, ib, ia], P[pl, :, ib, ia + 1], P[pl, :, ib + 1, ia], P[pl, :, ib + 1, ia + 1]]
+        corners.append(c)
+        feat = feat + (1 - fb) * ((1 - fa) * c[0] + fa * c[1]) + fb * ((1 - fa) * c[2] + fa * c[3])
+    feat = feat.detach().requires_grad_()
+    h = torch.nn.functional.softplus((feat / 3) @ (w1.double() / 32 ** 0.5).t() + b1.double())
+    o = h @ (w2.double() / 8.0).t() + b2.double()
+    d = o[0]
+    outside = float((q.abs() > 1).any())
+    sigma = (1 / alpha.double()) * (0.5 + 0.5 * torch.sign(-d) * (1 - torch.exp(-d.abs() / beta.double()))) * (1 - outside)
+    rgb = torch.softmax(o[1:], dim=0) @ att[s].double()
+    loss = gs[s, p].double() * sigma.sum() + (gr[s, p].double() * rgb).sum()
+    gF, = torch.autograd.grad(loss, feat)
+    sc = (res - 1) * 0.5 / r
+    terms = {}
+    for pl in (1, 2):
+        a, b = axes[pl]
+        fa = f[a]
+        dc = [float(gF @ c) for c in corners[pl]]
+        terms['ga%d*(dc2-dc0)' % pl] = float((1 - fa) * (dc[2] - dc[0])) * sc
+        terms['fa%d*(dc3-dc1)' % pl] = float(fa * (dc[3] - dc[1])) * sc
+    full = sum(terms.values())
+    best = None
+    names = list(terms)
+    for k in range(0, 5):
+        for sub in itertools.combinations(names, k):
+            v = sum(terms[t] for t in sub)
+            if best is None or abs(v - got) < best[0]:
+                best = (abs(v - got), sub)
+    missing = [t for t in names if t not in best[1]]
+    print('      z expected %.7g  float64 sum of the four terms %.7g  returned %.7g = the sum WITHOUT %s (residual %.2e); terms %s' % (
+        exp, full, got, missing, best[0], {k: '%.6g' % v for k, v in terms.items()}))
+
+
+def run(n, names=None):
+    import torch
+    sys.path.insert(0, ROOT)
+    from nerf_from_image_amd import _lib
+    dev = torch.device('cuda:0')
+    g = torch.Generator().manual_seed(70500)
+    B, A, r, P, res = 2, 10, 0.55, 70000, 64
+    planes = torch.randn(B, 3, 32, res, res, generator=g).to(dev)
+    w1 = torch.randn(64, 32, generator=g).to(dev); b1 = (0.3 * torch.randn(64, generator=g)).to(dev)
+    w2 = torch.randn(11, 64, generator=g).to(dev); b2 = (0.3 * torch.randn(11, generator=g)).to(dev)
+    x = ((torch.rand(B, P, 3, generator=g) * 2 - 1) * r * 1.15).to(dev)
+    att = (torch.rand(B, A, 3, generator=g) * 2 - 1).to(dev)
+    beta, alpha = torch.tensor([0.12], device=dev), torch.tensor([0.3], device=dev)
+    gs = torch.randn(B, P, generator=g).to(dev); gr = torch.randn(B, P, 3, generator=g).to(dev)
+    ref = None
+    for name in (names or VARIANTS):
+        _lib._lib = None
+        _lib.LIBRARY = os.path.join(OUT, 'libnfi_%s.so' % name) if name != 'product' else os.path.join(ROOT, 'nerf_from_image_amd', 'libnfi_hip.so')
+        from nerf_from_image_amd import field_backward as fb, ops
+        texels = ops.planes_to_texels(planes); image = ops.decoder_pack(w1, b1, w2, b2, A)
+
+        def once():
+            return fb.field_query_bwd(x, texels, image, w1, w2, r, A, att, True, beta, alpha, gs, gr, scatter_mode=1,
+                                      want_points=True)['g_points']
+        if ref is None:      # the no-SLP build, majority over 5 launches
+            ref = torch.stack([once().clone() for _ in range(5)]).median(dim=0).values
+        ev, launches_with, shown = 0, 0, 0
+        quarter = [0, 0, 0, 0]
+        comp = [0, 0, 0]
+        maxdiff_vs_ref = 0.0
+        # different builds round differently: an EVENT is a launch-to-launch difference, so the comparison is with this
+        # build's own majority over 5 launches
+        own = torch.stack([once().clone() for _ in range(5)]).median(dim=0).values
+        maxdiff_vs_ref = float((own - ref).abs().max())
+        for it in range(n):
+            got = once()
+            dd = (got - own).abs()
+            bad = torch.nonzero(dd.amax(-1) > 0)
+            if bad.numel():
+                launches_with += 1
+                ev += bad.shape[0]
+                for s, p in bad.tolist():
+                    if shown < 12:
+                        shown += 1
+                        print('   event: launch %d scene %d point %d (tile point %d): got %s  expected %s' % (
+                            it, s, p, p % 16, ['%.9g' % v for v in got[s, p].tolist()], ['%.9g' % v for v in own[s, p].tolist()]))
+                        explain(planes, w1, b1, w2, b2, att, beta, alpha, x, gs, gr, r, s, p, float(got[s, p, 2]), float(own[s, p, 2]))
+                    quarter[(p % 16) // 4] += 1
+                    for c in range(3):
+                        comp[c] += int(dd[s, p, c] > 0)
+        print('%-12s events %4d in %d launches (%d launches affected); by point-in-tile quarter %s; by component xyz %s; '
+              'max |g - noslp| %.2e' % (name, ev, n, launches_with, quarter, comp, maxdiff_vs_ref), flush=True)
+
+
+if __name__ == '__main__':
+    if sys.argv[1] == 'build':
+        build(sys.argv[2:] or None)
+    else:
+        run(int(sys.argv[2]) if len(sys.argv) > 2 else 1500, sys.argv[3:] or None)
