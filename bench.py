@@ -50,7 +50,7 @@ MFMA_F32_PEAK_TFLOPS = 157.3
 MFMA_F16_PEAK_TFLOPS = 2500.0
 MLP_FLOP_PER_RAY = 704512
 N_SIMD = 1024
-PMC_PROFILES = ('profiles/r2/pmc_render_fwd.json', 'profiles/r1/pmc_render_fwd_derived.json')
+PMC_PROFILES = ('profiles/r3/pmc_render_fwd.json', 'profiles/r2/pmc_render_fwd.json', 'profiles/r1/pmc_render_fwd_derived.json')
 
 
 def cameras(n, radius, gen):
@@ -137,10 +137,22 @@ def cpu_baseline_and_parity(seed, dev, ops):
     out = ops.render_fwd(dd['cam'], dd['focal'], R, R, S, texels, image, SCENE_RANGE, A, dd['att'], True, dd['beta'],
                          dd['alpha'], noise_coarse=nc.to(dev), noise_fine=nf.to(dev), fine_sampling=True,
                          white_background=True, skip_missed_rays=True)
-    parity = {k: float((out[k].cpu() - ref[k]).abs().max()) for k in ('rgb', 'depth', 'mask')}
-    parity.update(budget=1e-4, against='CPU oracle (reference ATen numerics), 1 image of this workload, same noise',
-                  ok=bool(max(parity['rgb'], parity['depth'], parity['mask']) <= 1e-4 and
-                          all(bool(torch.isfinite(out[k]).all()) for k in ('rgb', 'depth', 'mask'))),
+    # the same image through the oracle evaluated with PyTorch-ROCm ops on this GPU = the reference's own GPU numerics
+    # (its elementwise kernels contract a*b+c into FMAs, so the two oracles differ from EACH OTHER: the gap is printed)
+    with torch.no_grad():
+        ref_gpu = orc.render(dd['planes'], dd['w1'], dd['b1'], dd['w2'], dd['b2'], dd['cam'], dd['focal'], R, R, S, SCENE_RANGE,
+                             white_background=True, noise_coarse=nc.to(dev), noise_fine=nf.to(dev), use_sdf=True,
+                             beta=dd['beta'], alpha=dd['alpha'], attention_values=dd['att'])
+    keys = ('rgb', 'depth', 'mask')
+    vs_cpu = {k: float((out[k].cpu() - ref[k]).abs().max()) for k in keys}
+    vs_gpu = {k: float((out[k] - ref_gpu[k]).abs().max()) for k in keys}
+    gap = {k: float((ref_gpu[k].cpu() - ref[k]).abs().max()) for k in keys}
+    parity = dict(vs_cpu)                    # top-level rgb / depth / mask: against the pinned CPU oracle
+    parity.update(budget=1e-4, against='CPU oracle (reference ATen numerics, pinned to the live reference), 1 image of this '
+                                       'workload, same noise',
+                  vs_pytorch_rocm_oracle=vs_gpu, oracle_cpu_vs_pytorch_rocm_gap=gap,
+                  ok=bool(max(vs_cpu.values()) <= 1e-4 and all(bool(torch.isfinite(out[k]).all()) for k in keys)),
+                  ok_vs_pytorch_rocm=bool(all(vs_gpu[k] <= gap[k] + 1e-4 for k in keys)),
                   mask_mean=float(ref['mask'].mean()))
     return base, parity
 
@@ -262,8 +274,10 @@ def load_pmc_profile():
     return None, None
 
 
-def roofline(kernel_ms, marched, n_images):
-    """Roofline object of the fused render kernel (see the module docstring)."""
+def roofline(kernel_ms, marched, n_images, live_clock_hz=None):
+    """Roofline object of the fused render kernel (see the module docstring).  live_clock_hz: the shader clock measured
+    INSIDE the timed launches (nfi_render_args.clock_probe: s_memtime / s_memrealtime of one persistent wave); the peak
+    is priced at it, so that kernel time and clock come from the same run (without it: the profile's own clock)."""
     t = kernel_ms * 1e-3
     src, prof = load_pmc_profile()
     gather_gbs = marched * GATHER_BYTES_PER_RAY / t / 1e9
@@ -287,9 +301,12 @@ def roofline(kernel_ms, marched, n_images):
         r.update(achieved=None, peak=None, frac=None, traffic=None,
                  note='no PMC profile with issue_cycles_per_marched_ray under profiles/: run tools/gpu_session.sh <tag> pmc (tools/pmc_collect.py)')
         return r
-    clk = prof['shader_clock_hz']
+    clk = live_clock_hz or prof['shader_clock_hz']
     ach = prof['issue_cycles_per_marched_ray'] * marched / t
     peak = N_SIMD * clk
+    units = prof['rays_marched_per_launch']
+    valu_per_ray = prof.get('valu_cycles_per_marched_ray') or (
+        4.0 * prof['raw']['SQ_ACTIVE_INST_VALU'] / units if prof.get('raw', {}).get('SQ_ACTIVE_INST_VALU') else None)
     scale = marched / prof['rays_marched_per_launch']                 # byte counters scale with the rays marched
     l2 = prof['l2_request_bytes_per_launch'] * scale
     fab = prof['fabric_bytes_per_launch'] * scale
@@ -301,10 +318,36 @@ def roofline(kernel_ms, marched, n_images):
                                 'is mostly the write-back of the preceding kernels\' dirty lines (texel hand-off, rand)'}
     r.update(achieved=ach / 1e9, peak=peak / 1e9, frac=ach / peak, traffic=fab,
              issue_cycles_per_marched_ray=prof['issue_cycles_per_marched_ray'], shader_clock_hz=clk,
+             shader_clock_source='live: s_memtime / s_memrealtime of a persistent wave of the timed launches'
+             if live_clock_hz else 'the PMC profile (GRBM_GUI_ACTIVE / 8 / kernel time of its clock pass)',
              frac_in_profile_run=prof.get('issue_frac'),
+             valu_pipe={'cycles_per_marched_ray': valu_per_ray,
+                        'frac': None if valu_per_ray is None else valu_per_ray * marched / t / peak,
+                        'note': 'SQ_ACTIVE_INST_VALU x4: the vector ALU alone; `frac` above also counts LDS / VMEM / SALU '
+                                'issue, which overlaps between the resident waves, so it is a utilisation proxy and this '
+                                'is the binding pipe'},
+             waves_per_simd=prof.get('waves_per_simd'),
              note='instruction-issue bound: SQ_ACTIVE_INST_ANY (x4 cycles) per marched ray from the PMC profile, scaled by '
-                  'the live ray count and kernel time, over 1024 SIMDs x the profiled shader clock')
+                  'the live ray count and kernel time, over 1024 SIMDs x the shader clock')
     return r
+
+
+def self_launch(n):
+    """`python bench.py --gpus N` without a launcher (how the driver calls it): re-run this very command line under
+    torch.distributed.run, one process per GPU on 127.0.0.1; rank 0 prints the JSON line, the exit code is passed on."""
+    import socket
+    import subprocess
+    avail = torch.cuda.device_count()
+    if n > avail:
+        raise SystemExit('--gpus %d but only %d GPU(s) are visible' % (n, avail))
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(n), '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    raise SystemExit(subprocess.call(cmd, env=env))
 
 
 def main():
@@ -323,11 +366,13 @@ def main():
     ap.add_argument('--no-overlap', action='store_true', help='train mode: launch the collectives after backward')
     args = ap.parse_args()
 
+    if 'WORLD_SIZE' not in os.environ and (args.gpus > 1 or args.force_dist):
+        return self_launch(args.gpus)
     rank = int(os.environ.get('RANK', 0))
     local_rank = int(os.environ.get('LOCAL_RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
     if world != args.gpus:
-        raise SystemExit('--gpus %d but WORLD_SIZE=%d: launch N>1 with torch.distributed.run' % (args.gpus, world))
+        raise SystemExit('--gpus %d but WORLD_SIZE=%d' % (args.gpus, world))
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
     use_dist = world > 1 or args.force_dist
@@ -354,6 +399,8 @@ def main():
     ev = HipEvents()
     state = {'ws': None}
 
+    probe = torch.zeros(2, dtype=torch.int64, device=dev)
+
     def step(timed_kernel=False):
         texels = ops.planes_to_texels(d['planes'])
         image = ops.decoder_pack(d['w1'], d['b1'], d['w2'], d['b2'], A)
@@ -362,7 +409,7 @@ def main():
         out = ops.render_fwd(d['cam'], d['focal'], R, R, S, texels, image, SCENE_RANGE, A, d['att'], True, d['beta'],
                              d['alpha'], noise_coarse=noise_c, noise_fine=noise_f, fine_sampling=True,
                              white_background=True, skip_missed_rays=not args.no_skip, workspace=state['ws'],
-                             events=ev.pair() if timed_kernel else None)
+                             events=ev.pair() if timed_kernel else None, clock_probe=probe if timed_kernel else None)
         state['ws'] = out['_workspace']
         return out
 
@@ -389,11 +436,15 @@ def main():
         elapsed = float(t.item())
 
     # ---- dominant kernel, timed live with HIP events on its own stream (untimed extra launches) ----
-    k_ms = []
+    k_ms, k_clk = [], []
     for _ in range(min(50, max(5, args.steps))):
         step(timed_kernel=True)
         k_ms.append(ev.elapsed_ms())
+        cyc, ticks = (int(v) for v in probe.tolist())
+        if ticks > 0:
+            k_clk.append(cyc / ticks * 1e8)                # s_memrealtime ticks at 100 MHz
     kernel_ms = sum(k_ms) / len(k_ms)
+    live_clock = sum(k_clk) / len(k_clk) if k_clk else None
     # rays the kernel marches = rays whose line meets the cube inflated by 1e-4 (the kernel's own skip test, fp32)
     import numpy as np
     ro, rd = ops.raygen(R, R, d['focal'], d['cam'], normalize=True)
@@ -417,7 +468,7 @@ def main():
                        'images_per_gpu': B, 'resolution': R, 'samples': '64+64', 'plane_res': PLANE_RES,
                        'camera_radius': RADIUS, 'scene_range': SCENE_RANGE, 'rays_marched_fraction': marched / n_rays,
                        'skip_missed_rays': not args.no_skip, 'sharding': 'images across ranks, no collective'},
-            'roofline': roofline(kernel_ms, marched, B),
+            'roofline': roofline(kernel_ms, marched, B, live_clock),
             'kernel_ms_stats': stats(k_ms),
         }
         if world == 1 and not args.no_extras:

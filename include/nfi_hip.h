@@ -293,6 +293,9 @@ typedef struct nfi_composite_bwd_args {
   float* g_sigma_b; float* g_rgb_b;   /* [N,n_b], [N,n_b,3] out (n_b > 0) */
   float* g_extra_a; float* g_extra_b; /* out or NULL */
   float* g_ray_directions;            /* [N,3] out or NULL */
+  /* 0: lists a and b are dense ([N,n_a], [N,n_b]).  > 0: every per-sample array (inputs and gradients) has this many
+   * entries per ray, e.g. n_a + n_b with depth_b = depth_a + n_a for the stash layout of nfi_render_fwd */
+  int list_row_stride;
 } nfi_composite_bwd_args;
 int nfi_composite_bwd(const nfi_composite_bwd_args* a, nfi_stream_t stream);
 /* x = o + d*t: g_points [N,S,3], depth [N,S] -> g_ray_origins [N,3], g_ray_directions [N,3] (either may be NULL) */
@@ -438,6 +441,23 @@ typedef struct nfi_render_args {
    * together with stage taps, the cycle profile, the view-direction decoder or the exact-fp32 MLP. */
   float fast_termination;
   int texel_layout;              /* NFI_TEXELS_PLANAR (0) / NFI_TEXELS_INTERLEAVED */
+  /* optional uint64[2] device array (NULL = off): shader cycles (s_memtime) and 100 MHz reference ticks
+   * (s_memrealtime) between the start and the end of workgroup 0 / wave 0 of the render kernel, i.e. the shader clock
+   * DURING this launch = cycles / ticks x 1e8 Hz (bench.py prices the kernel's issue rate against it) */
+  void* clock_probe;
+  /* pixel-row window: this call renders rows [row_offset, row_offset + height) of an image that is full_height rows
+   * tall (full_height 0 = height: the whole image).  Rays, samples and pixels are bit-identical to the same rows of the
+   * full render (the pixel coordinate of get_ray_bundle, lib/nerf_utils.py:36-39, is (row_offset + row) / full_height);
+   * outputs, noise and taps are sized for the window.  One image sharded over the ranks of a node: SURVEY.md 8(e),
+   * run.py:598-605 (res_multiplier renders). */
+  int row_offset; int full_height;
+  /* training stash (all three or none; fine_sampling only): the per-sample state the backward needs, ray-major with
+   * the coarse samples in [0,S) and the fine samples in [S,2S) of every row - stash_t [N,2S], stash_sigma [N,2S],
+   * stash_rgb [N,2S,3], in SOURCE order (not merged).  nfi_composite_bwd (list_row_stride = 2S) and
+   * nfi_field_query_bwd over the 2S points of every ray then replace autograd of run.py:193-348.  Unlike the debug
+   * taps the stash keeps the missed-ray skip: rays that are skipped get an all-zero row.  Mutually exclusive with the
+   * t_coarse ... rgb_fine taps. */
+  float* stash_t; float* stash_sigma; float* stash_rgb;
 } nfi_render_args;
 size_t nfi_render_workspace_bytes(int64_t n_rays);
 int nfi_render_fwd(const nfi_render_args* a, nfi_stream_t stream);

@@ -3,7 +3,10 @@
 Every host-level op goes through :func:`differentiable`: the forward runs the HIP kernel(s); if
 any input requires grad, the call is recorded as ONE autograd node whose backward is the ``bwd``
 closure handed in by the op (it launches the HIP backward kernels).  An op without a backward
-fails loudly when a gradient is actually requested; nothing ever falls back to ATen.
+fails loudly when a gradient is actually requested; nothing ever falls back to ATen.  The nodes are
+first-order only: ``torch.autograd.grad(..., create_graph=True)`` THROUGH a node raises (the one
+second-order path of the reference that touches the renderer's neighbourhood, the path-length
+regulariser of the plane producer, is kept off the fused hand-off node: generator.hip_forward).
 
 Lifetime: the node keeps its INPUTS through ``save_for_backward`` and, of its outputs, only their
 shape/dtype/device (:class:`OutputMeta`).  Keeping an output tensor on ``ctx`` would close the
@@ -42,6 +45,14 @@ class _HipNode(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, *grads):
+        if torch.is_grad_enabled():
+            # the engine runs backward functions with grad mode ON only under create_graph=True.  The HIP backward
+            # kernels record no graph, so the node would silently act as a constant in the second-order graph
+            # (once_differentiable does not catch it either when the incoming gradients carry no graph themselves)
+            raise RuntimeError(
+                'nerf_from_image_amd: %s is first-order only - torch.autograd.grad(..., create_graph=True) / a double '
+                'backward through a HIP node is not supported (the reference needs it for the path-length output of '
+                'the plane producer only; keep HIP nodes out of that graph, see handoff.unfused)' % ctx.name)
         if ctx.bwd is None:
             raise NotImplementedError(
                 'nerf_from_image_amd: %s has no HIP backward (forward-only op); wrap the call in '

@@ -229,8 +229,9 @@ struct CameraParams {
   const float* focal;      // [B] or null (ortho)
   const float* bbox;       // [B,2,2] or null
   const float* center;     // [B,2] or null
-  int height, width;
+  int height, width;       // of the FULL image (pixel coordinates); rays are indexed over `rows` x width
   int normalize;
+  int rows, row0;          // window of image rows this launch covers: [row0, row0 + rows)  (whole image: height, 0)
 };
 
 __device__ __forceinline__ void make_ray(const CameraParams& c, int b, int row, int col, float (&o)[3],

@@ -4,6 +4,7 @@
 #include "nfi_device.hpp"
 #include "../../include/nfi_hip.h"
 
+#include <atomic>
 #include <cstdio>
 
 extern thread_local char nfi_err_buf[256];          // defined in nfi_kernels.hip
@@ -20,6 +21,24 @@ static inline int check_launch(const char* what) {
   }
   return NFI_OK;
 }
+
+// Raises a kernel's dynamic-LDS limit to `bytes` - the LARGEST size any launch of that kernel uses, a constant - once per
+// device.  The attribute is process-global per kernel and device; because the value never changes, host threads
+// launching concurrently (one per GPU under nn.DataParallel) cannot lower it under each other, and a failure is
+// reported instead of surfacing as a failed launch later.
+#define NFI_ENSURE_DYNAMIC_LDS(kernel, bytes, what)                                                                  \
+  do {                                                                                                               \
+    static std::atomic<unsigned long long> nfi_done_{0};                                                             \
+    int nfi_dev_ = 0;                                                                                                \
+    if (hipGetDevice(&nfi_dev_) != hipSuccess) return fail(NFI_ERR_LAUNCH, what ": hipGetDevice failed");            \
+    const unsigned long long nfi_bit_ = 1ull << (nfi_dev_ & 63);                                                     \
+    if (!(nfi_done_.load(std::memory_order_acquire) & nfi_bit_)) {                                                   \
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,     \
+                              (int)(bytes)) != hipSuccess)                                                           \
+        return fail(NFI_ERR_LAUNCH, what ": hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed");                \
+      nfi_done_.fetch_or(nfi_bit_, std::memory_order_release);                                                       \
+    }                                                                                                                \
+  } while (0)
 
 #define REQUIRE(cond, msg) \
   do {                     \

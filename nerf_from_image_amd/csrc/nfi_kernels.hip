@@ -310,7 +310,7 @@ struct RaygenOut {
 };
 
 __global__ __launch_bounds__(256) void raygen_kernel(CameraParams cam, int n_scenes, RaygenOut out) {
-  const int hw = cam.height * cam.width;
+  const int hw = cam.rows * cam.width;
   const int64_t n = (int64_t)n_scenes * hw;
   uint32_t kmin = 0u, kmax = 0u, cnt = 0u;
   for (int64_t ray = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; ray < n; ray += (int64_t)gridDim.x * blockDim.x) {
@@ -318,7 +318,7 @@ __global__ __launch_bounds__(256) void raygen_kernel(CameraParams cam, int n_sce
     int pix = (int)(ray - (int64_t)b * hw);
     int row = pix / cam.width, col = pix - row * cam.width;
     float o[3], d[3];
-    make_ray(cam, b, row, col, o, d);
+    make_ray(cam, b, cam.row0 + row, col, o, d);
     if (out.ro) { out.ro[ray * 3 + 0] = o[0]; out.ro[ray * 3 + 1] = o[1]; out.ro[ray * 3 + 2] = o[2]; }
     if (out.rd) { out.rd[ray * 3 + 0] = d[0]; out.rd[ray * 3 + 1] = d[1]; out.rd[ray * 3 + 2] = d[2]; }
     if (out.near_raw) {
@@ -383,7 +383,7 @@ __global__ __launch_bounds__(256) void finish_planes_kernel(const float* __restr
 extern "C" int nfi_raygen(const nfi_raygen_args* a, nfi_stream_t stream) {
   REQUIRE(a && a->cam2world && a->ray_origins && a->ray_directions, "raygen: null pointer");
   REQUIRE(a->n_scenes > 0 && a->height > 0 && a->width > 0, "raygen: bad shape");
-  CameraParams cam{a->cam2world, a->focal, a->bbox, a->focal ? a->center : nullptr, a->height, a->width, a->normalize};
+  CameraParams cam{a->cam2world, a->focal, a->bbox, a->focal ? a->center : nullptr, a->height, a->width, a->normalize, a->height, 0};
   RaygenOut out{a->ray_origins, a->ray_directions, nullptr, nullptr, nullptr, nullptr, 0.0f};
   int64_t n = (int64_t)a->n_scenes * a->height * a->width;
   hipLaunchKernelGGL(raygen_kernel, dim3((unsigned)std::min<int64_t>((n + 255) / 256, kRayBlocks)), dim3(256), 0, (hipStream_t)stream, cam,
@@ -1209,6 +1209,25 @@ struct RenderKernelParams {
   unsigned long long* prof;
   const float* xray;   // view-direction decoder: padded per-ray features [N][kRayFeatPad], or null
   float fast_od;       // FAST kernels: optical depth -ln(eps) behind which a ray is no longer marched
+  unsigned long long* clock_probe;   // null, or {shader cycles, 100 MHz ticks} lived by workgroup 0 / wave 0
+  int tap_stride;      // entries per ray in the per-sample tap arrays: S, or 2S for the training stash (fine half at +S)
+  int stash;           // 1: the taps are the training stash: missed rays keep being skipped and get an all-zero row
+};
+
+// start / end of the clock probe (nfi_render_args.clock_probe): one wave of the persistent grid lives as long as the launch
+struct ClockProbe {
+  unsigned long long c0 = 0, r0 = 0;
+  bool on = false;
+  __device__ __forceinline__ void start(const RenderKernelParams& k) {
+    on = k.clock_probe && blockIdx.x == 0 && threadIdx.x == 0;
+    if (on) { c0 = __builtin_readcyclecounter(); r0 = __builtin_amdgcn_s_memrealtime(); }
+  }
+  __device__ __forceinline__ void stop(const RenderKernelParams& k) const {
+    if (on) {
+      k.clock_probe[0] = __builtin_readcyclecounter() - c0;
+      k.clock_probe[1] = __builtin_amdgcn_s_memrealtime() - r0;
+    }
+  }
 };
 
 // inclusive fp32 scan over the 64 lanes (fast mode only: the exact path scans in double, see nfi_device.hpp)
@@ -1297,6 +1316,8 @@ __global__ __launch_bounds__(256, OCC) void render_fwd_kernel(RenderKernelParams
   __shared__ __attribute__((aligned(16))) float lds[kImg];
   __shared__ __attribute__((aligned(16))) float vfs[4][64];
   __shared__ WaveSlab slabs[4];
+  ClockProbe clock;
+  clock.start(k);
   if (PREC == 1) {
     // fp16 fragments overlay the fp32 fragment area; biases stay where they are
     for (int i = threadIdx.x; i < kB1F; i += blockDim.x) lds[i] = k.image[kW1H + i];
@@ -1363,6 +1384,15 @@ __global__ __launch_bounds__(256, OCC) void render_fwd_kernel(RenderKernelParams
         k.rgb[(size_t)ray * 3] = bg; k.rgb[(size_t)ray * 3 + 1] = bg; k.rgb[(size_t)ray * 3 + 2] = bg;
         k.depth[ray] = 0.0f; k.mask[ray] = 0.0f;
       }
+      if constexpr (TAPS) {
+        if (k.stash && valid) {
+          // an all-zero row: its composite backward is exactly zero and its points (the ray origin) carry no gradient
+          const size_t zs = (size_t)ray * (size_t)k.tap_stride + lane;
+          k.t_coarse[zs] = 0.0f; k.sigma_coarse[zs] = 0.0f; k.t_fine[zs] = 0.0f; k.sigma_fine[zs] = 0.0f;
+          float* q = k.rgb_coarse + zs * 3; q[0] = 0.0f; q[1] = 0.0f; q[2] = 0.0f;
+          q = k.rgb_fine + zs * 3; q[0] = 0.0f; q[1] = 0.0f; q[2] = 0.0f;
+        }
+      }
     } else {
       unsigned long long t0 = PROF ? __builtin_readcyclecounter() : 0;
       const int scene = (int)(ray / (uint32_t)k.hw);
@@ -1383,7 +1413,7 @@ __global__ __launch_bounds__(256, OCC) void render_fwd_kernel(RenderKernelParams
       float near = in.near, far = in.far;
       finish_planes((hitb & 1) != 0, fill_near, fill_far, near, far);
       const float dnorm = norm3(dx, dy, dz);
-      const size_t rs = (size_t)ray * S;
+      const size_t rs = (size_t)ray * (size_t)k.tap_stride;      // row of this ray in the per-sample tap / stash arrays
 
       // ---- coarse pass ----
       float tc = 0.0f;
@@ -1503,6 +1533,7 @@ __global__ __launch_bounds__(256, OCC) void render_fwd_kernel(RenderKernelParams
     pc[11] = __builtin_readcyclecounter() - tk0;
     for (int i = 0; i < 12; ++i) atomicAdd(k.prof + i, pc[i]);
   }
+  clock.stop(k);
 }
 
 // The same pipeline for 64 < S <= 128 samples per pass (BASELINE cfg5, ray_multiplier=2): every lane
@@ -1514,6 +1545,8 @@ __global__ __launch_bounds__(256, 2) void render_fwd_wide_kernel(RenderKernelPar
   __shared__ __attribute__((aligned(16))) float lds[kImg];
   __shared__ __attribute__((aligned(16))) float vfs[4][64];
   __shared__ WaveSlabWide slabs[4];
+  ClockProbe clock;
+  clock.start(k);
   if (PREC == 1) {
     for (int i = threadIdx.x; i < kB1F; i += blockDim.x) lds[i] = k.image[kW1H + i];
     for (int i = kB1F + threadIdx.x; i < kLdsImageFloats; i += blockDim.x) lds[i] = k.image[i];
@@ -1552,6 +1585,19 @@ __global__ __launch_bounds__(256, 2) void render_fwd_wide_kernel(RenderKernelPar
         k.rgb[(size_t)ray * 3] = bg; k.rgb[(size_t)ray * 3 + 1] = bg; k.rgb[(size_t)ray * 3 + 2] = bg;
         k.depth[ray] = 0.0f; k.mask[ray] = 0.0f;
       }
+      if constexpr (TAPS) {
+        if (k.stash) {
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            if (j * 64 + lane < S) {
+              const size_t zs = (size_t)ray * (size_t)k.tap_stride + j * 64 + lane;
+              k.t_coarse[zs] = 0.0f; k.sigma_coarse[zs] = 0.0f; k.t_fine[zs] = 0.0f; k.sigma_fine[zs] = 0.0f;
+              float* q = k.rgb_coarse + zs * 3; q[0] = 0.0f; q[1] = 0.0f; q[2] = 0.0f;
+              q = k.rgb_fine + zs * 3; q[0] = 0.0f; q[1] = 0.0f; q[2] = 0.0f;
+            }
+          }
+        }
+      }
     } else {
       const int scene = (int)(ray / (uint32_t)k.hw);
       if (scene != cur_scene) {
@@ -1574,6 +1620,7 @@ __global__ __launch_bounds__(256, 2) void render_fwd_wide_kernel(RenderKernelPar
       finish_planes((hitb & 1) != 0, fill_near, fill_far, near, far);
       const float dnorm = norm3(dx, dy, dz);
       const size_t rs = (size_t)ray * S;
+      const size_t ts = (size_t)ray * (size_t)k.tap_stride;      // row of this ray in the per-sample tap / stash arrays
       float* stage = &slab.srt[0][0];
 
       // ---- coarse pass ----
@@ -1673,7 +1720,7 @@ __global__ __launch_bounds__(256, 2) void render_fwd_wide_kernel(RenderKernelPar
           eidx[2 + j] = val[j] ? S + j * 64 + lane : 0x7fffffff;
           if constexpr (TAPS) {
             if (val[j]) {
-              const size_t i = rs + j * 64 + lane;
+              const size_t i = ts + j * 64 + lane;
               if (k.t_fine) k.t_fine[i] = tf[j];
               if (k.sigma_fine) k.sigma_fine[i] = q.sigma;
               if (k.rgb_fine) { float* o3 = k.rgb_fine + i * 3; o3[0] = q.r; o3[1] = q.g; o3[2] = q.b; }
@@ -1707,7 +1754,7 @@ __global__ __launch_bounds__(256, 2) void render_fwd_wide_kernel(RenderKernelPar
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
           if (val[j]) {
-            const size_t i = rs + j * 64 + lane;
+            const size_t i = ts + j * 64 + lane;
             if (k.t_coarse) k.t_coarse[i] = tc[j];
             if (k.sigma_coarse) k.sigma_coarse[i] = sc[j];
             if (k.rgb_coarse) { float* o3 = k.rgb_coarse + i * 3; o3[0] = rc[j]; o3[1] = gc[j]; o3[2] = bc[j]; }
@@ -1730,6 +1777,7 @@ __global__ __launch_bounds__(256, 2) void render_fwd_wide_kernel(RenderKernelPar
     }
     cur = nxt;
   }
+  clock.stop(k);
 }
 
 extern "C" size_t nfi_render_workspace_bytes(int64_t n_rays) {
@@ -1761,12 +1809,20 @@ extern "C" int nfi_render_fwd(const nfi_render_args* a, nfi_stream_t stream) {
   uint8_t* hit = a->hit ? a->hit : reinterpret_cast<uint8_t*>(ws + 16 + 8 * n);
   // note: 16 floats + 8n floats + n bytes <= workspace_bytes by construction (64 + 32n + pad(n))
   if (hipMemsetAsync(reduce, 0, 16, s) != hipSuccess) return fail(NFI_ERR_LAUNCH, "render: memset failed");
-  CameraParams cam{a->cam2world, a->focal, a->bbox, a->focal ? a->center : nullptr, a->height, a->width, 1};
+  const int full_h = a->full_height > 0 ? a->full_height : a->height;
+  REQUIRE(a->row_offset >= 0 && a->row_offset + a->height <= full_h, "render: row window outside the image");
+  CameraParams cam{a->cam2world, a->focal, a->bbox, a->focal ? a->center : nullptr, full_h, a->width, 1, a->height, a->row_offset};
   RaygenOut rout{ro, rd, near_raw, far_raw, hit, reduce, a->scene_range};
   hipLaunchKernelGGL(raygen_kernel, dim3((unsigned)std::min<int64_t>((n + 255) / 256, kRayBlocks)), dim3(256), 0, s, cam, a->n_scenes, rout);
 
-  const bool any_tap = a->t_coarse || a->sigma_coarse || a->rgb_coarse || a->t_fine || a->sigma_fine || a->rgb_fine ||
-                       a->t_sorted || a->weights || a->perm || a->near_plane || a->far_plane;
+  const bool stash = a->stash_t || a->stash_sigma || a->stash_rgb;
+  REQUIRE(!stash || (a->stash_t && a->stash_sigma && a->stash_rgb && a->fine_sampling),
+          "render: the training stash needs stash_t, stash_sigma, stash_rgb and fine sampling");
+  REQUIRE(!stash || !(a->t_coarse || a->sigma_coarse || a->rgb_coarse || a->t_fine || a->sigma_fine || a->rgb_fine),
+          "render: the training stash and the per-sample debug taps are mutually exclusive");
+  const bool debug_tap = a->t_coarse || a->sigma_coarse || a->rgb_coarse || a->t_fine || a->sigma_fine || a->rgb_fine ||
+                         a->t_sorted || a->weights || a->perm || a->near_plane || a->far_plane;
+  const bool any_tap = debug_tap || stash;
   RenderKernelParams k;
   memset(&k, 0, sizeof(k));
   k.n_scenes = a->n_scenes; k.hw = a->height * a->width; k.S = a->n_samples;
@@ -1779,8 +1835,16 @@ extern "C" int nfi_render_fwd(const nfi_render_args* a, nfi_stream_t stream) {
   k.near_plane = a->near_plane; k.far_plane = a->far_plane;
   k.t_coarse = a->t_coarse; k.sigma_coarse = a->sigma_coarse; k.rgb_coarse = a->rgb_coarse;
   k.t_fine = a->t_fine; k.sigma_fine = a->sigma_fine; k.rgb_fine = a->rgb_fine;
+  k.tap_stride = a->n_samples;
+  if (stash) {
+    // the stash rows hold the coarse samples in [0,S) and the fine samples in [S,2S)
+    k.tap_stride = 2 * a->n_samples; k.stash = 1;
+    k.t_coarse = a->stash_t; k.t_fine = a->stash_t + a->n_samples;
+    k.sigma_coarse = a->stash_sigma; k.sigma_fine = a->stash_sigma + a->n_samples;
+    k.rgb_coarse = a->stash_rgb; k.rgb_fine = a->stash_rgb + 3 * (size_t)a->n_samples;
+  }
   k.t_sorted = a->t_sorted; k.weights = a->weights; k.perm = a->perm;
-  k.skip_missed = (a->skip_missed_rays && !any_tap) ? 1 : 0;
+  k.skip_missed = (a->skip_missed_rays && !debug_tap) ? 1 : 0;
 
   k.counter = reduce + 3;
   k.width = a->width;
@@ -1811,6 +1875,7 @@ extern "C" int nfi_render_fwd(const nfi_render_args* a, nfi_stream_t stream) {
   k.tile_order = (((a->tuning >> 2) & 1) == 0 && (a->width % 8 == 0) && (a->height % 8 == 0)) ? 1 : 0;
   k.prof = (unsigned long long*)a->profile_cycles;
   k.xray = a->ray_features;
+  k.clock_probe = reinterpret_cast<unsigned long long*>(a->clock_probe);
   const bool fast = a->fast_termination > 0.0f;
   REQUIRE(a->fast_termination >= 0.0f && a->fast_termination < 1.0f, "render: fast_termination must be in [0,1)");
   REQUIRE(!fast || !(any_tap || a->profile_cycles || a->ray_features || ((a->tuning >> 3) & 1)),

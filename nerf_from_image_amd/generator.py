@@ -301,7 +301,13 @@ def hip_forward(self, viewdir, c, request_model_outputs=['sampler'], model_input
     else:
         w_syn = ws
     kwargs = {'noise_mode': 'const'} if model_inputs.get('freeze_noise') else {}
-    planes = self.synthesis_network(w_syn, **kwargs)
+    if 'path_length' in request_model_outputs:
+        # second-order output: keep the (once-differentiable) fused hand-off node out of this call's graph
+        from . import handoff
+        with handoff.unfused(self.synthesis_network):
+            planes = self.synthesis_network(w_syn, **kwargs)
+    else:
+        planes = self.synthesis_network(w_syn, **kwargs)
     planes = planes.view(batch, 3, 32, planes.shape[-2], planes.shape[-1])
 
     model_outputs = {}
@@ -375,14 +381,15 @@ def wrapped_forward(self, viewdir, c, request_model_outputs=['sampler'], model_i
     captured = {}
     hook = self.synthesis_network.register_forward_hook(lambda mod, inp, out: captured.__setitem__('planes', out))
     use_vd = bool(self.use_viewdir) and viewdir is not None
-    try:
-        if use_vd:
-            with _capture_ray_feature(self.viewdir_mapper) as cap:
-                model_outputs = self._nfi_original_forward(viewdir, c, req, model_inputs)
-        else:
-            model_outputs = self._nfi_original_forward(viewdir, c, req, model_inputs)
-    finally:
-        hook.remove()
+    import contextlib
+    from . import handoff
+    with contextlib.ExitStack() as stack:
+        stack.callback(hook.remove)
+        if 'path_length' in req:
+            # differentiated twice (generator.py:484-499): the fused hand-off node is first-order only
+            stack.enter_context(handoff.unfused(self.synthesis_network))
+        cap = stack.enter_context(_capture_ray_feature(self.viewdir_mapper)) if use_vd else None
+        model_outputs = self._nfi_original_forward(viewdir, c, req, model_inputs)
     planes = captured.get('planes')
     if planes is not None:
         planes = planes.view(planes.shape[0], 3, 32, planes.shape[-2], planes.shape[-1])

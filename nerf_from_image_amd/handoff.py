@@ -5,9 +5,13 @@ The reference's synthesis network ends with ``img = upsample2d(img) ; y = torgb(
 cost one NCHW -> channel-last pass per render (and one back per backward).  ``fuse_last_block`` replaces the tail of
 that block by ONE HIP kernel (``nfi_torgb_texels_fwd``: 1x1 modulated conv on MFMA + bias + bilinear up-filter + add)
 whose output is a ``[B,96,R,R]`` tensor in channels-last memory format - i.e. exactly the interleaved texel image the
-field kernels read, while every PyTorch consumer of ``planes`` (path-length, the reference's own regulariser branch)
-still sees the shape it expects.  Parameters, buffers and ``state_dict`` keys are untouched; the block's two 3x3
-modulated convolutions stay the reference's modules.
+field kernels read, while every PyTorch consumer of ``planes`` still sees the shape it expects.  Parameters, buffers
+and ``state_dict`` keys are untouched; the block's two 3x3 modulated convolutions stay the reference's modules.
+
+First-order only: the fused node has a HIP backward but no double backward, so a forward that asks for the
+``path_length`` output (``torch.autograd.grad(planes * noise, ws, create_graph=True)``, generator.py:484-499, which
+is then differentiated AGAIN) runs the block's original PyTorch tail for that call - ``with unfused(net):`` in
+``generator.hip_forward`` / ``wrapped_forward`` - instead of back-propagating an incomplete second-order gradient.
 
     import nerf_from_image_amd.handoff as nfi_handoff
     nfi_handoff.fuse_last_block(model.synthesis_network)          # or attach(model, fused_handoff=True)
@@ -72,6 +76,31 @@ def fuse_last_block(synthesis_network):
         blk._nfi_original_forward = blk.forward
         blk.forward = types.MethodType(fused_block_forward, blk)
     return blk
+
+
+class unfused:
+    """``with unfused(net):`` - the last block's original forward for the duration of the block (no-op when the block
+    is not fused)."""
+
+    def __init__(self, synthesis_network):
+        self.net = synthesis_network
+        self.blk = None
+
+    def __enter__(self):
+        try:
+            blk = last_block(self.net)
+        except AttributeError:
+            return self
+        if hasattr(blk, '_nfi_original_forward'):
+            self.blk = blk
+            self.fused = blk.forward
+            blk.forward = blk._nfi_original_forward
+        return self
+
+    def __exit__(self, *exc):
+        if self.blk is not None:
+            self.blk.forward = self.fused
+        return False
 
 
 def unfuse_last_block(synthesis_network):

@@ -22,12 +22,6 @@ import torch
 from . import ops
 from .autograd import differentiable, zeros_like_or
 
-# True (default, the reference's behaviour): compute_near_far_planes raises when no ray of the batch meets the scene
-# cube - the reference fails on min() of an empty selection (lib/nerf_utils.py:258).  The check reads one counter back
-# from the device, i.e. one host synchronisation per call; a training loop that cannot see such a batch may clear it.
-STRICT_NEAR_FAR = True
-
-
 def cumprod_exclusive(tensor: torch.Tensor) -> torch.Tensor:
     """tf.math.cumprod(..., exclusive=True) along the last dim.  Kept for API completeness only:
     nothing in this package calls it (the running transmittance lives inside the weights and
@@ -66,10 +60,16 @@ def get_ray_bundle_normalized(height: int, width: int, focal_length: Optional[to
     return _ray_bundle('get_ray_bundle_normalized', height, width, focal_length, tform_cam2world, bbox, center, True)
 
 
-def compute_near_far_planes(ray_origins: torch.Tensor, ray_directions: torch.Tensor, scene_range: float):
+def compute_near_far_planes(ray_origins: torch.Tensor, ray_directions: torch.Tensor, scene_range: float,
+                            strict: bool = True):
     """Slab test against [-scene_range, scene_range]^3 with the reference's miss-fill, clamps and
-    its failure when no ray hits.  No gradient (the reference detaches its inputs)."""
-    near, far, _ = ops.near_far(ray_origins.detach(), ray_directions.detach(), scene_range, strict=STRICT_NEAR_FAR)
+    its failure when no ray hits.  No gradient (the reference detaches its inputs).
+
+    strict (not in the reference's signature; default = its behaviour): raise when no ray of the batch meets the scene
+    cube - the reference fails on min() of an empty selection (lib/nerf_utils.py:258).  The check reads one counter
+    back from the device, i.e. one host synchronisation per call; a training loop that cannot see such a batch may pass
+    False (render option strict_near_far)."""
+    near, far, _ = ops.near_far(ray_origins.detach(), ray_directions.detach(), scene_range, strict=strict)
     return near, far
 
 

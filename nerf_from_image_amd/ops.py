@@ -358,8 +358,14 @@ def render_fwd(cam2world, focal, height, width, num_samples, texels, decoder_ima
                attention_values=None, use_sdf=True, beta=None, alpha=None, bbox=None, center=None,
                noise_coarse=None, noise_fine=None, fine_sampling=True, white_background=True, taps=(),
                skip_missed_rays=True, workspace=None, events=None, tuning=0, profile_cycles=None, ray_features=None,
-               fast_termination=0.0):
+               fast_termination=0.0, row_window=None, clock_probe=None, stash=False):
     """Fused forward render.  Returns dict(rgb [B,H,W,3], depth, mask [B,H,W], + requested taps).
+    row_window: None, or (row_offset, full_height): `height` rows starting at row_offset of an image full_height rows tall
+    (bit-identical to those rows of the full render; noise / outputs / taps are sized for the window).
+    clock_probe: None or a uint64 / int64 [2] device tensor receiving {shader cycles, 100 MHz ticks} of the render kernel.
+    stash: also return the training stash 'stash_t' [B,H,W,2S], 'stash_sigma' [B,H,W,2S], 'stash_rgb' [B,H,W,2S,3]
+    (coarse samples in [..., :S], fine in [..., S:], source order; skipped rays hold zeros) and 'ray_origins' /
+    'ray_directions' - what composite_bwd(list_row_stride=2S) + field_query_bwd need for the backward of the render.
     ray_features: padded [B,H,W,48] per-ray view-direction features (decoder_pack_viewdir image).
     fast_termination: 0 = exact; eps in (0,1) = opt-in transmittance-threshold termination + sample compaction (NOT
     parity: rgb/mask change by O(eps), see include/nfi_hip.h)."""
@@ -391,6 +397,14 @@ def render_fwd(cam2world, focal, height, width, num_samples, texels, decoder_ima
             continue
         shp, dt = shapes[name]
         tap_t[name] = torch.zeros(shp, dtype=dt, device=dev)
+    if stash:
+        if not fine_sampling:
+            raise ValueError('render_fwd: the training stash exists for fine sampling only')
+        for name in ('ray_origins', 'ray_directions'):
+            tap_t.setdefault(name, torch.empty(shapes[name][0], dtype=torch.float32, device=dev))
+        tap_t['stash_t'] = torch.empty((B, height, width, 2 * S), dtype=torch.float32, device=dev)
+        tap_t['stash_sigma'] = torch.empty((B, height, width, 2 * S), dtype=torch.float32, device=dev)
+        tap_t['stash_rgb'] = torch.empty((B, height, width, 2 * S, 3), dtype=torch.float32, device=dev)
     ws_bytes = lib.nfi_render_workspace_bytes(n)
     if workspace is None or workspace.numel() < ws_bytes:
         workspace = torch.empty((ws_bytes,), dtype=torch.uint8, device=dev)
@@ -418,7 +432,9 @@ def render_fwd(cam2world, focal, height, width, num_samples, texels, decoder_ima
             workspace=workspace, workspace_bytes=workspace.numel(), skip_missed_rays=int(skip_missed_rays),
             event_start=None if events is None else events[0], event_stop=None if events is None else events[1],
             tuning=int(tuning), profile_cycles=profile_cycles, ray_features=ray_features,
-            fast_termination=float(fast_termination), **tap_t)
+            fast_termination=float(fast_termination), clock_probe=clock_probe,
+            row_offset=0 if row_window is None else int(row_window[0]),
+            full_height=0 if row_window is None else int(row_window[1]), **tap_t)
     out.update(tap_t)
     out['_workspace'] = workspace
     return out
@@ -466,6 +482,30 @@ def sdf_gradient_bwd(points, texels, w1, b1, w2, b2, scene_range, g_sdf, g_gradi
 # --------------------------------------------------------------------------- #
 # backward wrappers
 # --------------------------------------------------------------------------- #
+def composite_bwd_stash(ray_directions, stash_t, stash_sigma, stash_rgb, g_rgb_map, g_mask=None, white_background=True,
+                        want_rd=True):
+    """Compositing backward on the training stash of render_fwd (rows of 2S entries: coarse | fine).  Returns
+    dict(g_sigma [..., 2S], g_rgb [..., 2S, 3], g_ray_directions?) in the stash's layout."""
+    rd = _f32c(ray_directions, 'ray_directions')
+    t, sg, col = _f32c(stash_t, 'stash_t'), _f32c(stash_sigma, 'stash_sigma'), _f32c(stash_rgb, 'stash_rgb')
+    S2 = t.shape[-1]
+    S = S2 // 2
+    n = t.numel() // S2
+    out = dict(g_sigma=torch.empty_like(sg), g_rgb=torch.empty_like(col))
+    if want_rd:
+        out['g_ray_directions'] = torch.empty_like(rd)
+    f4 = 4              # bytes per float: list b starts S entries into every row
+    with torch.cuda.device(rd.device):
+        _lib.call_struct('nfi_composite_bwd', 'nfi_composite_bwd_args', _stream(rd), n_rays=n, n_a=S, n_b=S,
+                         list_row_stride=S2, ray_directions=rd, depth_a=t, sigma_a=sg, rgb_a=col,
+                         depth_b=t.data_ptr() + S * f4, sigma_b=sg.data_ptr() + S * f4, rgb_b=col.data_ptr() + 3 * S * f4,
+                         n_extra=0, white_background=int(white_background), g_rgb_map=_f32c(g_rgb_map, 'g_rgb_map'),
+                         g_mask=_f32c(g_mask, 'g_mask'), g_sigma_a=out['g_sigma'], g_rgb_a=out['g_rgb'],
+                         g_sigma_b=out['g_sigma'].data_ptr() + S * f4, g_rgb_b=out['g_rgb'].data_ptr() + 3 * S * f4,
+                         g_ray_directions=out.get('g_ray_directions'))
+    return out
+
+
 def composite_bwd(ray_directions, depth_a, sigma_a, rgb_a, g_rgb_map, g_mask=None, depth_b=None, sigma_b=None,
                   rgb_b=None, extra_a=None, extra_b=None, g_extra_map=None, white_background=True, want_rd=True):
     rd = _f32c(ray_directions, 'ray_directions')

@@ -41,6 +41,42 @@ def shard_batch(*tensors, rank=None, world_size=None):
     return out[0] if len(out) == 1 else tuple(out)
 
 
+def shard_rows(height, rank=None, world_size=None, align=8):
+    """[row0, row1) of an image `height` rows tall for this rank when ONE image is rendered by all ranks (SURVEY.md 8(e):
+    "for a single huge image, shard pixel tiles and replicate the planes"; run.py:598-605 res_multiplier renders, or
+    any batch smaller than the node).  Contiguous bands of whole `align`-row strips (the render kernel hands rays out in
+    8 / 16 / 32-pixel blocks), as even as the strips allow; ranks beyond the strip count get an empty band."""
+    r, w = world()
+    rank = r if rank is None else rank
+    world_size = w if world_size is None else world_size
+    strips = -(-height // align)
+    lo = (strips * rank) // world_size
+    hi = (strips * (rank + 1)) // world_size
+    return min(lo * align, height), min(hi * align, height)
+
+
+def gather_rows(window, dim=1):
+    """All-gathers the row bands of :func:`shard_rows` (tensors [B, rows_r, W, ...], rows along `dim`) into the full
+    image on every rank.  Bands may differ in height (or be empty)."""
+    rank, w = world()
+    if w == 1:
+        return window
+    t = window.movedim(dim, 0).contiguous()
+    full = gather_metrics(t)
+    return full.movedim(0, dim).contiguous()
+
+
+def render_image_rows(render_rows, height, dim=1):
+    """One image over all ranks: `render_rows(row0, row1)` renders this rank's band (e.g. a render bound with
+    ``make_render(..., row_window=(row0, row1 - row0))`` or ops.render_fwd(row_window=(row0, height))) and returns a tensor
+    or a tuple of tensors with the rows along `dim`; the bands are gathered into full images on every rank."""
+    r0, r1 = shard_rows(height)
+    out = render_rows(r0, r1)
+    if isinstance(out, (tuple, list)):
+        return tuple(None if o is None else gather_rows(o, dim) for o in out)
+    return gather_rows(out, dim)
+
+
 class GradientBuckets:
     """Persistent flat fp32 gradient storage for a replica's parameters, with the collective overlapped with backward.
 
@@ -58,6 +94,20 @@ class GradientBuckets:
                            explicitly: on the fully connected xGMI mesh each is one direct exchange per peer).
 
     Use ``zero_grad()`` of this object instead of the optimiser's (which would detach the views).
+
+    SEVERAL backward() calls per optimiser step (the reference accumulates: one ``loss.backward()`` per discriminator
+    before ``optimizer_g.step()``, run.py:1044, and ``loss_real.backward()`` + ``loss_fake.backward()`` before
+    ``optimizer_d.step()``, run.py:1110-1139): run all but the LAST of them inside ``with buckets.no_sync():`` -
+    gradients then only accumulate in the flat buffers - and the last one outside, which launches the collectives::
+
+        buckets.zero_grad()
+        with buckets.no_sync():
+            loss_a.backward()
+        loss_b.backward()              # buckets go out as this backward completes them
+        buckets.finish(); optimiser.step()
+
+    A backward that reaches a bucket whose collective is already in flight would add local-only gradients to a buffer
+    that has been (or is being) reduced - silently wrong and rank-divergent - so it raises instead.
     """
 
     def __init__(self, parameters, bucket_bytes=32 << 20, average=False, mode='all_reduce', overlap=True, group=None):
@@ -67,10 +117,11 @@ class GradientBuckets:
         if not self.params:
             raise ValueError('GradientBuckets: no parameter requires grad')
         self.average, self.mode, self.overlap, self.group = average, mode, overlap, group
-        _, self.world_size = world()
         # a collective is issued whenever a process group exists - also with a single rank (bench.py --force-dist
         # runs the RCCL path on one GPU); without a process group the object only manages the flat storage
         self.active = dist.is_available() and dist.is_initialized()
+        self.world_size = dist.get_world_size(group) if self.active else 1     # of THIS group: shard padding, averaging
+        self._sync = True
         dev = self.params[0].device
         per = max(1, int(bucket_bytes) // 4)
         self.buckets = []          # dict(flat, params, offsets, pending, shard)
@@ -119,6 +170,23 @@ class GradientBuckets:
         self._handles = []
         self.launched_in_backward = 0
 
+    def no_sync(self):
+        """Context manager for every backward of a step except the last one: gradients accumulate, nothing is launched
+        and arrivals are not counted (see the class docstring)."""
+        buckets = self
+
+        class _NoSync:
+            def __enter__(self):
+                if any(buckets._launched):
+                    raise RuntimeError('GradientBuckets.no_sync(): collectives of this step are already in flight; '
+                                       'accumulating backwards must come BEFORE the synchronising one')
+                buckets._sync = False
+
+            def __exit__(self, *exc):
+                buckets._sync = True
+                return False
+        return _NoSync()
+
     def _launch(self, bi):
         b = self.buckets[bi]
         if not self.active:
@@ -134,9 +202,16 @@ class GradientBuckets:
         if p.grad.data_ptr() != self._ptr[id(p)]:
             raise RuntimeError('GradientBuckets: a .grad was replaced (use GradientBuckets.zero_grad(), not the '
                                "optimiser's zero_grad(set_to_none=True))")
+        if self._launched[bi] and self.active:
+            raise RuntimeError('GradientBuckets: a gradient arrived in a bucket whose collective was already launched '
+                               '(a second backward() in this step?).  Run every backward but the last inside '
+                               '`with buckets.no_sync():`, or call zero_grad() between steps')
+        if not self._sync or not self.overlap:
+            return                       # (without overlap nothing is launched before finish(): any number of backwards)
         self._arrivals[bi] += 1
-        if not self.overlap:
-            return
+        if self._arrivals[bi] > len(self.buckets[bi]['params']):
+            raise RuntimeError('GradientBuckets: a parameter received two gradients in one synchronising backward pass '
+                               '(two backward() calls without no_sync()?)')
         if self._arrivals[bi] == len(self.buckets[bi]['params']) and not self._launched[bi]:
             self._launch(bi)
             self._launched[bi] = True
@@ -173,29 +248,35 @@ class GradientBuckets:
 
 
 _FLAT_CACHE = {}
+_FLAT_CACHE_MAX = 4
 
 
-def allreduce_gradients(parameters, average=False):
-    """Sums (or averages) .grad of the given parameters across ranks, one shot after backward (no overlap; for the
-    persistent, overlapped form use :class:`GradientBuckets`).  Gradients that already live in GradientBuckets storage
-    are reduced in place; loose gradients go through ONE persistent flat staging buffer (re-used across steps)."""
+def allreduce_gradients(parameters, average=False, group=None):
+    """Sums (or averages) .grad of the given parameters across the ranks of `group`, one shot after backward (no
+    overlap; for the persistent, overlapped form use :class:`GradientBuckets`).  The gradients go through a persistent
+    flat staging buffer per (device, size) - generator and discriminator steps alternate every iteration, so both
+    sizes stay cached (at most four buffers are kept, oldest dropped first)."""
     params = [p for p in parameters if p.grad is not None]
-    rank, w = world()
-    if w == 1 or not params:
+    if not (dist.is_available() and dist.is_initialized()) or not params:
+        return 0
+    w = dist.get_world_size(group)
+    if w == 1:
         return 0
     n = sum(p.grad.numel() for p in params)
     key = (params[0].grad.device, n)
-    flat = _FLAT_CACHE.get(key)
+    flat = _FLAT_CACHE.pop(key, None)
     if flat is None:
-        _FLAT_CACHE.clear()                     # one staging buffer at a time (G and D steps alternate sizes rarely)
-        flat = _FLAT_CACHE[key] = torch.empty(n, dtype=torch.float32, device=key[0])
+        while len(_FLAT_CACHE) >= _FLAT_CACHE_MAX:
+            _FLAT_CACHE.pop(next(iter(_FLAT_CACHE)))
+        flat = torch.empty(n, dtype=torch.float32, device=key[0])
+    _FLAT_CACHE[key] = flat                    # (re-)inserted last: most recently used
     views, off = [], 0
     for p in params:
         k = p.grad.numel()
         views.append(flat[off:off + k].view_as(p.grad))
         off += k
     torch._foreach_copy_(views, [p.grad for p in params])
-    dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+    dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
     if average:
         flat /= w
     torch._foreach_copy_([p.grad for p in params], views)

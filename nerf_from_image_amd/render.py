@@ -5,37 +5,64 @@
     nfi_render.configure(args, dataset_config)          # once, where run.py builds them
     render = nfi_render.render                           # replaces run.py's own def
 
-Two execution paths, both HIP through the C ABI:
-  * fused   - one persistent launch for the whole pipeline (no gradient, no per-sample extras);
-  * staged  - one launch per stage through ``nerf_utils`` and the ``sampler`` closure, used when a
-              gradient or normals/semantics/coords maps are requested.
+Three execution paths, all HIP through the C ABI:
+  * fused          - one persistent launch for the whole pipeline (no gradient, no per-sample extras);
+  * fused + stash  - the SAME launch when a gradient is needed (training / inversion, fine sampling on): the kernel also
+                     writes a per-sample stash (depths, sigma, rgb of the 2S samples of every ray, ray-major), and the
+                     whole render is ONE autograd node whose backward is compositing backward on the stash -> one field
+                     backward launch over the 2S points of every ray (+ its binned plane-gradient scatter) -> ray /
+                     camera backward.  Replaces the ~20 launches of the staged graph;
+  * staged         - one launch per stage through ``nerf_utils`` and the ``sampler`` closure: normals / semantics /
+                     coords maps, the view-direction decoder with a gradient, or no fine sampling with a gradient.
 Randomness follows the reference, in its order: ``torch.rand`` of [B,H,W,S] for the stratified
 jitter (nerf_utils.py:115) BEFORE the model is called (its synthesis network draws noise of its own
 in training), then ``torch.rand`` of [B*H*W,S] for the inverse-CDF draws (nerf_utils.py:202), even
 in eval (``randomize`` defaults to True and no caller overrides it).
+
+Options (``configure(..., **options)`` / ``make_render(..., **options)``; per bound render function, nothing
+process-wide - the reference calls render from one thread per GPU):
+  fast_termination  0 = exact (default).  eps in (0,1): opt-in, NOT parity - transmittance threshold below which the
+                    fused inference kernel stops marching a ray (ops.render_fwd(fast_termination=...), DESIGN.md);
+  strict_near_far   True (default, the reference's behaviour): the staged path raises when no ray of the batch meets the
+                    scene cube (lib/nerf_utils.py:258 fails on min() of an empty selection) - one host synchronisation
+                    per call; a training loop that cannot see such a batch may clear it;
+  row_window        None, or (row_offset, rows): render only these image rows (fused inference path; one image sharded
+                    over the ranks of a node, parallel.shard_rows); the outputs then have `rows` rows.
 """
+import types
+
 import torch
 
 from . import nerf_utils, ops
+from .autograd import differentiable, zeros_like_or
+from .field_backward import field_query_bwd
 
 args = None
 dataset_config = None
-# opt-in, NOT parity: transmittance threshold below which the fused inference kernel stops marching a ray
-# (0 = exact path; see ops.render_fwd(fast_termination=...) and DESIGN.md)
-FAST_TERMINATION = 0.0
+_DEFAULTS = dict(fast_termination=0.0, strict_near_far=True, row_window=None)
+options = types.SimpleNamespace(**_DEFAULTS)
 
 
-def configure(new_args, new_dataset_config):
+def _options(kw):
+    unknown = set(kw) - set(_DEFAULTS)
+    if unknown:
+        raise TypeError('unknown render option(s) %s (known: %s)' % (sorted(unknown), sorted(_DEFAULTS)))
+    return types.SimpleNamespace(**dict(_DEFAULTS, **kw))
+
+
+def configure(new_args, new_dataset_config, **new_options):
     """Installs the globals run.py::render reads: args.{use_viewdir,use_sdf,attention_values,
-    fine_sampling} and dataset_config['scene_range'|'white_background']."""
-    global args, dataset_config
-    args, dataset_config = new_args, new_dataset_config
+    fine_sampling} and dataset_config['scene_range'|'white_background'], plus the options above."""
+    global args, dataset_config, options
+    args, dataset_config, options = new_args, new_dataset_config, _options(new_options)
 
 
-def make_render(new_args, new_dataset_config):
-    """A render function bound to its own args/dataset_config (for multi-config processes)."""
+def make_render(new_args, new_dataset_config, **new_options):
+    """A render function bound to its own args / dataset_config / options (multi-config processes, one per thread)."""
+    opts = _options(new_options)
+
     def bound(*a, **k):
-        return _render(new_args, new_dataset_config, *a, **k)
+        return _render(new_args, new_dataset_config, opts, *a, **k)
     return bound
 
 
@@ -44,8 +71,8 @@ def render(target_model, height, width, tform_cam2world, focal_length, center, b
            compute_coords=False, extra_model_outputs=[], extra_model_inputs={}, force_no_cam_grad=False):
     if args is None or dataset_config is None:
         raise RuntimeError('nerf_from_image_amd.render.configure(args, dataset_config) has not been called')
-    return _render(args, dataset_config, target_model, height, width, tform_cam2world, focal_length, center, bbox,
-                   model_input, depth_samples_per_ray, randomize, compute_normals, compute_semantics, compute_coords,
+    return _render(args, dataset_config, options, target_model, height, width, tform_cam2world, focal_length, center,
+                   bbox, model_input, depth_samples_per_ray, randomize, compute_normals, compute_semantics, compute_coords,
                    extra_model_outputs, extra_model_inputs, force_no_cam_grad)
 
 
@@ -53,7 +80,52 @@ def _needs_grad(*tensors):
     return torch.is_grad_enabled() and any(t is not None and torch.is_tensor(t) and t.requires_grad for t in tensors)
 
 
-def _render(cfg, dcfg, target_model, height, width, tform_cam2world, focal_length, center, bbox, model_input,
+def _render_with_stash(fused, height, width, S, cam, focal, bbox, center, noise_c, noise_f, white, cam_grad):
+    """The fused render as ONE autograd node (see the module docstring).  Gradients follow the reference's graph:
+    rgb_map / mask -> sigma, rgb of every sample and (through dists * ||rd||) the ray directions; depth_map and the
+    depth samples carry none; the field -> planes, decoder, colour table, beta, alpha and - unless the camera is
+    detached - the query points -> rays -> tform_cam2world / focal_length."""
+    texels, image = fused.texels, fused.decoder_image
+    A, use_sdf, scene_range = fused.n_attention, fused.use_sdf, fused.scene_range
+    w1, b1, w2, b2 = fused.decoder_params[:4]
+    B = cam.shape[0]
+    keep = {}
+
+    def fwd(a_cam, a_focal, pl, a_w1, a_b1, a_w2, a_b2, att, be, al):
+        out = ops.render_fwd(a_cam, a_focal, height, width, S, texels, image, scene_range, A, att, use_sdf, be, al,
+                             bbox=bbox, center=center, noise_coarse=noise_c, noise_fine=noise_f, fine_sampling=True,
+                             white_background=bool(white), skip_missed_rays=True, stash=True)
+        keep.update({k: out[k] for k in ('stash_t', 'stash_sigma', 'stash_rgb', 'ray_origins', 'ray_directions')})
+        return out['rgb'], out['depth'], out['mask']
+
+    def bwd(inputs, out_meta, grads, needs):
+        a_cam, a_focal, pl, a_w1, a_b1, a_w2, a_b2, att, be, al = inputs
+        g_rgb = zeros_like_or(grads[0], out_meta[0])
+        g_mask = None if grads[2] is None else grads[2].contiguous()
+        st_t, rd = keep['stash_t'], keep['ray_directions']
+        cb = ops.composite_bwd_stash(rd, st_t, keep['stash_sigma'], keep['stash_rgb'], g_rgb, g_mask,
+                                     white_background=bool(white), want_rd=cam_grad)
+        pts = ops.points_on_rays(keep['ray_origins'], rd, st_t).view(B, -1, 3)
+        g = field_query_bwd(pts, texels, image, a_w1, a_w2, scene_range, A, att, use_sdf, be, al,
+                            cb['g_sigma'].view(B, -1), cb['g_rgb'].view(B, -1, 3), want_points=cam_grad)
+        g_cam = g_focal = None
+        if cam_grad:
+            g_ro, g_rd = ops.points_bwd(g['g_points'].view(*st_t.shape, 3), st_t)
+            g_rd = g_rd + cb['g_ray_directions']
+            g_cam, g_focal = ops.raygen_bwd(height, width, a_focal, a_cam, bbox, center, True, g_ro, g_rd)
+        g_planes = ops.texel_grad_to_planes(g['g_texels']) if needs[2] else None
+        return (g_cam, g_focal, g_planes, g['g_w1'], g['g_b1'], g['g_w2'], g['g_b2'], g.get('g_attention_values'),
+                g.get('g_beta'), g.get('g_alpha'))
+
+    cam_in = cam if cam_grad else cam.detach()
+    focal_in = focal if (cam_grad or focal is None) else focal.detach()
+    res = differentiable('render', fwd, cam_in, focal_in, fused.planes, w1, b1, w2, b2,
+                         fused.attention_values if A > 0 else None, fused.beta if use_sdf else None,
+                         fused.alpha if use_sdf else None, bwd=bwd, non_differentiable_outputs=(1,))
+    return res
+
+
+def _render(cfg, dcfg, opts, target_model, height, width, tform_cam2world, focal_length, center, bbox, model_input,
             depth_samples_per_ray, randomize=True, compute_normals=False, compute_semantics=False,
             compute_coords=False, extra_model_outputs=[], extra_model_inputs={}, force_no_cam_grad=False):
     S = depth_samples_per_ray
@@ -71,6 +143,7 @@ def _render(cfg, dcfg, target_model, height, width, tform_cam2world, focal_lengt
     dev = tform_cam2world.device
     plain = not (compute_normals or compute_semantics or compute_coords)
     cam_grad = (not force_no_cam_grad) and _needs_grad(tform_cam2world, focal_length, bbox, center)
+    rows = height if opts.row_window is None else int(opts.row_window[1])
 
     # Order of the random draws as in the reference: the stratified jitter (rand_like inside
     # compute_query_points_from_rays, run.py:203-209) comes BEFORE target_model is called (whose synthesis network
@@ -81,34 +154,51 @@ def _render(cfg, dcfg, target_model, height, width, tform_cam2world, focal_lengt
         # run.py:192-219: the model needs the normalised ray directions before it can build the sampler
         rays = nerf_utils.get_ray_bundle_normalized(height, width, focal_length, tform_cam2world, bbox, center)
         viewdirs = (rays[1].detach() if force_no_cam_grad else rays[1]).unsqueeze(-2)
-    noise_c = torch.rand((B, height, width, S), dtype=torch.float32, device=dev) if randomize else None
+    noise_c = torch.rand((B, rows, width, S), dtype=torch.float32, device=dev) if randomize else None
 
     model_outputs = target_model(viewdirs, model_input, ['sampler'] + extra_model_outputs, extra_model_inputs)
     sampler = model_outputs['sampler']
     del model_outputs['sampler']
     fused = getattr(sampler, 'fused', None)
+    ray_features = getattr(fused, 'ray_features', None)
+
+    def inverse_cdf_draws():
+        if not cfg.fine_sampling:
+            return None
+        if randomize:
+            return torch.rand([B * rows * width, S], dtype=torch.float32, device=dev)
+        return None            # the kernels take linspace(0, 1, S) themselves (nerf_utils.py:196-200)
 
     if fused is not None and plain and not cam_grad and not fused.requires_grad and S <= 128:
         # ---------------- fused inference path (the kernel generates the rays itself) ----------------
-        noise_f = None
-        if cfg.fine_sampling and randomize:
-            noise_f = torch.rand([B * height * width, S], dtype=torch.float32, device=dev)
+        window = None if opts.row_window is None else (int(opts.row_window[0]), height)
         out = ops.render_fwd(
-            tform_cam2world.detach(), None if focal_length is None else focal_length.detach(), height, width, S,
+            tform_cam2world.detach(), None if focal_length is None else focal_length.detach(), rows, width, S,
             fused.texels, fused.decoder_image, scene_range, fused.n_attention,
             None if fused.attention_values is None else fused.attention_values.detach(), fused.use_sdf,
             None if fused.beta is None else fused.beta.detach(), None if fused.alpha is None else fused.alpha.detach(),
             bbox=None if bbox is None else bbox.detach(), center=None if center is None else center.detach(),
-            noise_coarse=noise_c, noise_fine=noise_f, fine_sampling=bool(cfg.fine_sampling),
-            white_background=bool(white), skip_missed_rays=True, ray_features=getattr(fused, 'ray_features', None),
-            fast_termination=FAST_TERMINATION)
+            noise_coarse=noise_c, noise_fine=inverse_cdf_draws(), fine_sampling=bool(cfg.fine_sampling),
+            white_background=bool(white), skip_missed_rays=True, ray_features=ray_features,
+            fast_termination=opts.fast_termination, row_window=window)
         return out['rgb'], out['depth'], out['mask'], None, None, model_outputs
+    if opts.row_window is not None:
+        raise NotImplementedError('row_window is an option of the fused inference path (no gradient, no extra maps)')
 
-    # ---------------- staged path (differentiable / extra maps) ----------------
+    if fused is not None and plain and cfg.fine_sampling and S <= 128 and ray_features is None:
+        # ---------------- fused render + stash as one differentiable node ----------------
+        det = (lambda t: None if t is None else t.detach())
+        rgb_map, depth_map, mask = _render_with_stash(
+            fused, height, width, S, tform_cam2world, focal_length, det(bbox), det(center), noise_c, inverse_cdf_draws(),
+            white, cam_grad)
+        return rgb_map, depth_map, mask, None, None, model_outputs
+
+    # ---------------- staged path (extra maps, view-direction decoder, single pass with a gradient) ----------------
     ray_origins, ray_directions = rays if rays is not None else nerf_utils.get_ray_bundle_normalized(
         height, width, focal_length, tform_cam2world, bbox, center)
     with torch.no_grad():
-        near, far = nerf_utils.compute_near_far_planes(ray_origins.detach(), ray_directions.detach(), scene_range)
+        near, far = nerf_utils.compute_near_far_planes(ray_origins.detach(), ray_directions.detach(), scene_range,
+                                                       strict=opts.strict_near_far)
     query_points, depth_values = nerf_utils.compute_query_points_from_rays(
         ray_origins, ray_directions, near, far, S, randomize=randomize, noise=noise_c)
     if force_no_cam_grad:

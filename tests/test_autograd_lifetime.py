@@ -85,3 +85,45 @@ def test_device_memory_is_flat_over_steps(gpu_device):
         torch.cuda.synchronize()
         live.append(torch.cuda.memory_allocated(gpu_device))
     assert live[-1] == live[2], live
+
+
+def test_double_backward_through_a_hip_node_raises():
+    """The HIP nodes are first-order only: create_graph=True through one must fail loudly, not return a constant."""
+    import pytest
+    from nerf_from_image_amd.autograd import differentiable
+    x = torch.randn(4, requires_grad=True)
+    y = differentiable('square', lambda t: t * t, x, bwd=lambda inputs, meta, grads, needs: (2 * inputs[0] * grads[0],))
+    with pytest.raises(RuntimeError, match='first-order only'):
+        torch.autograd.grad(y.sum(), x, create_graph=True)
+    g, = torch.autograd.grad(y.sum(), x)
+    assert torch.allclose(g, 2 * x.detach()) and not g.requires_grad
+
+
+def test_path_length_request_runs_the_unfused_block_tail():
+    """generator.hip_forward / wrapped_forward keep the fused hand-off node (first-order only) out of a forward that
+    asks for the second-order 'path_length' output."""
+    from nerf_from_image_amd import handoff
+
+    class Block(torch.nn.Module):
+        conv1 = torgb = None
+        in_channels = 0
+
+        def forward(self, *a):
+            return 'original'
+
+    class Net(torch.nn.Module):
+        img_resolution = 8
+
+        def __init__(self):
+            super().__init__()
+            self.b8 = Block()
+    net = Net()
+    blk = handoff.last_block(net)
+    blk._nfi_original_forward = blk.forward
+    blk.forward = lambda *a: 'fused'
+    assert net.b8.forward() == 'fused'
+    with handoff.unfused(net):
+        assert net.b8.forward() == 'original'
+    assert net.b8.forward() == 'fused'
+    with handoff.unfused(torch.nn.Linear(2, 2)):        # not a StyleGAN2-style network: no-op
+        pass

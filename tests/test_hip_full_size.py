@@ -288,3 +288,42 @@ def test_mlp_precision_modes(gpu_device):
                             noise_coarse=d2['noise_c'], noise_fine=d2['noise_f'])
         for k in ('rgb', 'mask'):
             assert err(r2[k], o2[k])['max'] <= 1e-4, (scale, k, err(r2[k], o2[k]))
+
+
+def test_training_stash_and_row_windows(gpu_device):
+    """(1) nfi_render_fwd's training stash (what the one-node differentiable render keeps for its backward) holds the
+    per-sample state of the debug taps, ray-major with coarse | fine halves, zeros for rays the kernel skipped, and
+    asking for it does not change a pixel.  (2) Rendering an image in row windows (one image sharded over the ranks of
+    a node, nfi_render_args.row_offset / full_height) gives bit-identical pixels to the full render."""
+    d = make_inputs(2, gpu_device, radius=2.0, seed=11)            # chairs-like: a good part of the rays miss the cube
+    texels = ops.planes_to_texels(d['planes'])
+    image = ops.decoder_pack(d['w1'], d['b1'], d['w2'], d['b2'], A)
+
+    def run(**kw):
+        return ops.render_fwd(d['cam'], d['focal'], R, R, S, texels, image, 0.55, A, d['att'], True, d['beta'], d['alpha'],
+                              noise_coarse=d['noise_c'], noise_fine=d['noise_f'], white_background=True, **kw)
+    plain = run()
+    st = run(stash=True)
+    taps = run(taps=('t_coarse', 'sigma_coarse', 'rgb_coarse', 't_fine', 'sigma_fine', 'rgb_fine', 'hit', 'ray_directions'))
+    for k in ('rgb', 'depth', 'mask'):
+        assert torch.equal(plain[k], st[k]), k
+    marched = (taps['hit'] & 2) != 0                                 # the kernel's own skip test (inflated cube)
+    assert 0.2 < marched.float().mean() < 0.9
+    for name, a, b in (('t', 't_coarse', 't_fine'), ('sigma', 'sigma_coarse', 'sigma_fine'), ('rgb', 'rgb_coarse', 'rgb_fine')):
+        both = torch.cat((taps[a], taps[b]), dim=3)
+        got = st['stash_' + name]
+        assert got.shape == both.shape
+        assert torch.equal(got[marched], both[marched]), name
+        assert float(got[~marched].abs().max()) == 0.0, name
+    assert torch.equal(st['ray_directions'], taps['ray_directions'])
+
+    # row windows: 3 uneven bands of the 128 rows
+    parts = []
+    for r0, r1 in ((0, 40), (40, 72), (72, 128)):
+        w = ops.render_fwd(d['cam'], d['focal'], r1 - r0, R, S, texels, image, 0.55, A, d['att'], True, d['beta'], d['alpha'],
+                           noise_coarse=d['noise_c'][:, r0:r1].contiguous(),
+                           noise_fine=d['noise_f'].view(2, R, R, S)[:, r0:r1].reshape(-1, S).contiguous(),
+                           white_background=True, row_window=(r0, R))
+        parts.append(w)
+    for k in ('rgb', 'depth', 'mask'):
+        assert torch.equal(torch.cat([p[k] for p in parts], dim=1), plain[k]), k

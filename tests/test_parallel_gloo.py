@@ -151,6 +151,104 @@ def test_gradient_buckets_reduce_scatter():
     _run_two(_bucket_worker, 'reduce_scatter')
 
 
+def _accumulate_worker(rank, world, port, q):
+    """Two backward() calls per optimiser step, as run.py:1044 / 1110-1139 do: all but the last under no_sync(); a
+    delay between them gives an (erroneously) early collective time to finish - the failure mode of round 2's code."""
+    import time
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        torch.manual_seed(0)
+        net = torch.nn.Sequential(torch.nn.Linear(7, 5), torch.nn.Tanh(), torch.nn.Linear(5, 3))
+        gb = parallel.GradientBuckets(list(net.parameters()), bucket_bytes=64)
+        x = torch.randn(6, 7)
+        xs = parallel.shard_batch(x)
+        ref = [p.detach().clone().requires_grad_() for p in net.parameters()]
+
+        def losses(ps, inp):
+            h = torch.tanh(inp @ ps[0].t() + ps[1])
+            o = h @ ps[2].t() + ps[3]
+            return (o ** 2).sum(), o.abs().sum()
+        for step in range(2):
+            gb.zero_grad()
+            la, lb = losses(list(net.parameters()), xs)
+            with gb.no_sync():
+                la.backward(retain_graph=True)
+            assert gb.launched_in_backward == 0 and not any(gb._launched)
+            time.sleep(0.3 if rank == 0 else 0.0)
+            lb.backward()
+            assert gb.launched_in_backward >= 1
+            gb.finish()
+            for r in ref:
+                r.grad = None
+            ra, rb = losses(ref, x)
+            (ra + rb).backward()
+            for p, r in zip(net.parameters(), ref):
+                assert torch.allclose(p.grad, r.grad, atol=1e-5), (step, (p.grad - r.grad).abs().max())
+        # misuse: a second synchronising backward in the same step must raise, not corrupt
+        gb.zero_grad()
+        la, lb = losses(list(net.parameters()), xs)
+        la.backward(retain_graph=True)
+        try:
+            lb.backward()
+            raised = False
+        except RuntimeError as e:
+            raised = 'no_sync' in str(e)
+        gb.finish()
+        assert raised
+        # ... and so must no_sync() after collectives went out
+        try:
+            with gb.no_sync():
+                pass
+            raised = False
+        except RuntimeError:
+            raised = True
+        assert raised
+        # sub-group: padding / averaging follow the GROUP's size, not the default group's
+        # (new_group is collective: both groups are built on every rank)
+        g0, g1 = dist.new_group([0]), dist.new_group([1])
+        mine = g0 if rank == 0 else g1
+        w = torch.nn.Parameter(torch.full((3,), float(rank + 1)))
+        gs = parallel.GradientBuckets([w], mode='reduce_scatter', average=True, group=mine)
+        assert gs.world_size == 1 and gs.buckets[0]['flat'].numel() == 3
+        (w * w).sum().backward()
+        gs.finish()
+        assert torch.allclose(w.grad, 2 * w.detach())
+        # one image over both ranks: row bands (whole 8-row strips) rendered locally, gathered to the full image
+        H, W = 40, 6
+        img = torch.arange(2 * H * W * 3, dtype=torch.float32).view(2, H, W, 3)
+        r0, r1 = parallel.shard_rows(H)
+        assert (r0, r1) == ((0, 16) if rank == 0 else (16, 40)) and r0 % 8 == 0
+        seen = []
+
+        def fake_rows(a, b):
+            seen.append((a, b))
+            return img[:, a:b], img[:, a:b, :, 0]
+        full, first = parallel.render_image_rows(fake_rows, H)
+        assert seen == [(r0, r1)] and torch.equal(full, img) and torch.equal(first, img[..., 0])
+        # fewer strips than ranks: one rank gets the strip, the other an empty band
+        assert parallel.shard_rows(8, rank=0, world_size=2) == (0, 0) and parallel.shard_rows(8, rank=1, world_size=2) == (0, 8)
+        # one-shot form keeps a staging buffer per gradient size (G and D steps alternate)
+        a, b = torch.nn.Parameter(torch.ones(5)), torch.nn.Parameter(torch.ones(9))
+        for _ in range(2):
+            for prm in (a, b):
+                prm.grad = torch.full_like(prm, float(rank + 1))
+                parallel.allreduce_gradients([prm])
+                assert torch.equal(prm.grad, torch.full_like(prm, 3.0))
+        assert {k[1] for k in parallel._FLAT_CACHE} >= {5, 9}
+        q.put((rank, 'ok'))
+    except Exception:  # pragma: no cover
+        import traceback
+        q.put((rank, traceback.format_exc()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_gradient_buckets_two_backwards_per_step():
+    _run_two(_accumulate_worker)
+
+
 def test_gradient_buckets_single_process():
     w = torch.nn.Parameter(torch.randn(4, 3))
     b = torch.nn.Parameter(torch.randn(3))

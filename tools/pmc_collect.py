@@ -113,6 +113,14 @@ def main():
             res['wait_frac_of_wave_time'] = (g('SQ_WAIT_ANY') or 0.0) / g('SQ_WAVE_CYCLES')
         if res.get('elapsed_cycles'):
             res['issue_frac'] = issue / (1024.0 * res['elapsed_cycles'])
+        if g('SQ_ACTIVE_INST_VALU'):
+            valu = 4.0 * g('SQ_ACTIVE_INST_VALU')
+            if units:
+                res['valu_cycles_per_marched_ray' if a.marched_from_bench else 'valu_cycles_per_unit'] = valu / units
+            if res.get('elapsed_cycles'):
+                res['valu_frac'] = valu / (1024.0 * res['elapsed_cycles'])
+        if g('SQ_WAVE_CYCLES') and res.get('elapsed_cycles'):
+            res['waves_per_simd'] = 4.0 * g('SQ_WAVE_CYCLES') / (1024.0 * res['elapsed_cycles'])
     if g('TCC_HIT_sum') is not None and g('TCC_MISS_sum') is not None:
         res['l2_request_bytes_per_launch'] = (g('TCC_HIT_sum') + g('TCC_MISS_sum')) * 128.0
         res['l2_hit_rate'] = g('TCC_HIT_sum') / max(g('TCC_HIT_sum') + g('TCC_MISS_sum'), 1.0)

@@ -103,7 +103,6 @@ def run(dev, steps, warmup, batch=4, res=128, samples=64, bucket_mb=32, reduce_m
     import types
     import torch.distributed as dist
     import nerf_from_image_amd.generator as nfi_gen
-    import nerf_from_image_amd.nerf_utils as nfi_nu
     import nerf_from_image_amd.render as nfi_render
     from nerf_from_image_amd.parallel import GradientBuckets
     rank = dist.get_rank() if use_dist else 0
@@ -111,7 +110,6 @@ def run(dev, steps, warmup, batch=4, res=128, samples=64, bucket_mb=32, reduce_m
     scene_range = 2.0
     model = PlaneProducer(scene_range).to(dev).train()
     nfi_gen.attach(model)
-    nfi_nu.STRICT_NEAR_FAR = False                            # no host synchronisation inside the step
     g = torch.Generator().manual_seed(1000 + rank)            # every rank its own images
     v = torch.randn(batch, 3, generator=g)
     eye = 3.0 * v / v.norm(dim=-1, keepdim=True)
@@ -125,7 +123,8 @@ def run(dev, steps, warmup, batch=4, res=128, samples=64, bucket_mb=32, reduce_m
     target_rgb = (torch.rand(batch, res, res, 3, generator=g) * 2 - 1).to(dev)
     target_mask = (torch.rand(batch, res, res, generator=g) > 0.5).float().to(dev)
     cfg = types.SimpleNamespace(use_viewdir=False, use_sdf=True, attention_values=10, fine_sampling=True)
-    render = nfi_render.make_render(cfg, {'scene_range': scene_range, 'white_background': False})
+    render = nfi_render.make_render(cfg, {'scene_range': scene_range, 'white_background': False},
+                                    strict_near_far=False)   # no host synchronisation inside the step
     params = [p for p in model.parameters() if p.requires_grad]
     n_params = sum(p.numel() for p in params)
     buckets = GradientBuckets(params, bucket_bytes=bucket_mb << 20, average=True, mode=reduce_mode, overlap=overlap)
