@@ -463,6 +463,30 @@ size_t nfi_render_workspace_bytes(int64_t n_rays);
 int nfi_render_fwd(const nfi_render_args* a, nfi_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Camera pose from a canonical-coordinate map: replaces the .cpu().numpy() + OpenCV solvePnPGeneric round trip of
+ * lib/pose_estimation.py:30-131 (compute_pose_pnp) that run.py:1709-1740 (estimate_poses_batch) makes for every
+ * inversion batch.  Per image and focal proposal: Hartley-normalised DLT start, polar decomposition, Levenberg-Marquardt
+ * on the reprojection error; per image the proposal with the smallest RMS reprojection error (OpenCV's definition,
+ * sqrt(sum |r|^2 / 2N)) among the solutions with t_z > 0; images without a solution (or with fewer than 6 foreground
+ * pixels; the reference: fewer than 4) get the reference's dummy pose (t = (0,0,-10), focal 1, error 10).
+ * PARITY UNPINNED: OpenCV is not available offline, no golden vectors exist (see csrc/nfi_pnp.inc).
+ * ------------------------------------------------------------------------------------------ */
+typedef struct nfi_pnp_args {
+  int n_images; int height; int width;
+  const float* coords;          /* [B,H,W,3] canonical object coordinates per pixel */
+  const float* mask;            /* [B,H,W]: a pixel is foreground where mask > mask_threshold (run.py:1710: 0.9) */
+  float mask_threshold;
+  int n_focal; const float* focal_proposals;   /* [n_focal] device array (pose_estimation.py:134-143) */
+  int refine_iterations;        /* Levenberg-Marquardt passes (0: linear start only = refine=False) */
+  void* workspace; size_t workspace_bytes;     /* nfi_pnp_workspace_bytes(n_images, n_focal), 8-byte aligned */
+  float* world2cam;             /* [B,4,4] out: flip @ [R|t], flip = diag(1,-1,-1,1) (pose_estimation.py:119-127) */
+  float* focal;                 /* [B] out: the chosen proposal */
+  float* error;                 /* [B] out: its RMS reprojection error */
+} nfi_pnp_args;
+size_t nfi_pnp_workspace_bytes(int n_images, int n_focal);
+int nfi_pose_pnp(const nfi_pnp_args* a, nfi_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
  * Plane-producer hand-off: the tail of the LAST StyleGAN2 synthesis block
  * (models/stylegan.py:383-435: img = upsample2d(img_prev); y = torgb(x, w); img += y) fused into one kernel that
  * writes the result as texels in the INTERLEAVED layout [B,R,R,3,32] (= a channels-last [B,96,R,R] tensor), so

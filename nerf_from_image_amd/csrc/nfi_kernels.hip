@@ -1174,6 +1174,7 @@ extern "C" int nfi_composite_fwd(const nfi_composite_args* a, nfi_stream_t strea
 #include "nfi_regulariser.inc"
 #include "nfi_neighbours.inc"
 #include "nfi_handoff.inc"
+#include "nfi_pnp.inc"
 
 // ------------------------------------------------------------------------------------------------
 // fused forward render
