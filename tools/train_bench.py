@@ -7,8 +7,9 @@ camera, scene_range 2.0, black background, image + alpha loss as with --supervis
 decoder / beta / alpha, all-reduce of ONE generator-sized fp32 gradient set (32.2 M parameters = 128.7 MB, SURVEY.md
 8(e)) through nerf_from_image_amd.parallel.GradientBuckets (buckets launched asynchronously while backward is still
 running), Adam step.  The discriminator, the data pipeline and the StyleGAN2 synthesis network are outside the hot
-path: the plane producer here is a small latent-modulated basis whose parameter count is padded to the
-reference generator's, so that the collective has the real size.
+path: the plane producer here is a small latent-modulated basis padded with tensors of the reference
+generator's own parameter list (tools/generator_param_sizes.json: 129 tensors, 1 ... 2 359 296 elements,
+models/stylegan.py:438-490), so that the collective has the real size AND the real bucket layout.
 
 Used by `bench.py --mode train` (and runnable alone under torch.distributed.run)."""
 import math
@@ -53,20 +54,34 @@ class _Mapping(nn.Module):
         return self.lin(z).unsqueeze(1).expand(-1, 15, -1).contiguous()
 
 
-class _Synthesis(nn.Module):
-    """ws[:, :14] -> [B,96,R,R]: K smooth basis images modulated by the latents (+ ballast parameters that pad the
-    replica to the reference generator's size; they receive zero gradients and ride along in the all-reduce)."""
+def reference_parameter_shapes():
+    """Shapes of the reference Generator's parameters in registration order (tools/generator_param_sizes.json, written
+    from the live class by tools/make_generator_param_sizes.py: 129 tensors, 32.16 M elements)."""
+    import json
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'generator_param_sizes.json')
+    return [tuple(p['shape']) for p in json.load(open(path))['parameters']]
 
-    def __init__(self, res, k, ballast):
+
+class _Synthesis(nn.Module):
+    """ws[:, :14] -> [B,96,R,R]: K smooth basis images modulated by the latents, plus padding parameters with the
+    reference generator's OWN tensor list (one tensor per reference parameter, same sizes, same order), so that the
+    gradient buckets - their number, sizes and the per-tensor gradient writes - are the reference's; they receive zero
+    gradients and ride along in the all-reduce."""
+
+    def __init__(self, res, k, pad_shapes):
         super().__init__()
-        low = torch.randn(k, 96, 16, 16)
-        self.basis = nn.Parameter(torch.nn.functional.interpolate(low, size=(res, res), mode='bilinear', align_corners=True))
-        self.proj = nn.Linear(512, k)
-        self.ballast = nn.Parameter(torch.zeros(max(ballast, 1)))
+        self.res = res
+        self.basis = nn.Parameter(torch.randn(k, 96, 16, 16))          # low resolution: the stand-in's own parameters stay
+        self.proj = nn.Linear(512, k)                                  # small next to the reference's tensor list
+        self.padding = nn.ParameterList([nn.Parameter(torch.zeros(s if len(s) else (1,))) for s in pad_shapes])
 
     def forward(self, ws, **kw):
         coef = self.proj(ws.mean(dim=1))
-        return basis_mix(coef, self.basis) + 0.0 * self.ballast[0]
+        basis = torch.nn.functional.interpolate(self.basis, size=(self.res, self.res), mode='bilinear', align_corners=True)
+        out = basis_mix(coef, basis)
+        if len(self.padding):
+            out = out + 0.0 * torch.stack([p.reshape(-1)[0] for p in self.padding]).sum()
+        return out
 
 
 class _Texture(nn.Module):
@@ -92,9 +107,17 @@ class PlaneProducer(nn.Module):
         self.texture_mapper = _Texture(10)
         self.beta = nn.Parameter(torch.tensor([0.1]))
         self.alpha = nn.Parameter(torch.tensor([0.05]))
-        self.synthesis_network = _Synthesis(plane_res, k, 0)
+        self.synthesis_network = _Synthesis(plane_res, k, [])
+        # pad with the reference's tensors, largest-first skipping as many elements as the stand-in's own modules hold
         have = sum(p.numel() for p in self.parameters())
-        self.synthesis_network = _Synthesis(plane_res, k, total_params - have + 1)
+        shapes = reference_parameter_shapes()
+        skip = []
+        for i in sorted(range(len(shapes)), key=lambda j: -int(torch.tensor(shapes[j] or (1,)).prod())):
+            n = int(torch.tensor(shapes[i] or (1,)).prod())
+            if n <= have:
+                skip.append(i)
+                have -= n
+        self.synthesis_network = _Synthesis(plane_res, k, [s for i, s in enumerate(shapes) if i not in set(skip)])
 
 
 def run(dev, steps, warmup, batch=4, res=128, samples=64, bucket_mb=32, reduce_mode='all_reduce', overlap=True,
