@@ -14,6 +14,20 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+// build-time experiment knobs of the fused render kernels (product values below; tools/probes/render_variants.py)
+#ifndef NFI_PLANEWISE
+#define NFI_PLANEWISE 0          // 1: gather + blend one plane at a time (32 instead of 96 texel registers in flight)
+#endif
+#ifndef NFI_TILE_PAIR
+#define NFI_TILE_PAIR 1          // 1: two field tiles go through the decoder MLP together; 0: one at a time
+#endif
+#ifndef NFI_SCALAR_RAY
+#define NFI_SCALAR_RAY 0         // 1: the marched ray's origin / direction / near / far through v_readfirstlane into SGPRs
+#endif
+#ifndef NFI_RENDER_OCC
+#define NFI_RENDER_OCC 2         // workgroups of 4 waves per CU the render kernels are compiled and launched for
+#endif
+
 namespace nfi {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -442,6 +456,38 @@ __device__ __forceinline__ void tile_bilinear(const TileTex<TEX>& T, float fx, f
   }
 }
 
+// The same gather + blend one plane at a time (identical arithmetic and order: plane 0, 1, 2; corners 00, 10, 01, 11).
+template <int TEX>
+__device__ __forceinline__ void tile_gather_planewise(const FieldParams& P, int g, uint32_t xi, float fx, float fy, float fz,
+                                                      float (&feat)[8]) {
+  const uint32_t x0 = xi & 1023u, y0 = (xi >> 10) & 1023u, z0 = (xi >> 20) & 1023u;
+#pragma unroll
+  for (int s = 0; s < 8; ++s) feat[s] = 0.0f;
+#pragma unroll
+  for (int pl = 0; pl < 3; ++pl) {
+    const uint32_t a0 = (pl == 2) ? y0 : x0, b0 = (pl == 0) ? y0 : z0;
+    const uint32_t voff = (uint32_t)pl * P.plane_bytes + __umul24(b0 * (uint32_t)P.res + a0, P.pix_bytes) + (uint32_t)g * 16u;
+    float tv[4][8];
+    load_texel8<TEX>(P, voff, 0, 0, tv[0]);
+    load_texel8<TEX>(P, voff, P.pix_bytes, 0, tv[1]);
+    load_texel8<TEX>(P, voff, P.row_bytes, 0, tv[2]);
+    load_texel8<TEX>(P, voff, P.row_pix_bytes, 0, tv[3]);
+    const float fa = (pl == 2) ? fy : fx, fb = (pl == 0) ? fy : fz;
+    const float ga = 1.0f - fa, gb = 1.0f - fb;
+    const float w00 = ga * gb, w10 = fa * gb, w01 = ga * fb, w11 = fa * fb;
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+      float acc = feat[s];
+      acc = fmaf(w00, tv[0][s], acc);
+      acc = fmaf(w10, tv[1][s], acc);
+      acc = fmaf(w01, tv[2][s], acc);
+      acc = fmaf(w11, tv[3][s], acc);
+      feat[s] = acc;
+    }
+    __builtin_amdgcn_sched_barrier(0);       // keep the next plane's loads from being hoisted above this blend
+  }
+}
+
 // density / colour epilogue on the decoder outputs o (lane (g,j): rows 4g..4g+3 of point j; row 0 =
 // distance/density, rows 1.. = colour logits pre-scaled by log2e)
 template <bool ATT, int N>
@@ -809,10 +855,16 @@ __device__ __forceinline__ SampleOut field_wave(const FieldParams& P, float scen
     const float cfx = __shfl(fx, srcL, 64), cfy = __shfl(fy, srcL, 64), cfz = __shfl(fz, srcL, 64);
     const uint32_t cxi = (uint32_t)__shfl(xi, srcL, 64);
     const int fcur = __shfl(flags, srcM, 64);
+    float featL[8];
+#if NFI_PLANEWISE
+    // one plane at a time: 8 loads (32 texel registers) in flight instead of 24 (96) - the register budget of three
+    // waves per SIMD (experiment of round 3)
+    tile_gather_planewise<TEX>(P, lq, cxi, cfx, cfy, cfz, featL);
+#else
     TileTex<TEX> T;
     tile_issue<TEX>(P, lq, cxi, T);
-    float featL[8];
     tile_bilinear<TEX>(T, cfx, cfy, cfz, featL);
+#endif
     // pitch 36 floats: conflict-free for both the 16-byte writes and the 16-byte reads
     __builtin_amdgcn_sched_barrier(0);
     f32x4* wr = reinterpret_cast<f32x4*>(stage + lp * 36 + lq * 4);
@@ -827,6 +879,24 @@ __device__ __forceinline__ SampleOut field_wave(const FieldParams& P, float scen
     __builtin_amdgcn_sched_barrier(0);
     return fcur;
   };
+#if !NFI_TILE_PAIR
+  // one tile at a time (half the accumulator registers of the pair form; experiment knob of round 3)
+  if constexpr (!VD) {
+#pragma unroll 1
+    while (tm != 0) {
+      const int ta = __builtin_ctz(tm);
+      tm &= tm - 1;
+      float feat1[1][8];
+      const int fa = gather_tile(ta, feat1[0]);
+      const float outs1[1] = {(fa & 1) ? 1.0f : 0.0f};
+      float* const sems1[1] = {(sem_base && (fa & 2)) ? sem_base + (size_t)(16 * ta + j) * P.n_attention : nullptr};
+      TileOut to1[1];
+      tile_mlp<ATT, 1, PREC>(P, lane, feat1, outs1, sems1, to1);
+      if (g == ta) { so.sdf = to1[0].sdf; so.sigma = to1[0].sigma; so.r = to1[0].r; so.g = to1[0].g; so.b = to1[0].b; }
+    }
+    return so;
+  }
+#endif
 #pragma unroll 1
   while (tm != 0) {
     unsigned long long c0 = prof ? __builtin_readcyclecounter() : 0;

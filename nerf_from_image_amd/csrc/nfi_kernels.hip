@@ -1410,8 +1410,15 @@ __global__ __launch_bounds__(256, OCC) void render_fwd_kernel(RenderKernelParams
         }
         wave_lds_fence();
       }
+#if NFI_SCALAR_RAY
+      // the ray is the same for all 64 lanes: keep its eight inputs in scalar registers
+      const float ox = uniform_f32(in.ox), oy = uniform_f32(in.oy), oz = uniform_f32(in.oz), dx = uniform_f32(in.dx),
+                  dy = uniform_f32(in.dy), dz = uniform_f32(in.dz);
+      float near = uniform_f32(in.near), far = uniform_f32(in.far);
+#else
       const float ox = in.ox, oy = in.oy, oz = in.oz, dx = in.dx, dy = in.dy, dz = in.dz;
       float near = in.near, far = in.far;
+#endif
       finish_planes((hitb & 1) != 0, fill_near, fill_far, near, far);
       const float dnorm = norm3(dx, dy, dz);
       const size_t rs = (size_t)ray * (size_t)k.tap_stride;      // row of this ray in the per-sample tap / stash arrays
@@ -1541,7 +1548,7 @@ __global__ __launch_bounds__(256, OCC) void render_fwd_kernel(RenderKernelParams
 // owns two coarse and two fine samples (element e = slot*64 + lane), the field is marched 64 points
 // at a time, and the merge ranks all 2S keys against each other.
 template <int TEX, bool ATT, bool TAPS, int PREC, bool VD = false, bool FAST = false>
-__global__ __launch_bounds__(256, 2) void render_fwd_wide_kernel(RenderKernelParams k) {
+__global__ __launch_bounds__(256, NFI_RENDER_OCC) void render_fwd_wide_kernel(RenderKernelParams k) {
   constexpr int kImg = VD ? kVdImageFloats : kLdsImageFloats;
   __shared__ __attribute__((aligned(16))) float lds[kImg];
   __shared__ __attribute__((aligned(16))) float vfs[4][64];
@@ -1886,7 +1893,7 @@ extern "C" int nfi_render_fwd(const nfi_render_args* a, nfi_stream_t stream) {
   // persistent 1-D grid: OCC blocks of 4 waves per CU, never more blocks than rays need
   // 2 blocks (8 waves) per CU: with the whole 256-VGPR budget the field tile keeps more loads and MFMA chains in
   // flight than at 3 blocks/CU (MI355X, 8 x 128^2: 0.96 vs 1.01-1.08 ms; 4 blocks/CU spill: 1.52 ms)
-  const int occ = 2;
+  const int occ = NFI_RENDER_OCC;
   int64_t blocks = (int64_t)256 * occ;
   if (blocks > (n + 3) / 4) blocks = (n + 3) / 4;
   dim3 grid((unsigned)blocks);
@@ -1895,12 +1902,12 @@ extern "C" int nfi_render_fwd(const nfi_render_args* a, nfi_stream_t stream) {
   const bool strict = ((a->tuning >> 3) & 1) != 0;   // exact-fp32 MLP instead of the split-fp16 one
 #define NFI_LAUNCH_RENDER(TEX, ATT)                                                                                   \
   do {                                                                                                                \
-    if (fast) hipLaunchKernelGGL((render_fwd_kernel<TEX, ATT, 2, false, 1, false, false, true>), grid, dim3(256), 0, s, k); \
-    else if (k.prof) hipLaunchKernelGGL((render_fwd_kernel<TEX, ATT, 2, false, 1, true>), grid, dim3(256), 0, s, k);    \
-    else if (any_tap && strict) hipLaunchKernelGGL((render_fwd_kernel<TEX, ATT, 2, true, 0>), grid, dim3(256), 0, s, k); \
-    else if (any_tap) hipLaunchKernelGGL((render_fwd_kernel<TEX, ATT, 2, true, 1>), grid, dim3(256), 0, s, k);          \
-    else if (strict) hipLaunchKernelGGL((render_fwd_kernel<TEX, ATT, 2, false, 0>), grid, dim3(256), 0, s, k);          \
-    else hipLaunchKernelGGL((render_fwd_kernel<TEX, ATT, 2, false, 1>), grid, dim3(256), 0, s, k);                      \
+    if (fast) hipLaunchKernelGGL((render_fwd_kernel<TEX, ATT, NFI_RENDER_OCC, false, 1, false, false, true>), grid, dim3(256), 0, s, k); \
+    else if (k.prof) hipLaunchKernelGGL((render_fwd_kernel<TEX, ATT, NFI_RENDER_OCC, false, 1, true>), grid, dim3(256), 0, s, k);    \
+    else if (any_tap && strict) hipLaunchKernelGGL((render_fwd_kernel<TEX, ATT, NFI_RENDER_OCC, true, 0>), grid, dim3(256), 0, s, k); \
+    else if (any_tap) hipLaunchKernelGGL((render_fwd_kernel<TEX, ATT, NFI_RENDER_OCC, true, 1>), grid, dim3(256), 0, s, k);          \
+    else if (strict) hipLaunchKernelGGL((render_fwd_kernel<TEX, ATT, NFI_RENDER_OCC, false, 0>), grid, dim3(256), 0, s, k);          \
+    else hipLaunchKernelGGL((render_fwd_kernel<TEX, ATT, NFI_RENDER_OCC, false, 1>), grid, dim3(256), 0, s, k);                      \
   } while (0)
 #define NFI_LAUNCH_RENDER_WIDE(TEX, ATT)                                                                             \
   do {                                                                                                                \
@@ -1913,7 +1920,7 @@ extern "C" int nfi_render_fwd(const nfi_render_args* a, nfi_stream_t stream) {
 #define NFI_LAUNCH_RENDER_VD(TEX, ATT)                                                                                        \
   do {                                                                                                                      \
     if (a->n_samples > 64) hipLaunchKernelGGL((render_fwd_wide_kernel<TEX, ATT, true, 0, true>), grid, dim3(256), 0, s, k);   \
-    else hipLaunchKernelGGL((render_fwd_kernel<TEX, ATT, 2, true, 0, false, true>), grid, dim3(256), 0, s, k);                \
+    else hipLaunchKernelGGL((render_fwd_kernel<TEX, ATT, NFI_RENDER_OCC, true, 0, false, true>), grid, dim3(256), 0, s, k);                \
   } while (0)
   if (a->ray_features) {
     if (a->texel_dtype == NFI_TEXEL_F32) {

@@ -93,14 +93,20 @@ def test_bench_roofline_is_reproducible_from_the_committed_profile():
     fraction is a fraction (round 1 printed 1.97 against HBM), the byte-side levels each have their own peak."""
     import json
     import bench
-    prof = json.load(open(os.path.join(ROOT, 'profiles', 'r2', 'pmc_render_fwd.json')))
+    prof = json.load(open(os.path.join(ROOT, 'profiles', 'r3', 'pmc_render_fwd.json')))
     kernel_ms, marched = prof['kernel_ns_in_clock_pass'] * 1e-6, prof['rays_marched_per_launch']
     r = bench.roofline(kernel_ms, marched, 8)
-    assert r['source'] == 'profiles/r2/pmc_render_fwd.json' and r['bound'] == 'valu-issue'
+    assert r['source'] == 'profiles/r3/pmc_render_fwd.json' and r['bound'] == 'valu-issue'
     assert abs(r['frac'] - r['achieved'] / r['peak']) < 1e-12 and 0.3 < r['frac'] <= 1.0
     # at the profile's own kernel time the fraction is the profile's issue fraction
     assert abs(r['frac'] - prof['issue_frac']) < 0.01 * prof['issue_frac']
     assert r['traffic'] == prof['fabric_bytes_per_launch']
+    # the vector ALU alone (the pipe that binds) and the occupancy the profile ran at
+    assert abs(r['valu_pipe']['frac'] - prof['valu_frac']) < 0.01 * prof['valu_frac'] and 0.4 < r['valu_pipe']['frac'] < r['frac']
+    assert 1.5 < r['waves_per_simd'] <= 2.0
+    # priced at a shader clock measured in the timed launches, the fraction scales with the clock ratio
+    live = bench.roofline(kernel_ms, marched, 8, live_clock_hz=2.4e9)
+    assert abs(live['frac'] - r['frac'] * prof['shader_clock_hz'] / 2.4e9) < 1e-9 and 'live' in live['shader_clock_source']
     for level in ('hbm_compulsory', 'l2_requests', 'fabric'):
         assert 0.0 < r['levels'][level]['frac'] < 1.0, level
     assert r['levels']['gather_stream_algorithmic']['x_hbm_peak'] > 1.0      # cache-served: why HBM is not the bound

@@ -1,0 +1,74 @@
+"""Variant builds of the fused render kernels (build-time knobs of nfi_device.hpp) for A/B timing on the GPU box.
+
+    python tools/probes/render_variants.py build                     # here: build/variants/libnfi_render_<name>.so
+    python tools/probes/render_variants.py run                       # on the GPU box: ms per launch of every variant
+
+    base        product build (3 planes of loads in flight, 2 workgroups per CU)
+    pw_occ2     gather one plane at a time, 2 workgroups per CU
+    pw_occ3     gather one plane at a time, 3 workgroups per CU (<= 168 VGPRs)
+    occ3        all loads in flight, 3 workgroups per CU (the compiler has to fit 168 VGPRs)
+    pw_scalar   pw_occ2 + the marched ray's origin / direction / near / far in scalar registers
+    pw_scalar_single(_occ3)   + one field tile at a time through the decoder MLP (half the accumulators)
+"""
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+OUT = os.path.join(ROOT, 'build', 'variants')
+VARIANTS = {'base': ['-DNFI_PLANEWISE=0'], 'pw_occ2': ['-DNFI_PLANEWISE=1'], 'pw_occ3': ['-DNFI_PLANEWISE=1', '-DNFI_RENDER_OCC=3'],
+            'occ3': ['-DNFI_PLANEWISE=0', '-DNFI_RENDER_OCC=3'],
+            'pw_scalar': ['-DNFI_PLANEWISE=1', '-DNFI_SCALAR_RAY=1'],
+            'pw_scalar_single': ['-DNFI_PLANEWISE=1', '-DNFI_SCALAR_RAY=1', '-DNFI_TILE_PAIR=0'],
+            'pw_scalar_single_occ3': ['-DNFI_PLANEWISE=1', '-DNFI_SCALAR_RAY=1', '-DNFI_TILE_PAIR=0', '-DNFI_RENDER_OCC=3']}
+
+
+def build(names):
+    import __graft_entry__ as entry
+    from concurrent.futures import ThreadPoolExecutor
+    os.makedirs(OUT, exist_ok=True)
+    bwd_obj = os.path.join(ROOT, 'build', 'nfi_backward_field.o')
+    assert os.path.exists(bwd_obj), 'run python __graft_entry__.py first'
+    src = os.path.join(entry.CSRC, 'nfi_kernels.hip')
+
+    def one(name):
+        obj = os.path.join(OUT, 'render_%s.o' % name)
+        seen, n = entry.compile_unit(src, VARIANTS[name], obj)
+        subprocess.check_call([os.environ.get('HIPCC', '/opt/rocm/bin/hipcc'), '--offload-arch=gfx950', '-fPIC', '-shared', obj,
+                               bwd_obj, '-o', os.path.join(OUT, 'libnfi_render_%s.so' % name)])
+        os.remove(obj)
+        return name, n
+    with ThreadPoolExecutor(4) as pool:
+        for name, n in pool.map(one, names):
+            print('built', name, '(%d packed-fp32 instructions rewritten)' % n, flush=True)
+
+
+def run(names, iters=60):
+    import torch
+    import bench
+    from nerf_from_image_amd import _lib
+    dev = torch.device('cuda:0')
+    rows = []
+    for name in names:
+        _lib._lib = None
+        _lib.LIBRARY = os.path.join(OUT, 'libnfi_render_%s.so' % name)
+        from nerf_from_image_amd import ops
+        res = {}
+        ref = None
+        for case, (n_img, radius, kw) in {'chairs_b8': (8, bench.RADIUS, {}), 'all_hit_b8': (8, 1.3, {}), 'chairs_b1': (1, bench.RADIUS, {}),
+                                          'cfg5_b2': (2, bench.RADIUS, {'R': 256, 'S': 128})}.items():
+            r, out = bench.time_render(ops, dev, n_img, radius, ops.TEXEL_F32, iters=iters, **kw)
+            res[case] = r['ms']['median']
+            res[case + '_sum'] = float(out['rgb'].double().sum())
+        rows.append((name, res))
+        print('%-8s ' % name + '  '.join('%s %.4f ms' % (k, v) for k, v in res.items() if not k.endswith('_sum')) +
+              '   checksums ' + ' '.join('%.6f' % v for k, v in res.items() if k.endswith('_sum')), flush=True)
+
+
+if __name__ == '__main__':
+    names = sys.argv[2:] or list(VARIANTS)
+    if sys.argv[1] == 'build':
+        build(names)
+    else:
+        run(names)
