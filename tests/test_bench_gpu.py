@@ -78,3 +78,23 @@ def test_bench_distributed_code_path(gpu_device):
     assert r.returncode == 0, (r.stdout[-1000:], r.stderr[-3000:])
     j = _last_json(r.stdout)
     assert j['n_gpus'] == 1 and j['value'] > 1e6 and j['scaling'] == 'weak'
+
+
+@pytest.mark.parametrize('mode', ['render', 'train'])
+def test_bench_launches_itself_when_called_without_a_launcher(gpu_device, mode):
+    """How the driver calls it for N > 1: plain `python bench.py --gpus N ...`, no torchrun, no WORLD_SIZE.  bench.py then
+    re-runs its own command line under torch.distributed.run (one process per GPU on 127.0.0.1); exercised here with
+    one rank through --force-dist (the box has one GPU): rc 0, ONE JSON line from rank 0, RCCL initialised."""
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
+    cmd = [sys.executable, 'bench.py', '--gpus', '1', '--force-dist', '--steps', '3', '--warmup', '1']
+    cmd += ['--mode', 'train'] if mode == 'train' else ['--no-cpu-baseline', '--no-extras', '--images-per-gpu', '2']
+    r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, (r.stdout[-1000:], r.stderr[-3000:])
+    j = _last_json(r.stdout)
+    assert j['n_gpus'] == 1 and j['value'] > 1e5
+    if mode == 'train':
+        assert 'RCCL' in j['config']['collective'] and len(j['per_rank']) == 1
+    # asking for more GPUs than the box has fails loudly instead of hanging in a rendezvous
+    r = subprocess.run([sys.executable, 'bench.py', '--gpus', '64', '--steps', '1', '--warmup', '0'], cwd=ROOT,
+                       capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode != 0 and 'GPU(s) are visible' in (r.stderr + r.stdout)
