@@ -24,6 +24,9 @@
 #ifndef NFI_SCALAR_RAY
 #define NFI_SCALAR_RAY 0         // 1: the marched ray's origin / direction / near / far through v_readfirstlane into SGPRs
 #endif
+#ifndef NFI_PREFETCH_RAY
+#define NFI_PREFETCH_RAY 1       // 1: the next ray's inputs are loaded into registers while the current ray is marched
+#endif
 #ifndef NFI_RENDER_OCC
 #define NFI_RENDER_OCC 2         // workgroups of 4 waves per CU the render kernels are compiled and launched for
 #endif

@@ -1376,7 +1376,9 @@ __global__ __launch_bounds__(256, OCC) void render_fwd_kernel(RenderKernelParams
   if (cur < n_rays) load_inputs(ray_of(cur), in);
   while (cur < n_rays) {
     fly = fetch();
+#if NFI_PREFETCH_RAY
     if (nxt < n_rays) load_inputs(ray_of(nxt), pre);
+#endif
     const uint32_t ray = ray_of(cur);
     const uint32_t hitb = in.hit;
     if (k.skip_missed && !(hitb & 2)) {
@@ -1533,7 +1535,11 @@ __global__ __launch_bounds__(256, OCC) void render_fwd_kernel(RenderKernelParams
         pc[4] += t1 - t0; pc[5] += t2 - t1; pc[6] += t3 - t2; pc[7] += t4 - t3; pc[8] += t5 - t4; pc[9] += t6 - t5; pc[10] += 1;
       }
     }
+#if NFI_PREFETCH_RAY
     in = pre;
+#else
+    if (nxt < n_rays) load_inputs(ray_of(nxt), in);      // (experiment: no register-resident prefetch of the next ray)
+#endif
     cur = nxt;
     nxt = fly;
   }

@@ -299,10 +299,12 @@ def test_field_query_backward_viewdir(gpu_device, A, use_sdf, N, S):
         rel_close(a, b, 'grad ' + n, 5e-4)
 
 
-@pytest.mark.parametrize('fine,ortho,S', [(True, False, 32), (False, False, 32), (True, True, 32), (False, False, 512)])
+@pytest.mark.parametrize('fine,ortho,S', [(True, False, 32), (False, False, 32), (True, True, 32), (False, False, 512),
+                                          (True, False, 96)])      # 96 + 96: the two-slot render kernel's stash
 def test_render_backward_end_to_end(gpu_device, fine, ortho, S):
     """d(rgb, mask)/d(planes producer params, decoder, beta, alpha, attention values, camera, focal) through
-    nfi_render.render (staged HIP path) against autograd of the oracle with the same noise."""
+    nfi_render.render - with fine sampling the fused render + training stash as ONE autograd node, without it the staged
+    path - against autograd of the oracle with the same noise."""
     from test_host_api_gpu import RandTap
     dev = gpu_device
     torch.manual_seed(7)
@@ -428,3 +430,39 @@ def test_backward_outputs_without_atomics_are_bit_reproducible(gpu_device):
         assert torch.equal(run(1, want_points=True)['g_points'], ref)
         assert torch.equal(run(0, want_points=True)['g_points'], ref)
         assert torch.equal(run(0, points_only=True, normalize_points=True)['g_points'], ref_n)
+
+
+def test_render_backward_without_camera_gradient(gpu_device):
+    """force_no_cam_grad (run.py:211-214) and a camera that needs no gradient take the field backward without its
+    coordinate-gradient pass: the other gradients must be the ones of the full backward, the camera gets none."""
+    from test_host_api_gpu import RandTap
+    dev = gpu_device
+    torch.manual_seed(9)
+    model = StandInGenerator(0.55, attention_values=10, use_sdf=True, plane_res=32).to(dev)
+    nfi_gen.attach(model)
+    g = torch.Generator().manual_seed(22)
+    B, H, W, S = 2, 16, 16, 32
+    cam0 = look_at_cameras(B, 1.5, g).to(dev)
+    focal = torch.full((B,), 1.1, device=dev)
+    z = torch.randn(B, 512, generator=g).to(dev)
+    w_rgb = torch.randn(B, H, W, 3, generator=g).to(dev)
+    cfg = types.SimpleNamespace(use_viewdir=False, use_sdf=True, attention_values=10, fine_sampling=True)
+    render = nfi_render.make_render(cfg, {'scene_range': 0.55, 'white_background': False})
+    params = [model.decoder.net[0].weight, model.decoder.net[2].weight, model.beta, model.synthesis_network.basis]
+
+    def grads(cam, force):
+        torch.manual_seed(33)                      # identical noise draws
+        rgb, _, mask, _, _, _ = render(model, H, W, cam, focal, None, None, z, S, force_no_cam_grad=force)
+        return rgb, torch.autograd.grad((rgb * w_rgb).sum() + mask.sum(), params + ([cam] if cam.requires_grad and not force else []))
+    cam_g = cam0.clone().requires_grad_()
+    rgb_a, full = grads(cam_g, False)
+    rgb_b, forced = grads(cam_g, True)
+    rgb_c, plain = grads(cam0.clone(), False)
+    assert torch.equal(rgb_a, rgb_b) and torch.equal(rgb_a, rgb_c)
+    assert float(full[-1].abs().max()) > 0
+    for a, b, c in zip(full[:4], forced, plain):         # (float atomics: equal up to summation order)
+        scale = max(a.abs().max().item(), 1e-12)
+        assert (b - c).abs().max().item() <= 1e-4 * scale
+        assert (a - b).abs().max().item() <= 1e-4 * scale
+    with pytest.raises(RuntimeError):
+        torch.autograd.grad(render(model, H, W, cam_g, focal, None, None, z, S, force_no_cam_grad=True)[0].sum(), [cam_g])
