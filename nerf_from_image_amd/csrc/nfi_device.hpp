@@ -85,6 +85,29 @@ constexpr int kVdVF = kVdImageFloats;
 constexpr int kVdFieldLdsFloats = kVdVF + 64;          // 6080
 constexpr int kRayFeatPad = 48;                        // per-ray feature row: [0, x_0..x_31, 0 x 15]
 
+// ---- division of a 32-bit unsigned by a launch-invariant divisor ------------------------------------------------
+// q = x / d as a multiply-high, two adds and two shifts (Granlund-Montgomery, round-up form: exact for every 32-bit x).
+// The render kernels decode a queue position into (scene, block row, block column) once per ray with three such
+// divisions; as plain `/` they are ~25 VALU instructions each (the operands are wave-uniform, but there is no scalar
+// divide), this way they are scalar-ALU work.
+struct FastDiv {
+  uint32_t mul, shift;      // mul == 0: d == 1
+};
+inline FastDiv make_fastdiv(uint32_t d) {
+  FastDiv f{0u, 0u};
+  if (d <= 1u) return f;
+  uint32_t l = 0;
+  while ((1ull << l) < d) ++l;                                   // l = ceil(log2 d), 1..32
+  f.mul = (uint32_t)((((1ull << l) - d) << 32) / d + 1ull);
+  f.shift = l - 1u;
+  return f;
+}
+__device__ __forceinline__ uint32_t fastdiv(uint32_t x, FastDiv f) {
+  const uint32_t t = __umulhi(x, f.mul);
+  const uint32_t q = (t + ((x - t) >> 1)) >> f.shift;
+  return f.mul == 0u ? x : q;
+}
+
 // ---- small wave helpers ---------------------------------------------------------------------
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
 // Ordering point between the lanes of ONE wave around its private LDS slab: LDS operations of a wave execute in

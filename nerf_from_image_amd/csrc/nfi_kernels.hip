@@ -767,7 +767,7 @@ __device__ __forceinline__ void merge_pair_scatter(WaveSlab& slab, const MergeIn
   wave_lds_fence();
   const uint4* kv = reinterpret_cast<const uint4*>(slab.key);
   const int n4 = (S + 3) >> 2;
-  int cnt_a = 0, cnt_b = 0, cnt_c = 0, cnt_e = 0;
+  int cnt_a = 0, cnt_b = 0, cnt_c = 0;
   for (int i = 0; i < n4; ++i) {
     const uint4 q = kv[i];
     const uint32_t qq[4] = {q.x, q.y, q.z, q.w};
@@ -775,12 +775,18 @@ __device__ __forceinline__ void merge_pair_scatter(WaveSlab& slab, const MergeIn
     for (int e = 0; e < 4; ++e) {
       cnt_a += (qq[e] < kc) ? 1 : 0;
       cnt_b += (qq[e] < kf) ? 1 : 0;
-      cnt_e += (qq[e] == kf) ? 1 : 0;
     }
   }
-  // fine depths are almost never equal (then cnt_e == 1: the key itself); only if some are, redo the count with the
-  // stable tie-break of torch.sort (earlier index first)
-  if (!__all(!valid || cnt_e == 1)) {
+  // fine depths are almost never equal.  Equal keys have equal counts of smaller keys and distinct keys distinct counts,
+  // so a tie shows as two lanes claiming the same slot of a scratch row (the cdf row is free after the resampling):
+  // one LDS write + read instead of a third comparison per key.  Only then the count is redone with the stable
+  // tie-break of torch.sort (earlier index first)
+  uint32_t* claim = reinterpret_cast<uint32_t*>(slab.cdf);
+  if (valid) claim[cnt_b] = (uint32_t)lane;
+  wave_lds_fence();
+  const bool lost = valid && claim[cnt_b] != (uint32_t)lane;
+  wave_lds_fence();
+  if (__any(lost)) {
     cnt_b = 0;
     for (int i = 0; i < n4; ++i) {
       const uint4 q = kv[i];
@@ -854,7 +860,7 @@ __device__ __forceinline__ bool merge_pair_scatter_wide(Slab& slab, const float 
   wave_lds_fence();
   const uint4* kv = reinterpret_cast<const uint4*>(slab.key);
   const int n4 = (S + 3) >> 2;
-  int cnt_a[2] = {0, 0}, cnt_b[2] = {0, 0}, cnt_e[2] = {0, 0};
+  int cnt_a[2] = {0, 0}, cnt_b[2] = {0, 0};
   for (int i = 0; i < n4; ++i) {
     const uint4 q = kv[i];
     const uint32_t qq[4] = {q.x, q.y, q.z, q.w};
@@ -864,10 +870,18 @@ __device__ __forceinline__ bool merge_pair_scatter_wide(Slab& slab, const float 
       for (int j = 0; j < 2; ++j) {
         cnt_a[j] += (qq[e] < kc[j]) ? 1 : 0;
         cnt_b[j] += (qq[e] < kf[j]) ? 1 : 0;
-        cnt_e[j] += (qq[e] == kf[j]) ? 1 : 0;
       }
   }
-  if (!__all((!val[0] || cnt_e[0] == 1) && (!val[1] || cnt_e[1] == 1))) {
+  // ties among the fine keys = two elements claiming the same slot (see merge_pair_scatter)
+  uint32_t* claim = reinterpret_cast<uint32_t*>(slab.cdf);
+#pragma unroll
+  for (int j = 0; j < 2; ++j) if (val[j]) claim[cnt_b[j]] = (uint32_t)(j * 64 + lane);
+  wave_lds_fence();
+  bool lost = false;
+#pragma unroll
+  for (int j = 0; j < 2; ++j) lost = lost || (val[j] && claim[cnt_b[j]] != (uint32_t)(j * 64 + lane));
+  wave_lds_fence();
+  if (__any(lost)) {
     cnt_b[0] = cnt_b[1] = 0;            // equal fine depths exist: stable tie-break (earlier index first)
     for (int i = 0; i < n4; ++i) {
       const uint4 q = kv[i];
@@ -1211,6 +1225,7 @@ struct RenderKernelParams {
   const float* xray;   // view-direction decoder: padded per-ray features [N][kRayFeatPad], or null
   float fast_od;       // FAST kernels: optical depth -ln(eps) behind which a ray is no longer marched
   unsigned long long* clock_probe;   // null, or {shader cycles, 100 MHz ticks} lived by workgroup 0 / wave 0
+  FastDiv div_hw, div_bps, div_bw;   // division by rays per image, blocks per scene, blocks per image row (nfi_device.hpp)
   int tap_stride;      // entries per ray in the per-sample tap arrays: S, or 2S for the training stash (fine half at +S)
   int stash;           // 1: the taps are the training stash: missed rays keep being skipped and get an all-zero row
 };
@@ -1278,8 +1293,8 @@ struct RayQueue {
   }
   __device__ __forceinline__ uint32_t ray_at(uint32_t q, uint32_t pos) const {
     const uint32_t b = (pos >> (2 * bsh)) * 8u + q;
-    const uint32_t in = pos & ((1u << (2 * bsh)) - 1u), scene = b / bps, bb = b - scene * bps;
-    const uint32_t by = bb / bw, bx = bb - by * bw;
+    const uint32_t in = pos & ((1u << (2 * bsh)) - 1u), scene = fastdiv(b, k.div_bps), bb = b - scene * bps;
+    const uint32_t by = fastdiv(bb, k.div_bw), bx = bb - by * bw;
     const uint32_t st = in >> 6, sty = st >> (bsh - 3), stx = st & ((1u << (bsh - 3)) - 1u);   // 8x8 sub-tile of the block
     const uint32_t y = (by << bsh) + (sty << 3) + ((in >> 3) & 7u), x = (bx << bsh) + (stx << 3) + (in & 7u);
     return scene * (uint32_t)k.hw + y * (uint32_t)k.width + x;
@@ -1398,7 +1413,7 @@ __global__ __launch_bounds__(256, OCC) void render_fwd_kernel(RenderKernelParams
       }
     } else {
       unsigned long long t0 = PROF ? __builtin_readcyclecounter() : 0;
-      const int scene = (int)(ray / (uint32_t)k.hw);
+      const int scene = (int)fastdiv(ray, k.div_hw);
       if (scene != cur_scene) {
         cur_scene = scene;
         const char* tex_scene = reinterpret_cast<const char*>(k.texels) + (size_t)scene * 3 * k.res * k.res * tb;
@@ -1613,7 +1628,7 @@ __global__ __launch_bounds__(256, NFI_RENDER_OCC) void render_fwd_wide_kernel(Re
         }
       }
     } else {
-      const int scene = (int)(ray / (uint32_t)k.hw);
+      const int scene = (int)fastdiv(ray, k.div_hw);
       if (scene != cur_scene) {
         cur_scene = scene;
         const char* tex_scene = reinterpret_cast<const char*>(k.texels) + (size_t)scene * 3 * k.res * k.res * tb;
@@ -1878,6 +1893,10 @@ extern "C" int nfi_render_fwd(const nfi_render_args* a, nfi_stream_t stream) {
     k.xcd_block_shift = sel == 1 ? 3 : (sel == 2 ? 5 : (sel == 3 ? 4 : ((both & 31) == 0 ? 5 : ((both & 15) == 0 ? 4 : 3))));
     const int side = 1 << k.xcd_block_shift;
     k.xcd_blocks = (((a->tuning >> 4) & 1) == 0 && (a->width % side == 0) && (a->height % side == 0)) ? 1 : 0;
+    const uint32_t bw = (uint32_t)a->width >> k.xcd_block_shift, bh = (uint32_t)a->height >> k.xcd_block_shift;
+    k.div_hw = make_fastdiv((uint32_t)k.hw);
+    k.div_bw = make_fastdiv(bw > 0 ? bw : 1u);
+    k.div_bps = make_fastdiv(bw * bh > 0 ? bw * bh : 1u);
     // (A scene-per-XCD hand-out - queue q holding the blocks of scenes q, q+8, ... so that every XCD's L2 holds one
     // scene's texels - was tried in round 2 and is slower: the shared scene keeps the eight L2s' misses on lines another
     // XCD has just pulled into the Infinity Cache.  Even as a run-time option it cost the default path 13 %, the extra
