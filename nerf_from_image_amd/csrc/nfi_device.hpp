@@ -616,6 +616,51 @@ __device__ __forceinline__ void pow2_normaliser(float amax, float& s, float& inv
   inv = bits2f((int)(e << 23));
 }
 
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((__vector_size__(4 * sizeof(__fp16)))) __fp16 nfi_fp16x4;
+__device__ __forceinline__ f16x4 lds_read_tr16(const char* p) {
+  return __builtin_bit_cast(f16x4, __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) nfi_fp16x4*)(p)));
+}
+__device__ __forceinline__ f16x8 lds_read_tr16x2(const char* p, int second) {
+  const f16x4 a = lds_read_tr16(p), b = lds_read_tr16(p + second);
+  return __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+__device__ __forceinline__ float row_allreduce_max(float v) {
+  v = fmaxf(v, dpp_f32<kDppQuadXor1>(v, v));
+  v = fmaxf(v, dpp_f32<kDppQuadXor2>(v, v));
+  v = fmaxf(v, dpp_f32<kDppRowHalfMirror>(v, v));
+  v = fmaxf(v, dpp_f32<kDppRowMirror>(v, v));
+  return v;
+}
+// Sticky power-of-two scale of a set of weight-gradient accumulators whose A operands are tile-scaled fp16 (see
+// nfi_backward_field.inc).  am_pt: the lane's point's largest entry (uniform over the four 16-lane rows); es: biased
+// exponent of the scale (0: not set yet); et_max: biased exponent of the largest tile maximum seen.  A tile's largest
+// entry lands in [2^8, 2^9) when the scale is (re)set, which happens when it would leave [2^-2, 2^14) under the current
+// one.  The scale never rises more than 2^40 above what the largest tile seen so far asks for: the accumulators then stay
+// far from overflow when they are rescaled, and a tile 2^40 below the largest one contributes nothing to an fp32 sum
+// anyway.  Returns the factor the accumulators of the set have to be multiplied by (1: nothing to do).
+__device__ __forceinline__ float sticky_scale(float am_pt, int& es, int& et_max) {
+  const int et = (int)(((uint32_t)__builtin_amdgcn_readfirstlane((int)f2bits(row_allreduce_max(am_pt))) >> 23) & 0xffu);
+  float fac = 1.0f;
+  if (et == 0 || et == 255) { if (es == 0) es = 127; return fac; }
+  et_max = max(et_max, et);
+  const int want = min(max(min(262 - et, 302 - et_max), 1), 254);
+  if (es == 0) { es = want; return fac; }
+  const int u = et + es - 254;
+  if (u > 13 || (u < -2 && want > es)) {
+    fac = bits2f((uint32_t)min(max(want - es + 127, 1), 254) << 23);
+    es = want;
+  }
+  return fac;
+}
+// fp16 pair 2^x, x = es + e_pt - 254: a scale 2^(es - 127) over the point's own normaliser (inv_pt = 2^(e_pt - 127) is what
+// pow2_normaliser returned as `inv`); 0 below the fp16 normal range
+__device__ __forceinline__ uint32_t ratio_f16x2(int es, float inv_pt) {
+  const int x = es + (int)((f2bits(inv_pt) >> 23) & 0xffu) - 254;
+  const uint32_t hb = x < -14 ? 0u : (uint32_t)(min(x, 15) + 15) << 10;
+  return hb | (hb << 16);
+}
+
 // PREC 0: exact fp32 MFMA (v_mfma_f32_16x16x4_f32, 48 per tile).
 // PREC 1: split fp16 (v_mfma_f32_16x16x32_f16, 18 per tile): every operand is hi + lo in fp16 and the
 //         products hi*hi + hi*lo + lo*hi are accumulated in fp32 - 2^-21 relative per product instead of
