@@ -593,14 +593,25 @@ __device__ __forceinline__ void tile_epilogue(const FieldParams& P, int lane, co
 // order one.  The resolution is ABSOLUTE, 2^-24 (the fp16 subnormal spacing; subnormals are preserved by the MFMA in
 // the default kernel mode): fine for activations, whose products accumulate with O(1) terms, NOT for operands of
 // arbitrary scale such as gradients - those are brought to [1, 2) first (pow2_normaliser below).
+#ifndef NFI_SPLIT_MIX
+#define NFI_SPLIT_MIX 1     // 1: residual x - float(hi) as one v_fma_mix_f32 per value (reads the fp16 half in place) instead of cvt + sub
+#endif
 __device__ __forceinline__ void split_f16x8(const float (&x)[8], f16x8& hi, f16x8& lo) {
   typedef float f32x2 __attribute__((ext_vector_type(2)));
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     auto h = __builtin_amdgcn_cvt_pkrtz(x[2 * i], x[2 * i + 1]);
+#if NFI_SPLIT_MIX
+    float r0, r1;
+    const uint32_t hb = __builtin_bit_cast(uint32_t, h);
+    asm("v_fma_mix_f32 %0, -%1, 1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(r0) : "v"(hb), "v"(x[2 * i]));
+    asm("v_fma_mix_f32 %0, -%1, 1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r1) : "v"(hb), "v"(x[2 * i + 1]));
+    auto l = __builtin_amdgcn_cvt_pkrtz(r0, r1);
+#else
     const f32x2 xv = {x[2 * i], x[2 * i + 1]}, hv = {(float)h[0], (float)h[1]};
     const f32x2 r = xv - hv;                                  // one v_pk_add_f32 (exact: Sterbenz-like residual)
     auto l = __builtin_amdgcn_cvt_pkrtz(r[0], r[1]);
+#endif
     hi[2 * i] = h[0]; hi[2 * i + 1] = h[1];
     lo[2 * i] = l[0]; lo[2 * i + 1] = l[1];
   }

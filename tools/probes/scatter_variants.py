@@ -13,11 +13,7 @@ sys.path.insert(0, ROOT)
 OUT = os.path.join(ROOT, 'build', 'variants')
 VARIANTS = {
     'base': [],
-    'depth16': ['-DNFI_BIN_DEPTH=16'],
-    'tile8': ['-DNFI_BIN_TILE_SMALL=1'],
-    'tile8_d16': ['-DNFI_BIN_TILE_SMALL=1', '-DNFI_BIN_DEPTH=16'],
-    'tile8_d12': ['-DNFI_BIN_TILE_SMALL=1', '-DNFI_BIN_DEPTH=12'],
-    'tile8_scene_d16': ['-DNFI_BIN_TILE_SMALL=1', '-DNFI_BIN_SCENE_MAJOR=1', '-DNFI_BIN_DEPTH=16'],
+    'split_mix': ['-DNFI_SPLIT_MIX=1'],
 }
 
 
