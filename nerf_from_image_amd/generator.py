@@ -85,7 +85,18 @@ def texels_of(planes, texel_dtype=ops.TEXEL_F32):
     v = ops.planes_view_as_texels(p) if p.dtype == torch.float32 else None
     if v is not None:
         return v if texel_dtype == ops.TEXEL_F32 else v.to(ops._TEXEL_TORCH[texel_dtype])
-    return ops.planes_to_texels(p, texel_dtype)
+    # one forward asks twice (the sampler and the regulariser branch): the transposed copy stays with the planes tensor
+    # object (and goes away with it); an in-place update of the planes bumps _version and invalidates it
+    key = (planes._version, texel_dtype)
+    hit = getattr(planes, '_nfi_texels', None)
+    if hit is not None and hit[0] == key:
+        return hit[1]
+    t = ops.planes_to_texels(p, texel_dtype)
+    try:
+        planes._nfi_texels = (key, t)
+    except AttributeError:           # (a tensor subclass with __slots__)
+        pass
+    return t
 
 
 def make_sampler(planes, decoder, scene_range, n_attention, attention_values, use_sdf, beta, alpha,
