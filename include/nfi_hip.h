@@ -348,6 +348,12 @@ typedef struct nfi_field_bwd_args {
    * nfi_field_bwd_workspace_bytes(a) of workspace (177 B per point).  Same result up to fp32 summation order. */
   int scatter_mode;
   int texel_layout;              /* of texels AND g_texels */
+  /* Order hint (0: none): the points are [rays][samples_per_ray] with the rays in row-major order of an image
+   * rays_per_row wide (what nfi_render_fwd's training stash holds).  The kernel then walks the rays in 16 x 16- (or 8 x 8-)
+   * pixel tiles, one tile at a time per XCD, for L2 locality of the texel gather; results do not depend on it beyond the
+   * summation order of the parameter gradients.  Ignored unless samples_per_ray is a multiple of 64 and the image
+   * divides into whole tiles. */
+  int rays_per_row;
 } nfi_field_bwd_args;
 size_t nfi_field_bwd_workspace_bytes(const nfi_field_bwd_args* a);  /* for the scatter_mode / decoder of *a */
 size_t nfi_decoder_bwd_image_floats(void);          /* workspace floats, plain decoder */

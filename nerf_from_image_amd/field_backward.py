@@ -10,10 +10,12 @@ BINNED_SCATTER_MIN_POINTS = 1 << 16
 
 def field_query_bwd(points, texels, decoder_image, w1, w2, scene_range, n_attention, attention_values, use_sdf, beta,
                     alpha, g_sigma, g_rgb, g_sdf=None, g_semantics=None, want_points=False, points_only=False,
-                    normalize_points=False, viewdir=None, scatter_mode=None):
+                    normalize_points=False, viewdir=None, scatter_mode=None, ray_order=None):
     """Returns dict(g_texels [B,3,R,R,32], g_w1, g_b1, g_w2, g_b2, g_attention_values?, g_beta?, g_alpha?, g_points?).
     viewdir: None or dict(ray_features=padded [B,N,48], samples_per_ray, w3) for the --use_viewdir decoder
-    (decoder_image from ops.decoder_pack_viewdir, w2 [33,64]); adds g_ray_features [B,N,32], g_w3, g_b3."""
+    (decoder_image from ops.decoder_pack_viewdir, w2 [33,64]); adds g_ray_features [B,N,32], g_w3, g_b3.
+    ray_order: None or (samples_per_ray, rays_per_row) - the points are [rays][samples] with the rays in row-major image
+    order (the fused render's stash): a locality hint for the kernel's walk, no effect on the result."""
     f = ops._f32c
     points = f(points, 'points')
     B, P = points.shape[0], points.shape[1]
@@ -48,6 +50,8 @@ def field_query_bwd(points, texels, decoder_image, w1, w2, scene_range, n_attent
             out['g_w3'] = torch.zeros((n3, 32), dtype=torch.float32, device=dev)
             out['g_b3'] = torch.zeros((n3,), dtype=torch.float32, device=dev)
             vd_args['g_ray_features'] = torch.zeros_like(rf)
+    if ray_order is not None and viewdir is None:
+        vd_args = dict(samples_per_ray=int(ray_order[0]), rays_per_row=int(ray_order[1]))
     if scatter_mode is None:
         # binned plane-gradient scatter pays once the counting sort is amortised (dense renders); tiny queries
         # (tests, the regulariser's 31^3 probes) scatter straight from the kernel

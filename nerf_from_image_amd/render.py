@@ -107,7 +107,8 @@ def _render_with_stash(fused, height, width, S, cam, focal, bbox, center, noise_
                                      white_background=bool(white), want_rd=cam_grad)
         pts = ops.points_on_rays(keep['ray_origins'], rd, st_t).view(B, -1, 3)
         g = field_query_bwd(pts, texels, image, a_w1, a_w2, scene_range, A, att, use_sdf, be, al,
-                            cb['g_sigma'].view(B, -1), cb['g_rgb'].view(B, -1, 3), want_points=cam_grad)
+                            cb['g_sigma'].view(B, -1), cb['g_rgb'].view(B, -1, 3), want_points=cam_grad,
+                            ray_order=(2 * S, width))
         g_cam = g_focal = None
         if cam_grad:
             g_ro, g_rd = ops.points_bwd(g['g_points'].view(*st_t.shape, 3), st_t)

@@ -53,6 +53,9 @@ def main():
     dev = torch.device('cuda:0')
     fn, (a, k) = capture(dev)
     a = tuple(t.detach() if torch.is_tensor(t) else t for t in a)
+    if os.environ.get('NFI_NO_RAY_ORDER'):
+        k = {n: v for n, v in k.items() if n != 'ray_order'}
+    print('ray_order hint:', k.get('ray_order'))
     out = fn(*a, **k)
     torch.cuda.synchronize()
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(n + 1)]
