@@ -1,6 +1,6 @@
 #!/bin/bash
 # One GPU-box session: tests, parity report, bench (render + train), rocprofv3 stats + PMC of the render kernel.
-# usage (via gpurun): bash tools/gpu_session.sh <tag> [what...]   what: tests report bench train pmc bwd   (default: all)
+# usage (via gpurun): bash tools/gpu_session.sh <tag> [what...]   what: tests report bench train pmc pmc_bwd bwd handoff prof_inv prof_train prof_bench regulariser train_bwd stress   (default: tests report bench train pmc)
 TAG=${1:-s}
 shift
 WHAT=${@:-tests report bench train pmc}
@@ -58,6 +58,15 @@ for f in glob.glob("$O/prof_train/**/*kernel_stats.csv", recursive=True):
         print('%8.3f ms %6s calls %8.1f us  %s' % (float(r['TotalDurationNs']) / 1e6, r['Calls'], float(r['AverageNs']) / 1e3, r['Name'][:90]))
 PY
       ;;
+    prof_bench)
+      (cd /tmp && export TMPDIR=/tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_bench -o b -- python $R/bench.py --steps 100 --warmup 20 --no-extras --no-cpu-baseline > $O/prof_bench.log 2>&1); tail -c 300 $O/prof_bench.log
+      python tools/kstats.py $O/prof_bench 8;;
+    regulariser)
+      timeout 300 python tools/bench_regulariser.py > $O/bench_regulariser.log 2>&1; tail -2 $O/bench_regulariser.log;;
+    train_bwd)
+      timeout 300 python tools/bench_train_backward.py 30 > $O/bench_train_backward.log 2>&1; tail -2 $O/bench_train_backward.log;;
+    stress)
+      timeout 900 python tools/repro_stress.py > $O/repro_stress.log 2>&1; tail -12 $O/repro_stress.log;;
   esac
 done
 cat $O/env.txt
