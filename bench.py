@@ -364,6 +364,9 @@ def main():
     ap.add_argument('--bucket-mb', type=int, default=32, help='train mode: gradient bucket size')
     ap.add_argument('--reduce-mode', choices=('all_reduce', 'reduce_scatter'), default='all_reduce')
     ap.add_argument('--no-overlap', action='store_true', help='train mode: launch the collectives after backward')
+    ap.add_argument('--serial', action='store_true',
+                    help='render mode: one stream, every step after the previous one (default: two HIP streams - the next '
+                         "step's texel hand-off, decoder pack and noise draws overlap this step's render)")
     args = ap.parse_args()
 
     if 'WORLD_SIZE' not in os.environ and (args.gpus > 1 or args.force_dist):
@@ -401,39 +404,87 @@ def main():
 
     probe = torch.zeros(2, dtype=torch.int64, device=dev)
 
-    def step(timed_kernel=False):
-        texels = ops.planes_to_texels(d['planes'])
-        image = ops.decoder_pack(d['w1'], d['b1'], d['w2'], d['b2'], A)
-        noise_c = torch.rand((B, R, R, S), dtype=torch.float32, device=dev)
-        noise_f = torch.rand([n_rays, S], dtype=torch.float32, device=dev)
-        out = ops.render_fwd(d['cam'], d['focal'], R, R, S, texels, image, SCENE_RANGE, A, d['att'], True, d['beta'],
-                             d['alpha'], noise_coarse=noise_c, noise_fine=noise_f, fine_sampling=True,
-                             white_background=True, skip_missed_rays=not args.no_skip, workspace=state['ws'],
-                             events=ev.pair() if timed_kernel else None, clock_probe=probe if timed_kernel else None)
+    def prepare():
+        """Everything of a step in front of the render: texel hand-off of the producer's planes, decoder operand image,
+        the two noise draws."""
+        return dict(texels=ops.planes_to_texels(d['planes']), image=ops.decoder_pack(d['w1'], d['b1'], d['w2'], d['b2'], A),
+                    noise_c=torch.rand((B, R, R, S), dtype=torch.float32, device=dev),
+                    noise_f=torch.rand([n_rays, S], dtype=torch.float32, device=dev))
+
+    def render(pre, timed_kernel=False):
+        out = ops.render_fwd(d['cam'], d['focal'], R, R, S, pre['texels'], pre['image'], SCENE_RANGE, A, d['att'], True,
+                             d['beta'], d['alpha'], noise_coarse=pre['noise_c'], noise_fine=pre['noise_f'],
+                             fine_sampling=True, white_background=True, skip_missed_rays=not args.no_skip,
+                             workspace=state['ws'], events=ev.pair() if timed_kernel else None,
+                             clock_probe=probe if timed_kernel else None)
         state['ws'] = out['_workspace']
         return out
+
+    def step(timed_kernel=False):
+        return render(prepare(), timed_kernel)
 
     def fence():
         if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        out = step()
-    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
-    fence()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        marks[i].record()
-        out = step()
-    marks[args.steps].record()
-    fence()
-    elapsed = time.perf_counter() - t0
-    per_step = [marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps)]
-    if use_dist:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    prep_stream = torch.cuda.Stream(device=dev)
+
+    def run_steps(n, pipelined, marks=None):
+        """n steps.  Serial: one stream.  Pipelined: the front of step i + 1 runs on a second HIP stream while step i
+        renders (two slots; a slot is refilled only after the render that read it has finished).  Every step does all of
+        its work either way."""
+        main = torch.cuda.current_stream(dev)
+        if not pipelined:
+            for i in range(n):
+                out = step()
+                if marks is not None:
+                    marks[i + 1].record()
+            return out
+        slots = [{}, {}]
+
+        def fill(i):
+            slot = slots[i % 2]
+            with torch.cuda.stream(prep_stream):
+                if 'done' in slot:
+                    prep_stream.wait_event(slot['done'])
+                slot['pre'] = prepare()
+                slot['ready'] = torch.cuda.Event()
+                slot['ready'].record(prep_stream)
+        prep_stream.wait_stream(main)
+        fill(0)
+        for i in range(n):
+            if i + 1 < n:
+                fill(i + 1)
+            slot = slots[i % 2]
+            main.wait_event(slot['ready'])
+            out = render(slot['pre'])
+            slot['done'] = torch.cuda.Event()
+            slot['done'].record(main)
+            if marks is not None:
+                marks[i + 1].record()
+        main.wait_stream(prep_stream)
+        return out
+
+    def timed(pipelined):
+        run_steps(args.warmup, pipelined)
+        marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
+        fence()
+        t0 = time.perf_counter()
+        marks[0].record()
+        out = run_steps(args.steps, pipelined, marks)
+        fence()
+        elapsed = time.perf_counter() - t0
+        per_step = [marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps)]
+        if use_dist:
+            t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        return elapsed, per_step, out
+
+    pipelined = not args.serial
+    elapsed, per_step, out = timed(pipelined)
+    other_elapsed, other_per_step, _ = timed(not pipelined)      # the other schedule, for the record (same K, same fences)
 
     # ---- dominant kernel, timed live with HIP events on its own stream (untimed extra launches) ----
     k_ms, k_clk = [], []
@@ -457,6 +508,11 @@ def main():
             'metric': 'rendered rays/sec (128x128, 64+64 samples)', 'value': value, 'unit': 'rays/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': elapsed / args.steps * 1e3,
             'ms_per_step_stats': stats(per_step),
+            'schedule': ('two HIP streams: texel hand-off + decoder pack + noise draws of step i+1 overlap the render of '
+                         'step i (double-buffered; every step does all of its work)') if pipelined else 'one stream, serial steps',
+            'other_schedule': {'schedule': 'one stream, serial steps' if pipelined else 'two HIP streams (pipelined)',
+                               'value': world * n_rays * args.steps / other_elapsed,
+                               'ms_per_step': other_elapsed / args.steps * 1e3, 'ms_per_step_stats': stats(other_per_step)},
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
             'config': {'workload': 'cfg2: shapenet_chairs-like forward render, %d images/GPU, 128x128 rays/image, '
                                    '64 coarse + 64 fine samples, 3x256x256x32 fp32 triplanes, SDF decoder, A=10; '
