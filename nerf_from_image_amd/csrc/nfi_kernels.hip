@@ -1830,14 +1830,17 @@ extern "C" int nfi_render_fwd(const nfi_render_args* a, nfi_stream_t stream) {
   hipStream_t s = (hipStream_t)stream;
   // carve the workspace
   float* ws = reinterpret_cast<float*>(a->workspace);
-  uint32_t* reduce = reinterpret_cast<uint32_t*>(ws);           // 16 floats reserved
-  float* ro = a->ray_origins ? a->ray_origins : ws + 16;
-  float* rd = a->ray_directions ? a->ray_directions : ws + 16 + 3 * n;
-  float* near_raw = ws + 16 + 6 * n;
-  float* far_raw = ws + 16 + 7 * n;
-  uint8_t* hit = a->hit ? a->hit : reinterpret_cast<uint8_t*>(ws + 16 + 8 * n);
-  // note: 16 floats + 8n floats + n bytes <= workspace_bytes by construction (64 + 32n + pad(n))
-  if (hipMemsetAsync(reduce, 0, 16, s) != hipSuccess) return fail(NFI_ERR_LAUNCH, "render: memset failed");
+  // [reduce: 16 floats][8 per-XCD work counters, 64 B apart: 128 floats][ro rd near far: 8n floats][hit: n bytes, padded]
+  uint32_t* reduce = reinterpret_cast<uint32_t*>(ws);
+  uint32_t* xcd_counter = reinterpret_cast<uint32_t*>(ws + 16);
+  constexpr int kRays0 = 16 + 128;
+  float* ro = a->ray_origins ? a->ray_origins : ws + kRays0;
+  float* rd = a->ray_directions ? a->ray_directions : ws + kRays0 + 3 * n;
+  float* near_raw = ws + kRays0 + 6 * n;
+  float* far_raw = ws + kRays0 + 7 * n;
+  uint8_t* hit = a->hit ? a->hit : reinterpret_cast<uint8_t*>(ws + kRays0 + 8 * n);
+  // (64 + 512 + 32n + pad(n) bytes = nfi_render_workspace_bytes)  ONE memset clears the reduction cells and the counters
+  if (hipMemsetAsync(reduce, 0, 64 + 8 * 64, s) != hipSuccess) return fail(NFI_ERR_LAUNCH, "render: memset failed");
   const int full_h = a->full_height > 0 ? a->full_height : a->height;
   REQUIRE(a->row_offset >= 0 && a->row_offset + a->height <= full_h, "render: row window outside the image");
   CameraParams cam{a->cam2world, a->focal, a->bbox, a->focal ? a->center : nullptr, full_h, a->width, 1, a->height, a->row_offset};
@@ -1902,9 +1905,7 @@ extern "C" int nfi_render_fwd(const nfi_render_args* a, nfi_stream_t stream) {
     // XCD has just pulled into the Infinity Cache.  Even as a run-time option it cost the default path 13 %, the extra
     // division in the per-ray position decode; removed, DESIGN.md "negative results".)
   }
-  k.xcd_counter = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(a->workspace) + 64 + (size_t)n * 32 +
-                                              (((size_t)n + 63) & ~(size_t)63));
-  if (k.xcd_blocks && hipMemsetAsync(k.xcd_counter, 0, 8 * 64, s) != hipSuccess) return fail(NFI_ERR_LAUNCH, "render: memset failed");
+  k.xcd_counter = xcd_counter;
   k.tile_order = (((a->tuning >> 2) & 1) == 0 && (a->width % 8 == 0) && (a->height % 8 == 0)) ? 1 : 0;
   k.prof = (unsigned long long*)a->profile_cycles;
   k.xray = a->ray_features;
