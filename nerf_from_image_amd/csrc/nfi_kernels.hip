@@ -19,25 +19,50 @@ extern "C" int nfi_version(void) { return 100; }
 // ------------------------------------------------------------------------------------------------
 // planes [B,3,32,R,R] <-> texels [B,3,R,R,32]
 // ------------------------------------------------------------------------------------------------
+// 256 pixels x 32 channels per block through LDS.  Loads: 16 bytes per lane along the pixels (a wave reads 1 KB of one
+// channel row per instruction).  tile[c][p + 8 (c >> 3)] with a row pitch of 288 floats: the 16-byte LDS writes stay
+// aligned and contiguous, and the transposing reads - lane (p, q) gathers channels 8q .. 8q + 7 of pixel p - hit bank
+// (p + 8 q) mod 32: conflict free.  Stores: every lane 32 contiguous bytes of its texel (4 lanes = one 128-B texel).
+constexpr int kP2tPixels = 256, kP2tPitch = 288;
 template <int TEX>
 __global__ __launch_bounds__(256) void planes_to_texels_kernel(const float* __restrict__ planes, void* __restrict__ texels,
                                                                int hw) {
-  __shared__ float tile[kC][65];
+  __shared__ __attribute__((aligned(16))) float tile[kC][kP2tPitch];
   const int img = blockIdx.y;                 // b*3 + plane
-  const int px0 = blockIdx.x * 64;
+  const int px0 = blockIdx.x * kP2tPixels;
   const float* src = planes + (size_t)img * kC * hw;
-  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  {
+    const int c4 = threadIdx.x & 63, r0 = threadIdx.x >> 6;
+    if ((hw & 3) == 0 && px0 + kP2tPixels <= hw) {
+      f32x4 v[8];
 #pragma unroll
-  for (int c = ty; c < kC; c += 4) {
-    int px = px0 + tx;
-    tile[c][tx] = (px < hw) ? src[(size_t)c * hw + px] : 0.0f;
+      for (int i = 0; i < 8; ++i) v[i] = *reinterpret_cast<const f32x4*>(src + (size_t)(r0 + 4 * i) * hw + px0 + 4 * c4);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int c = r0 + 4 * i;
+        *reinterpret_cast<f32x4*>(&tile[c][4 * c4 + 8 * (c >> 3)]) = v[i];
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int c = r0 + 4 * i;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int px = px0 + 4 * c4 + e;
+          tile[c][4 * c4 + e + 8 * (c >> 3)] = (px < hw) ? src[(size_t)c * hw + px] : 0.0f;
+        }
+      }
+    }
   }
   __syncthreads();
-  const int p = threadIdx.x >> 2, q = threadIdx.x & 3;  // pixel, channel octet
-  if (px0 + p < hw) {
+  const int q = threadIdx.x & 3;              // channel octet
+#pragma unroll
+  for (int it = 0; it < kP2tPixels / 64; ++it) {
+    const int p = it * 64 + (threadIdx.x >> 2);
+    if (px0 + p >= hw) continue;
     float v[8];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) v[k] = tile[q * 8 + k][p];
+    for (int k = 0; k < 8; ++k) v[k] = tile[q * 8 + k][p + 8 * q];
     if (TEX == 0) {
       float4* dst = reinterpret_cast<float4*>(reinterpret_cast<float*>(texels) + ((size_t)img * hw + px0 + p) * kC + q * 8);
       dst[0] = make_float4(v[0], v[1], v[2], v[3]);
@@ -96,7 +121,7 @@ extern "C" int nfi_planes_to_texels(const float* planes, void* texels, int n_sce
   REQUIRE(n_scenes > 0 && plane_res >= 2 && plane_res <= 1024, "planes_to_texels: plane_res must be in [2,1024]");
   REQUIRE(texel_dtype >= NFI_TEXEL_F32 && texel_dtype <= NFI_TEXEL_F16, "planes_to_texels: bad texel dtype");
   int hw = plane_res * plane_res;
-  dim3 grid((hw + 63) / 64, n_scenes * 3);
+  dim3 grid((hw + kP2tPixels - 1) / kP2tPixels, n_scenes * 3);
   if (texel_dtype == NFI_TEXEL_F32)
     hipLaunchKernelGGL(planes_to_texels_kernel<0>, grid, dim3(256), 0, (hipStream_t)stream, planes, texels, hw);
   else if (texel_dtype == NFI_TEXEL_BF16)
