@@ -430,16 +430,18 @@ def main():
 
     prep_stream = torch.cuda.Stream(device=dev)
 
-    def run_steps(n, pipelined, marks=None):
+    def run_steps(n, pipelined, marks=None, timed_kernel=False, after=None):
         """n steps.  Serial: one stream.  Pipelined: the front of step i + 1 runs on a second HIP stream while step i
         renders (two slots; a slot is refilled only after the render that read it has finished).  Every step does all of
         its work either way."""
         main = torch.cuda.current_stream(dev)
         if not pipelined:
             for i in range(n):
-                out = step()
+                out = step(timed_kernel)
                 if marks is not None:
                     marks[i + 1].record()
+                if after is not None:
+                    after()
             return out
         slots = [{}, {}]
 
@@ -458,11 +460,13 @@ def main():
                 fill(i + 1)
             slot = slots[i % 2]
             main.wait_event(slot['ready'])
-            out = render(slot['pre'])
+            out = render(slot['pre'], timed_kernel)
             slot['done'] = torch.cuda.Event()
             slot['done'].record(main)
             if marks is not None:
                 marks[i + 1].record()
+            if after is not None:
+                after()
         main.wait_stream(prep_stream)
         return out
 
@@ -484,16 +488,16 @@ def main():
 
     pipelined = not args.serial
     elapsed, per_step, out = timed(pipelined)
-    other_elapsed, other_per_step, _ = timed(not pipelined)      # the other schedule, for the record (same K, same fences)
 
     # ---- dominant kernel, timed live with HIP events on its own stream (untimed extra launches) ----
     k_ms, k_clk = [], []
-    for _ in range(min(50, max(5, args.steps))):
-        step(timed_kernel=True)
+
+    def read_kernel_events():
         k_ms.append(ev.elapsed_ms())
         cyc, ticks = (int(v) for v in probe.tolist())
         if ticks > 0:
             k_clk.append(cyc / ticks * 1e8)                # s_memrealtime ticks at 100 MHz
+    run_steps(min(50, max(5, args.steps)), pipelined, timed_kernel=True, after=read_kernel_events)    # same schedule as the timed steps
     kernel_ms = sum(k_ms) / len(k_ms)
     live_clock = sum(k_clk) / len(k_clk) if k_clk else None
     # rays the kernel marches = rays whose line meets the cube inflated by 1e-4 (the kernel's own skip test, fp32)
@@ -510,9 +514,6 @@ def main():
             'ms_per_step_stats': stats(per_step),
             'schedule': ('two HIP streams: texel hand-off + decoder pack + noise draws of step i+1 overlap the render of '
                          'step i (double-buffered; every step does all of its work)') if pipelined else 'one stream, serial steps',
-            'other_schedule': {'schedule': 'one stream, serial steps' if pipelined else 'two HIP streams (pipelined)',
-                               'value': world * n_rays * args.steps / other_elapsed,
-                               'ms_per_step': other_elapsed / args.steps * 1e3, 'ms_per_step_stats': stats(other_per_step)},
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
             'config': {'workload': 'cfg2: shapenet_chairs-like forward render, %d images/GPU, 128x128 rays/image, '
                                    '64 coarse + 64 fine samples, 3x256x256x32 fp32 triplanes, SDF decoder, A=10; '

@@ -30,8 +30,7 @@ def test_bench_single_process(gpu_device):
     assert j['n_gpus'] == 1 and j['steps'] == 3 and j['value'] > 1e6 and j['dtype'] == 'f32'
     assert 'split-fp16' in j['config']['mlp']
     assert j['ms_per_step_stats']['min'] <= j['ms_per_step_stats']['median'] <= j['ms_per_step_stats']['max']
-    # the headline schedule (two HIP streams) and the serial one are both timed over the same K steps
-    assert 'two HIP streams' in j['schedule'] and j['other_schedule']['value'] > 1e6
+    assert 'two HIP streams' in j['schedule']           # (--serial: one stream)
     rf = j['roofline']
     # a roofline is a bound: the kernel's binding resource is instruction issue, and the fraction cannot exceed 1
     assert rf['bound'] == 'valu-issue' and rf['source'] and 0.0 < rf['frac'] <= 1.0
