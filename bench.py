@@ -404,24 +404,26 @@ def main():
 
     probe = torch.zeros(2, dtype=torch.int64, device=dev)
 
-    def prepare():
-        """Everything of a step in front of the render: texel hand-off of the producer's planes, decoder operand image,
-        the two noise draws."""
+    def prepare(slot_ws=None):
+        """Everything of a step in front of the render kernel: texel hand-off of the producer's planes, decoder operand
+        image, the two noise draws, the ray set-up (rays, scene-cube test, miss-fill reduction) into the slot's workspace."""
         return dict(texels=ops.planes_to_texels(d['planes']), image=ops.decoder_pack(d['w1'], d['b1'], d['w2'], d['b2'], A),
                     noise_c=torch.rand((B, R, R, S), dtype=torch.float32, device=dev),
-                    noise_f=torch.rand([n_rays, S], dtype=torch.float32, device=dev))
+                    noise_f=torch.rand([n_rays, S], dtype=torch.float32, device=dev),
+                    ws=ops.render_setup(d['cam'], d['focal'], R, R, SCENE_RANGE, workspace=slot_ws))
 
     def render(pre, timed_kernel=False):
         out = ops.render_fwd(d['cam'], d['focal'], R, R, S, pre['texels'], pre['image'], SCENE_RANGE, A, d['att'], True,
                              d['beta'], d['alpha'], noise_coarse=pre['noise_c'], noise_fine=pre['noise_f'],
                              fine_sampling=True, white_background=True, skip_missed_rays=not args.no_skip,
-                             workspace=state['ws'], events=ev.pair() if timed_kernel else None,
+                             workspace=pre['ws'], rays_ready=True, events=ev.pair() if timed_kernel else None,
                              clock_probe=probe if timed_kernel else None)
-        state['ws'] = out['_workspace']
         return out
 
     def step(timed_kernel=False):
-        return render(prepare(), timed_kernel)
+        pre = prepare(state['ws'])
+        state['ws'] = pre['ws']
+        return render(pre, timed_kernel)
 
     def fence():
         if use_dist:
@@ -450,7 +452,7 @@ def main():
             with torch.cuda.stream(prep_stream):
                 if 'done' in slot:
                     prep_stream.wait_event(slot['done'])
-                slot['pre'] = prepare()
+                slot['pre'] = prepare(slot['pre']['ws'] if 'pre' in slot else None)
                 slot['ready'] = torch.cuda.Event()
                 slot['ready'].record(prep_stream)
         prep_stream.wait_stream(main)
@@ -512,12 +514,12 @@ def main():
             'metric': 'rendered rays/sec (128x128, 64+64 samples)', 'value': value, 'unit': 'rays/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': elapsed / args.steps * 1e3,
             'ms_per_step_stats': stats(per_step),
-            'schedule': ('two HIP streams: texel hand-off + decoder pack + noise draws of step i+1 overlap the render of '
-                         'step i (double-buffered; every step does all of its work)') if pipelined else 'one stream, serial steps',
+            'schedule': ('two HIP streams: texel hand-off + decoder pack + noise draws + ray set-up of step i+1 overlap the '
+                         'render kernel of step i (double-buffered; every step does all of its work)') if pipelined else 'one stream, serial steps',
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
             'config': {'workload': 'cfg2: shapenet_chairs-like forward render, %d images/GPU, 128x128 rays/image, '
                                    '64 coarse + 64 fine samples, 3x256x256x32 fp32 triplanes, SDF decoder, A=10; '
-                                   'step = texel hand-off + decoder pack + 2 rand draws + ray set-up + fused render'
+                                   'step = texel hand-off + decoder pack + 2 rand draws + ray set-up + fused render kernel'
                                    % B,
                        'mlp': 'split-fp16: decoder MLP operands as fp16 hi+lo pairs (22 significand bits), products '
                               'hi*hi + hi*lo + lo*hi accumulated in fp32 on v_mfma_f32_16x16x32_f16; everything else '

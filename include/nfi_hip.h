@@ -464,9 +464,17 @@ typedef struct nfi_render_args {
    * taps the stash keeps the missed-ray skip: rays that are skipped get an all-zero row.  Mutually exclusive with the
    * t_coarse ... rgb_fine taps. */
   float* stash_t; float* stash_sigma; float* stash_rgb;
+  /* 1: the workspace already holds the ray set-up of these cameras / this image window (nfi_render_setup with the same
+   * camera, shape, scene_range and workspace arguments, ordered before this call): nfi_render_fwd then launches the render
+   * kernel only.  Lets a caller run the set-up of the NEXT batch on another stream while this one renders. */
+  int rays_ready;
 } nfi_render_args;
 size_t nfi_render_workspace_bytes(int64_t n_rays);
 int nfi_render_fwd(const nfi_render_args* a, nfi_stream_t stream);
+/* The ray set-up of nfi_render_fwd alone (get_ray_bundle + normalize + the scene-cube test of
+ * lib/nerf_utils.py:28-91, 237-268 into the workspace, the batch-wide miss-fill reduction and the work counters cleared).
+ * Reads only the camera / shape / scene_range / workspace fields (and ray_origins / ray_directions / hit if given). */
+int nfi_render_setup(const nfi_render_args* a, nfi_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Camera pose from a canonical-coordinate map: replaces the .cpu().numpy() + OpenCV solvePnPGeneric round trip of

@@ -1840,6 +1840,48 @@ extern "C" size_t nfi_render_workspace_bytes(int64_t n_rays) {
   return n * 8 * sizeof(float) + ((n + 63) & ~(size_t)63) + 64 + 8 * 64;     // + 8 per-XCD work counters
 }
 
+// workspace carve + ray set-up shared by nfi_render_setup and nfi_render_fwd
+struct RenderWorkspace { uint32_t* reduce; uint32_t* xcd_counter; float* ro; float* rd; float* near_raw; float* far_raw; uint8_t* hit; int64_t n; };
+
+static int render_carve(const nfi_render_args* a, RenderWorkspace& w) {
+  REQUIRE(a && a->cam2world && a->workspace, "render: null pointer");
+  REQUIRE(a->n_scenes > 0 && a->height > 0 && a->width > 0, "render: bad image shape");
+  const int64_t n = (int64_t)a->n_scenes * a->height * a->width;
+  if (a->workspace_bytes < nfi_render_workspace_bytes(n)) return fail(NFI_ERR_WORKSPACE_TOO_SMALL, "render: workspace too small");
+  // [reduce: 16 floats][8 per-XCD work counters, 64 B apart: 128 floats][ro rd near far: 8n floats][hit: n bytes, padded]
+  float* ws = reinterpret_cast<float*>(a->workspace);
+  constexpr int kRays0 = 16 + 128;
+  w.n = n;
+  w.reduce = reinterpret_cast<uint32_t*>(ws);
+  w.xcd_counter = reinterpret_cast<uint32_t*>(ws + 16);
+  w.ro = a->ray_origins ? a->ray_origins : ws + kRays0;
+  w.rd = a->ray_directions ? a->ray_directions : ws + kRays0 + 3 * n;
+  w.near_raw = ws + kRays0 + 6 * n;
+  w.far_raw = ws + kRays0 + 7 * n;
+  w.hit = a->hit ? a->hit : reinterpret_cast<uint8_t*>(ws + kRays0 + 8 * n);
+  return NFI_OK;
+}
+
+static int render_setup(const nfi_render_args* a, const RenderWorkspace& w, hipStream_t s) {
+  // (64 + 512 + 32n + pad(n) bytes = nfi_render_workspace_bytes)  ONE memset clears the reduction cells and the counters
+  if (hipMemsetAsync(w.reduce, 0, 64 + 8 * 64, s) != hipSuccess) return fail(NFI_ERR_LAUNCH, "render: memset failed");
+  const int full_h = a->full_height > 0 ? a->full_height : a->height;
+  REQUIRE(a->row_offset >= 0 && a->row_offset + a->height <= full_h, "render: row window outside the image");
+  CameraParams cam{a->cam2world, a->focal, a->bbox, a->focal ? a->center : nullptr, full_h, a->width, 1, a->height, a->row_offset};
+  RaygenOut rout{w.ro, w.rd, w.near_raw, w.far_raw, w.hit, w.reduce, a->scene_range};
+  hipLaunchKernelGGL(raygen_kernel, dim3((unsigned)std::min<int64_t>((w.n + 255) / 256, kRayBlocks)), dim3(256), 0, s, cam, a->n_scenes, rout);
+  return NFI_OK;
+}
+
+extern "C" int nfi_render_setup(const nfi_render_args* a, nfi_stream_t stream) {
+  RenderWorkspace w;
+  int rc = render_carve(a, w);
+  if (rc) return rc;
+  rc = render_setup(a, w, (hipStream_t)stream);
+  if (rc) return rc;
+  return check_launch("render_setup");
+}
+
 extern "C" int nfi_render_fwd(const nfi_render_args* a, nfi_stream_t stream) {
   REQUIRE(a && a->cam2world && a->rgb && a->depth && a->mask && a->workspace, "render: null pointer");
   REQUIRE(a->n_scenes > 0 && a->height > 0 && a->width > 0, "render: bad image shape");
@@ -1850,27 +1892,19 @@ extern "C" int nfi_render_fwd(const nfi_render_args* a, nfi_stream_t stream) {
   int rc = check_field_common(a->texels, a->plane_res, a->texel_dtype, a->decoder_image, a->n_attention,
                                a->attention_values, a->use_sdf, a->beta, a->alpha, a->texel_layout);
   if (rc) return rc;
-  const int64_t n = (int64_t)a->n_scenes * a->height * a->width;
-  if (a->workspace_bytes < nfi_render_workspace_bytes(n)) return fail(NFI_ERR_WORKSPACE_TOO_SMALL, "render: workspace too small");
+  RenderWorkspace w;
+  rc = render_carve(a, w);
+  if (rc) return rc;
+  const int64_t n = w.n;
   hipStream_t s = (hipStream_t)stream;
-  // carve the workspace
-  float* ws = reinterpret_cast<float*>(a->workspace);
-  // [reduce: 16 floats][8 per-XCD work counters, 64 B apart: 128 floats][ro rd near far: 8n floats][hit: n bytes, padded]
-  uint32_t* reduce = reinterpret_cast<uint32_t*>(ws);
-  uint32_t* xcd_counter = reinterpret_cast<uint32_t*>(ws + 16);
-  constexpr int kRays0 = 16 + 128;
-  float* ro = a->ray_origins ? a->ray_origins : ws + kRays0;
-  float* rd = a->ray_directions ? a->ray_directions : ws + kRays0 + 3 * n;
-  float* near_raw = ws + kRays0 + 6 * n;
-  float* far_raw = ws + kRays0 + 7 * n;
-  uint8_t* hit = a->hit ? a->hit : reinterpret_cast<uint8_t*>(ws + kRays0 + 8 * n);
-  // (64 + 512 + 32n + pad(n) bytes = nfi_render_workspace_bytes)  ONE memset clears the reduction cells and the counters
-  if (hipMemsetAsync(reduce, 0, 64 + 8 * 64, s) != hipSuccess) return fail(NFI_ERR_LAUNCH, "render: memset failed");
-  const int full_h = a->full_height > 0 ? a->full_height : a->height;
-  REQUIRE(a->row_offset >= 0 && a->row_offset + a->height <= full_h, "render: row window outside the image");
-  CameraParams cam{a->cam2world, a->focal, a->bbox, a->focal ? a->center : nullptr, full_h, a->width, 1, a->height, a->row_offset};
-  RaygenOut rout{ro, rd, near_raw, far_raw, hit, reduce, a->scene_range};
-  hipLaunchKernelGGL(raygen_kernel, dim3((unsigned)std::min<int64_t>((n + 255) / 256, kRayBlocks)), dim3(256), 0, s, cam, a->n_scenes, rout);
+  uint32_t* reduce = w.reduce;
+  uint32_t* xcd_counter = w.xcd_counter;
+  float *ro = w.ro, *rd = w.rd, *near_raw = w.near_raw, *far_raw = w.far_raw;
+  uint8_t* hit = w.hit;
+  if (!a->rays_ready) {
+    rc = render_setup(a, w, s);
+    if (rc) return rc;
+  }
 
   const bool stash = a->stash_t || a->stash_sigma || a->stash_rgb;
   REQUIRE(!stash || (a->stash_t && a->stash_sigma && a->stash_rgb && a->fine_sampling),

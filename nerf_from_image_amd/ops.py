@@ -354,11 +354,33 @@ TAP_NAMES = ('ray_origins', 'ray_directions', 'near_plane', 'far_plane', 'hit', 
              'rgb_coarse', 't_fine', 'sigma_fine', 'rgb_fine', 't_sorted', 'weights', 'perm')
 
 
+def render_setup(cam2world, focal, height, width, scene_range, bbox=None, center=None, workspace=None, row_window=None):
+    """The ray set-up of render_fwd alone (nfi_render_setup) into `workspace` (allocated when None; returned).  A
+    render_fwd(..., workspace=that, rays_ready=True) with the same cameras / shape / scene_range / row_window then launches
+    the render kernel only - e.g. with the set-up of the next batch running on another stream meanwhile.  (Not for calls
+    that ask for the ray_origins / ray_directions taps or the training stash: those write rays to their own tensors.)"""
+    lib = _lib.load()
+    cam2world = _f32c(cam2world, 'tform_cam2world')
+    dev = cam2world.device
+    B = cam2world.shape[0]
+    n = B * height * width
+    ws_bytes = lib.nfi_render_workspace_bytes(n)
+    if workspace is None or workspace.numel() < ws_bytes:
+        workspace = torch.empty((ws_bytes,), dtype=torch.uint8, device=dev)
+    with torch.cuda.device(dev):
+        _lib.call_struct('nfi_render_setup', 'nfi_render_args', _stream(cam2world), n_scenes=B, height=height, width=width,
+                         scene_range=float(scene_range), cam2world=cam2world, focal=_f32c(focal, 'focal_length'),
+                         bbox=_f32c(bbox, 'bbox'), center=_f32c(center, 'center'), workspace=workspace,
+                         workspace_bytes=workspace.numel(), row_offset=0 if row_window is None else int(row_window[0]),
+                         full_height=0 if row_window is None else int(row_window[1]))
+    return workspace
+
+
 def render_fwd(cam2world, focal, height, width, num_samples, texels, decoder_image, scene_range, n_attention,
                attention_values=None, use_sdf=True, beta=None, alpha=None, bbox=None, center=None,
                noise_coarse=None, noise_fine=None, fine_sampling=True, white_background=True, taps=(),
                skip_missed_rays=True, workspace=None, events=None, tuning=0, profile_cycles=None, ray_features=None,
-               fast_termination=0.0, row_window=None, clock_probe=None, stash=False):
+               fast_termination=0.0, row_window=None, clock_probe=None, stash=False, rays_ready=False):
     """Fused forward render.  Returns dict(rgb [B,H,W,3], depth, mask [B,H,W], + requested taps).
     row_window: None, or (row_offset, full_height): `height` rows starting at row_offset of an image full_height rows tall
     (bit-identical to those rows of the full render; noise / outputs / taps are sized for the window).
@@ -434,7 +456,7 @@ def render_fwd(cam2world, focal, height, width, num_samples, texels, decoder_ima
             tuning=int(tuning), profile_cycles=profile_cycles, ray_features=ray_features,
             fast_termination=float(fast_termination), clock_probe=clock_probe,
             row_offset=0 if row_window is None else int(row_window[0]),
-            full_height=0 if row_window is None else int(row_window[1]), **tap_t)
+            full_height=0 if row_window is None else int(row_window[1]), rays_ready=int(bool(rays_ready)), **tap_t)
     out.update(tap_t)
     out['_workspace'] = workspace
     return out

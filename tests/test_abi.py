@@ -28,7 +28,7 @@ def test_header_declares_the_expected_entry_points():
                  'nfi_composite_fwd', 'nfi_planes_to_texels', 'nfi_decoder_pack', 'nfi_decoder_pack_viewdir',
                  'nfi_field_query_bwd', 'nfi_field_bwd_workspace_bytes', 'nfi_composite_bwd', 'nfi_points_bwd',
                  'nfi_raygen_bwd', 'nfi_bbox_overlay', 'nfi_resample', 'nfi_ray_weights', 'nfi_sdf_gradient_fwd',
-                 'nfi_sdf_gradient_bwd'):
+                 'nfi_sdf_gradient_bwd', 'nfi_render_setup'):
         assert name in declared
 
 
@@ -55,8 +55,8 @@ def test_library_contains_gfx950_code_objects_only(lib):
 def test_struct_layout_matches_header():
     # spot checks: field order and the natural-alignment size ctypes derives from the parsed header
     f = [n for n, _ in _lib.STRUCT_FIELDS['nfi_render_args']]
-    assert f[:4] == ['n_scenes', 'height', 'width', 'n_samples'] and f[-10:] == ['profile_cycles', 'ray_features', 'fast_termination', 'texel_layout', 'clock_probe', 'row_offset', 'full_height',
-                                                                                          'stash_t', 'stash_sigma', 'stash_rgb']
+    assert f[:4] == ['n_scenes', 'height', 'width', 'n_samples'] and f[-11:] == ['profile_cycles', 'ray_features', 'fast_termination', 'texel_layout', 'clock_probe', 'row_offset', 'full_height',
+                                                                                          'stash_t', 'stash_sigma', 'stash_rgb', 'rays_ready']
     assert ctypes.sizeof(_lib.STRUCTS['nfi_sample_pdf_args']) == 8 + 4 + 4 + 3 * 8 + 8 + 3 * 8
     for name, st in _lib.STRUCTS.items():
         assert ctypes.sizeof(st) % 8 == 0 or ctypes.sizeof(st) % 4 == 0, name

@@ -327,3 +327,38 @@ def test_training_stash_and_row_windows(gpu_device):
         parts.append(w)
     for k in ('rgb', 'depth', 'mask'):
         assert torch.equal(torch.cat([p[k] for p in parts], dim=1), plain[k]), k
+
+
+def test_render_with_separate_ray_setup(gpu_device):
+    """nfi_render_setup + nfi_render_fwd(rays_ready=1) - the ray set-up of a batch done ahead of its render, on another
+    stream in bench.py - gives the same pixels as the one-call render, also when the set-up ran on a second stream while
+    an earlier render was still in flight, and with a row window."""
+    d = make_inputs(2, gpu_device, radius=2.0, seed=5)
+    texels = ops.planes_to_texels(d['planes'])
+    image = ops.decoder_pack(d['w1'], d['b1'], d['w2'], d['b2'], A)
+
+    def run(**kw):
+        return ops.render_fwd(d['cam'], d['focal'], R, R, S, texels, image, 0.55, A, d['att'], True, d['beta'], d['alpha'],
+                              noise_coarse=d['noise_c'], noise_fine=d['noise_f'], white_background=True, **kw)
+    plain = run()
+    ws = ops.render_setup(d['cam'], d['focal'], R, R, 0.55)
+    two = run(workspace=ws, rays_ready=True)
+    side = torch.cuda.Stream(device=gpu_device)
+    side.wait_stream(torch.cuda.current_stream(gpu_device))
+    busy = run()                                                    # something in flight on the main stream
+    with torch.cuda.stream(side):
+        ws2 = ops.render_setup(d['cam'], d['focal'], R, R, 0.55)
+    torch.cuda.current_stream(gpu_device).wait_stream(side)
+    three = run(workspace=ws2, rays_ready=True)
+    for k in ('rgb', 'depth', 'mask'):
+        assert torch.equal(plain[k], two[k]) and torch.equal(plain[k], three[k]) and torch.equal(plain[k], busy[k]), k
+    # a row window
+    r0, r1 = 40, 72
+    kw = dict(noise_coarse=d['noise_c'][:, r0:r1].contiguous(),
+              noise_fine=d['noise_f'].view(2, R, R, S)[:, r0:r1].reshape(-1, S).contiguous(), white_background=True, row_window=(r0, R))
+    a = ops.render_fwd(d['cam'], d['focal'], r1 - r0, R, S, texels, image, 0.55, A, d['att'], True, d['beta'], d['alpha'], **kw)
+    wsw = ops.render_setup(d['cam'], d['focal'], r1 - r0, R, 0.55, row_window=(r0, R))
+    b = ops.render_fwd(d['cam'], d['focal'], r1 - r0, R, S, texels, image, 0.55, A, d['att'], True, d['beta'], d['alpha'],
+                       workspace=wsw, rays_ready=True, **kw)
+    for k in ('rgb', 'depth', 'mask'):
+        assert torch.equal(a[k], b[k]) and torch.equal(a[k], plain[k][:, r0:r1]), k
