@@ -466,3 +466,49 @@ def test_render_backward_without_camera_gradient(gpu_device):
         assert (a - b).abs().max().item() <= 1e-4 * scale
     with pytest.raises(RuntimeError):
         torch.autograd.grad(render(model, H, W, cam_g, focal, None, None, z, S, force_no_cam_grad=True)[0].sum(), [cam_g])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('H,W,spr', [(32, 48, 128), (16, 24, 64), (40, 8, 192)])
+def test_ray_order_hint_changes_nothing(gpu_device, H, W, spr):
+    """nfi_field_bwd_args.rays_per_row: the points are [rays][samples] of an H x W image; the kernel then walks the rays in
+    16 x 16- (or 8 x 8-) pixel tiles, one tile per XCD at a time.  Same coordinate gradients bit for bit (they are written
+    per point), same plane / parameter gradients up to fp32 summation order; also for images that only divide into 8-pixel
+    tiles."""
+    from nerf_from_image_amd import field_backward as fb, ops as hops
+    dev = gpu_device
+    g = torch.Generator().manual_seed(77 + H)
+    B, A, r, res = 2, 10, 0.55, 64
+    P = H * W * spr
+    planes = torch.randn(B, 3, 32, res, res, generator=g).to(dev)
+    dec = _Decoder(1 + A, g).to(dev)
+    w1, b1, w2, b2 = dec.net[0].weight, dec.net[0].bias, dec.net[2].weight, dec.net[2].bias
+    x = ((torch.rand(B, P, 3, generator=g) * 2 - 1) * r).to(dev)
+    att = (torch.rand(B, A, 3, generator=g) * 2 - 1).to(dev)
+    beta, alpha = torch.tensor([0.12], device=dev), torch.tensor([0.3], device=dev)
+    g_sig, g_rgb = torch.randn(B, P, generator=g).to(dev), torch.randn(B, P, 3, generator=g).to(dev)
+    g_sig[0, : P // 3] = 0; g_rgb[0, : P // 3] = 0                     # whole tiles without a gradient
+    texels, image = hops.planes_to_texels(planes), hops.decoder_pack(w1, b1, w2, b2, A)
+    a = fb.field_query_bwd(x, texels, image, w1, w2, r, A, att, True, beta, alpha, g_sig, g_rgb, want_points=True)
+    b = fb.field_query_bwd(x, texels, image, w1, w2, r, A, att, True, beta, alpha, g_sig, g_rgb, want_points=True,
+                           ray_order=(spr, W))
+    assert torch.equal(a['g_points'], b['g_points'])
+    assert a['g_texels'].abs().max() > 0
+    for k in a:
+        # (beta / alpha: one fp32 sum over all points of terms that largely cancel with these random gradients - the
+        #  order of the walk shows at 1e-4 of the RESULT, 1e-7 of the terms)
+        rel_close(b[k], a[k], 'ray-order hint ' + k, 1e-3 if k in ('g_beta', 'g_alpha') else 2e-5)
+
+
+@pytest.mark.gpu
+def test_planes_to_texels_all_sizes(gpu_device):
+    """The layout kernels against torch.permute: tiny / odd planes, sizes that are not multiples of the 256-pixel block,
+    fp32 / bf16 / fp16 storage (round to nearest even), and the round trip."""
+    from nerf_from_image_amd import ops as hops
+    g = torch.Generator().manual_seed(0)
+    for R in (2, 3, 5, 16, 17, 48, 255, 300):
+        pl = torch.randn(2, 3, 32, R, R, generator=g).to(gpu_device)
+        ref = pl.permute(0, 1, 3, 4, 2).contiguous()
+        for dt, td in ((hops.TEXEL_F32, torch.float32), (hops.TEXEL_BF16, torch.bfloat16), (hops.TEXEL_F16, torch.float16)):
+            assert torch.equal(hops.planes_to_texels(pl, dt).view(ref.shape), ref.to(td)), (R, dt)
+        assert torch.equal(hops.texels_to_planes(hops.planes_to_texels(pl)), pl), R
