@@ -197,6 +197,16 @@ __device__ __forceinline__ double wave_incl_scan_add(double v, int lane) {
   v += dpp_f64<kDppRowBcast31, 0xc>(0.0, v);
   return v;
 }
+// the same in fp32 (the renderer's opt-in fast mode; exact for small integer counts: the merge's histogram)
+__device__ __forceinline__ float wave_incl_scan_add_f32(float v) {
+  v += dpp_f32<NFI_DPP_ROW_SHR(1)>(0.0f, v);
+  v += dpp_f32<NFI_DPP_ROW_SHR(2)>(0.0f, v);
+  v += dpp_f32<NFI_DPP_ROW_SHR(4)>(0.0f, v);
+  v += dpp_f32<NFI_DPP_ROW_SHR(8)>(0.0f, v);
+  v += dpp_f32<kDppRowBcast15, 0xa>(0.0f, v);
+  v += dpp_f32<kDppRowBcast31, 0xc>(0.0f, v);
+  return v;
+}
 __device__ __forceinline__ double wave_incl_scan_mul(double v, int lane) {
   (void)lane;
   v *= dpp_f64<NFI_DPP_ROW_SHR(1)>(1.0, v);

@@ -779,6 +779,9 @@ __device__ __forceinline__ void merge_scatter(Slab& slab, const float (&dep)[NS]
 // i.e. the stable ascending order of cat(coarse, fine) (coarse first on ties), ~4x fewer compares
 // than ranking all 2S keys against all 2S keys.  Falls back to the general count when the coarse
 // depths are not ascending (possible only through 1-ulp rounding of the jittered depths).
+#ifndef NFI_MERGE_HIST
+#define NFI_MERGE_HIST 1      // 0: the coarse samples' ranks by a second comparison per fine key (round 2 / start of round 3)
+#endif
 struct MergeIn { float t, sigma, r, g, b; };
 __device__ __forceinline__ void merge_pair_scatter(WaveSlab& slab, const MergeIn& c, const MergeIn& f, int S, int lane,
                                                    int& rank_c, int& rank_f) {
@@ -793,13 +796,40 @@ __device__ __forceinline__ void merge_pair_scatter(WaveSlab& slab, const MergeIn
   const uint4* kv = reinterpret_cast<const uint4*>(slab.key);
   const int n4 = (S + 3) >> 2;
   int cnt_a = 0, cnt_b = 0, cnt_c = 0;
-  for (int i = 0; i < n4; ++i) {
-    const uint4 q = kv[i];
-    const uint32_t qq[4] = {q.x, q.y, q.z, q.w};
+  if (ascending && NFI_MERGE_HIST) {
+    // #{fine < z_k} against all fine keys; the coarse side needs no second comparison per key: with the coarse keys
+    // ascending, a fine key f is below coarse key k exactly when #{coarse <= f} <= k, so #{fine < t_k} is the running sum
+    // over the histogram of the fine keys' upper bounds (one LDS add per lane + one wave scan instead of 64 compares)
+    for (int i = 0; i < n4; ++i) {
+      const uint4 q = kv[i];
+      const uint32_t qq[4] = {q.x, q.y, q.z, q.w};
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      cnt_a += (qq[e] < kc) ? 1 : 0;
-      cnt_b += (qq[e] < kf) ? 1 : 0;
+      for (int e = 0; e < 4; ++e) cnt_b += (qq[e] < kf) ? 1 : 0;
+    }
+    // #{coarse <= z_k}: branch-free upper bound over the ascending coarse keys
+    int pos = 0;
+#pragma unroll
+    for (int step = 64; step >= 1; step >>= 1) {
+      int idx = pos + step;
+      if (idx <= S && slab.key[64 + idx - 1] <= kf) pos = idx;
+    }
+    cnt_c = pos;
+    uint32_t* hist = reinterpret_cast<uint32_t*>(slab.bins);      // (free after the resampling) entries 0 .. S
+    hist[lane] = 0u;
+    if (lane == 0) hist[64] = 0u;
+    wave_lds_fence();
+    if (valid) atomicAdd(&hist[cnt_c], 1u);
+    wave_lds_fence();
+    cnt_a = (int)wave_incl_scan_add_f32((float)hist[lane]);
+  } else {
+    for (int i = 0; i < n4; ++i) {
+      const uint4 q = kv[i];
+      const uint32_t qq[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        cnt_a += (qq[e] < kc) ? 1 : 0;
+        cnt_b += (qq[e] < kf) ? 1 : 0;
+      }
     }
   }
   // fine depths are almost never equal.  Equal keys have equal counts of smaller keys and distinct keys distinct counts,
@@ -824,14 +854,15 @@ __device__ __forceinline__ void merge_pair_scatter(WaveSlab& slab, const MergeIn
     }
   }
   if (ascending) {
-    // #{coarse <= z_k}: branch-free upper bound over the ascending coarse keys
-    int pos = 0;
+    if (!NFI_MERGE_HIST) {
+      int pos = 0;
 #pragma unroll
-    for (int step = 64; step >= 1; step >>= 1) {
-      int idx = pos + step;
-      if (idx <= S && slab.key[64 + idx - 1] <= kf) pos = idx;
+      for (int step = 64; step >= 1; step >>= 1) {
+        int idx = pos + step;
+        if (idx <= S && slab.key[64 + idx - 1] <= kf) pos = idx;
+      }
+      cnt_c = pos;
     }
-    cnt_c = pos;
     rank_c = lane + cnt_a;
   } else {
     int cnt_d = 0;   // coarse j before coarse k
@@ -885,7 +916,7 @@ __device__ __forceinline__ bool merge_pair_scatter_wide(Slab& slab, const float 
   wave_lds_fence();
   const uint4* kv = reinterpret_cast<const uint4*>(slab.key);
   const int n4 = (S + 3) >> 2;
-  int cnt_a[2] = {0, 0}, cnt_b[2] = {0, 0};
+  int cnt_a[2] = {0, 0}, cnt_b[2] = {0, 0}, cnt_c[2];
   for (int i = 0; i < n4; ++i) {
     const uint4 q = kv[i];
     const uint32_t qq[4] = {q.x, q.y, q.z, q.w};
@@ -893,9 +924,34 @@ __device__ __forceinline__ bool merge_pair_scatter_wide(Slab& slab, const float 
     for (int e = 0; e < 4; ++e)
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
-        cnt_a[j] += (qq[e] < kc[j]) ? 1 : 0;
+        if (!NFI_MERGE_HIST) cnt_a[j] += (qq[e] < kc[j]) ? 1 : 0;
         cnt_b[j] += (qq[e] < kf[j]) ? 1 : 0;
       }
+  }
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    int pos = 0;                        // #{coarse <= z}: upper bound over the ascending coarse keys
+#pragma unroll
+    for (int step = 128; step >= 1; step >>= 1) {
+      const int idx = pos + step;
+      if (idx <= S && slab.key[128 + idx - 1] <= kf[j]) pos = idx;
+    }
+    cnt_c[j] = pos;
+  }
+  if (NFI_MERGE_HIST) {
+    // #{fine < t_e} for the ascending coarse keys = running sum over the histogram of the fine keys' upper bounds
+    // (merge_pair_scatter): entries 0 .. S of the bins row, element e = slot * 64 + lane
+    uint32_t* hist = reinterpret_cast<uint32_t*>(slab.bins);
+    hist[lane] = 0u; hist[64 + lane] = 0u;
+    if (lane == 0) hist[128] = 0u;
+    wave_lds_fence();
+#pragma unroll
+    for (int j = 0; j < 2; ++j) if (val[j]) atomicAdd(&hist[cnt_c[j]], 1u);
+    wave_lds_fence();
+    const float s0 = wave_incl_scan_add_f32((float)hist[lane]);
+    const float t0 = bits2f((uint32_t)__builtin_amdgcn_readlane((int)f2bits(s0), 63));
+    const float s1 = t0 + wave_incl_scan_add_f32((float)hist[64 + lane]);
+    cnt_a[0] = (int)s0; cnt_a[1] = (int)s1;
   }
   // ties among the fine keys = two elements claiming the same slot (see merge_pair_scatter)
   uint32_t* claim = reinterpret_cast<uint32_t*>(slab.cdf);
@@ -922,14 +978,8 @@ __device__ __forceinline__ bool merge_pair_scatter_wide(Slab& slab, const float 
   }
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
-    int pos = 0;                        // #{coarse <= z}: upper bound over the ascending coarse keys
-#pragma unroll
-    for (int step = 128; step >= 1; step >>= 1) {
-      const int idx = pos + step;
-      if (idx <= S && slab.key[128 + idx - 1] <= kf[j]) pos = idx;
-    }
     rank[j] = j * 64 + lane + cnt_a[j];
-    rank[2 + j] = pos + cnt_b[j];
+    rank[2 + j] = cnt_c[j] + cnt_b[j];
   }
   wave_lds_fence();
 #pragma unroll
@@ -1271,16 +1321,6 @@ struct ClockProbe {
   }
 };
 
-// inclusive fp32 scan over the 64 lanes (fast mode only: the exact path scans in double, see nfi_device.hpp)
-__device__ __forceinline__ float wave_incl_scan_add_f32(float v) {
-  v += dpp_f32<NFI_DPP_ROW_SHR(1)>(0.0f, v);
-  v += dpp_f32<NFI_DPP_ROW_SHR(2)>(0.0f, v);
-  v += dpp_f32<NFI_DPP_ROW_SHR(4)>(0.0f, v);
-  v += dpp_f32<NFI_DPP_ROW_SHR(8)>(0.0f, v);
-  v += dpp_f32<kDppRowBcast15, 0xa>(0.0f, v);
-  v += dpp_f32<kDppRowBcast31, 0xc>(0.0f, v);
-  return v;
-}
 __device__ __forceinline__ float uniform_f32(float v) {
   return bits2f((uint32_t)__builtin_amdgcn_readfirstlane((int)f2bits(v)));
 }

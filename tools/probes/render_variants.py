@@ -23,7 +23,7 @@ VARIANTS = {'base': ['-DNFI_PLANEWISE=0'], 'pw_occ2': ['-DNFI_PLANEWISE=1'], 'pw
             'pw_scalar_single': ['-DNFI_PLANEWISE=1', '-DNFI_SCALAR_RAY=1', '-DNFI_TILE_PAIR=0'],
             'sched_max_ilp': ['-mllvm', '-amdgpu-sched-strategy=max-ilp'],
             'sched_max_clause': ['-mllvm', '-amdgpu-sched-strategy=max-memory-clause'],
-            'no_slp': ['-fno-slp-vectorize'], 'reg_occ2': ['-DNFI_REG_OCC=2'], 'split_mix': ['-DNFI_SPLIT_MIX=1'],
+            'no_slp': ['-fno-slp-vectorize'], 'reg_occ2': ['-DNFI_REG_OCC=2'], 'split_mix': ['-DNFI_SPLIT_MIX=1'], 'merge_cmp': ['-DNFI_MERGE_HIST=0'],
             'pw_scalar_single_occ3': ['-DNFI_PLANEWISE=1', '-DNFI_SCALAR_RAY=1', '-DNFI_TILE_PAIR=0', '-DNFI_RENDER_OCC=3']}
 
 
