@@ -611,10 +611,12 @@ extern "C" int nfi_bbox_overlay(const float* points, int64_t n_points, float sce
 // ------------------------------------------------------------------------------------------------
 template <int N>
 struct __attribute__((aligned(16))) WaveSlabT {
+  static constexpr int kN = N;
   float cdf[N];
   float bins[N];
   uint32_t key[N];
   float srt[5][N];   // depth, sigma, r, g, b in merged order
+  float piv[N / 8];  // every eighth cdf entry (cdf[8p + 7], +inf past the end): build_cdf / invert_cdf
 };
 using WaveSlab = WaveSlabT<128>;       // up to 64 + 64 samples per ray
 using WaveSlabWide = WaveSlabT<256>;   // up to 128 + 128
@@ -644,14 +646,35 @@ __device__ __forceinline__ void build_cdf(Slab& slab, const float (&bins)[SPL], 
     int e = j * 64 + lane;
     if (e < M - 1) slab.cdf[e + 1] = inc[j];
     if (e < M) slab.bins[e] = bins[j];
+    // pivot table for the two-level search of invert_cdf: entry p = cdf[8p + 7] (+inf past the end)
+    if (((e + 1) & 7) == 7) slab.piv[(e + 1) >> 3] = (e + 1 < M) ? inc[j] : INFINITY;
   }
   if (lane == 0) slab.cdf[0] = 0.0f;
   wave_lds_fence();
 }
 
-template <class Slab>
+// NP: pivots to look at = ceil(largest M / 8) of the caller (a multiple of 4; build_cdf<SPL> writes 8 SPL of them)
+template <int NP, class Slab>
 __device__ __forceinline__ float invert_cdf(const Slab& slab, int M, float u, int& ind) {
-  ind = upper_bound_lds(slab.cdf, M, u);
+  // searchsorted(cdf, u, right=True) = #{cdf <= u} over the ascending cdf, as an 8-way two-level search: the pivots
+  // (every eighth entry: two or four 16-byte broadcast reads) give the block, the block's eight entries the position -
+  // two dependent LDS round trips instead of the seven or eight of a binary search
+  {
+    const f32x4* pv = reinterpret_cast<const f32x4*>(slab.piv);
+    int b = 0;
+#pragma unroll
+    for (int i = 0; i < NP / 4; ++i) {
+      const f32x4 p = pv[i];
+      b += (p.x <= u ? 1 : 0) + (p.y <= u ? 1 : 0) + (p.z <= u ? 1 : 0) + (p.w <= u ? 1 : 0);
+    }
+    const f32x4* cv = reinterpret_cast<const f32x4*>(slab.cdf + 8 * b);
+    const f32x4 c0 = cv[0], c1 = cv[1];
+    const float c[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
+    int cnt = 0;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) cnt += (8 * b + e < M && c[e] <= u) ? 1 : 0;
+    ind = 8 * b + cnt;
+  }
   int lo = ind - 1 < 0 ? 0 : ind - 1;
   int hi = ind > M - 1 ? M - 1 : ind;
   float c_lo = slab.cdf[lo], c_hi = slab.cdf[hi];
@@ -685,7 +708,7 @@ __device__ __forceinline__ float resample_ray(WaveSlab& slab, float sigma, float
   float wts[1] = {lane_next(sm, 0.0f)};                    // weights e = 0..S-3  <- smooth[e+1]
   build_cdf<1>(slab, mid, wts, S - 1, lane);
   int ind;
-  float z = invert_cdf(slab, S - 1, u, ind);
+  float z = invert_cdf<8>(slab, S - 1, u, ind);
   if (taps) { taps->w = w[0]; taps->smooth = sm; taps->ind = ind; }
   return z;
 }
@@ -721,7 +744,7 @@ __device__ __forceinline__ void resample_ray_wide(Slab& slab, const float (&sigm
   for (int j = 0; j < SP; ++j) mid[j] = 0.5f * (tn[j] + t[j]);  // bins e = 0..S-2
   build_cdf<SP>(slab, mid, wts, S - 1, lane);
 #pragma unroll
-  for (int j = 0; j < SP; ++j) z[j] = invert_cdf(slab, S - 1, u[j], ind[j]);
+  for (int j = 0; j < SP; ++j) z[j] = invert_cdf<8 * SP>(slab, S - 1, u[j], ind[j]);
 }
 
 // ---- merge + composite ---------------------------------------------------------------------------
@@ -792,6 +815,8 @@ __device__ __forceinline__ void merge_pair_scatter(WaveSlab& slab, const MergeIn
   const bool ascending = __all(lane >= S - 1 || kc <= kc_next);
   slab.key[lane] = kf;            // fine keys   [0,64)   (padding 0xFFFFFFFF ranks after everything)
   slab.key[64 + lane] = kc;       // coarse keys [64,128)
+  uint32_t* kpiv = reinterpret_cast<uint32_t*>(slab.piv);          // every eighth coarse key (the pivot row is free after the resampling)
+  if ((lane & 7) == 7) kpiv[lane >> 3] = kc;
   wave_lds_fence();
   const uint4* kv = reinterpret_cast<const uint4*>(slab.key);
   const int n4 = (S + 3) >> 2;
@@ -800,20 +825,32 @@ __device__ __forceinline__ void merge_pair_scatter(WaveSlab& slab, const MergeIn
     // #{fine < z_k} against all fine keys; the coarse side needs no second comparison per key: with the coarse keys
     // ascending, a fine key f is below coarse key k exactly when #{coarse <= f} <= k, so #{fine < t_k} is the running sum
     // over the histogram of the fine keys' upper bounds (one LDS add per lane + one wave scan instead of 64 compares)
-    for (int i = 0; i < n4; ++i) {
-      const uint4 q = kv[i];
-      const uint32_t qq[4] = {q.x, q.y, q.z, q.w};
+    // (all 16 quads, whatever S: the padding keys 0xFFFFFFFF never count, and a fixed trip count lets the 16 LDS reads
+    //  go out together instead of one LDS latency per turn)
+    uint4 qv[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) qv[i] = kv[i];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const uint32_t qq[4] = {qv[i].x, qv[i].y, qv[i].z, qv[i].w};
 #pragma unroll
       for (int e = 0; e < 4; ++e) cnt_b += (qq[e] < kf) ? 1 : 0;
     }
-    // #{coarse <= z_k}: branch-free upper bound over the ascending coarse keys
-    int pos = 0;
+    // #{coarse <= z_k} over the ascending coarse keys: 8-way two-level search (pivots, then the block's eight keys), two
+    // dependent LDS round trips instead of a binary search's seven
+    {
+      const uint4* pv = reinterpret_cast<const uint4*>(kpiv);
+      const uint4 p0 = pv[0], p1 = pv[1];
+      const int b = (p0.x <= kf ? 1 : 0) + (p0.y <= kf ? 1 : 0) + (p0.z <= kf ? 1 : 0) + (p0.w <= kf ? 1 : 0) +
+                    (p1.x <= kf ? 1 : 0) + (p1.y <= kf ? 1 : 0) + (p1.z <= kf ? 1 : 0) + (p1.w <= kf ? 1 : 0);
+      const uint4* cv = reinterpret_cast<const uint4*>(slab.key + 64 + 8 * b);
+      const uint4 c0 = cv[0], c1 = cv[1];
+      const uint32_t c[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
+      int cnt = 0;
 #pragma unroll
-    for (int step = 64; step >= 1; step >>= 1) {
-      int idx = pos + step;
-      if (idx <= S && slab.key[64 + idx - 1] <= kf) pos = idx;
+      for (int e = 0; e < 8; ++e) cnt += (8 * b + e < 64 && c[e] <= kf) ? 1 : 0;
+      cnt_c = 8 * b + cnt;
     }
-    cnt_c = pos;
     uint32_t* hist = reinterpret_cast<uint32_t*>(slab.bins);      // (free after the resampling) entries 0 .. S
     hist[lane] = 0u;
     if (lane == 0) hist[64] = 0u;
@@ -913,30 +950,49 @@ __device__ __forceinline__ bool merge_pair_scatter_wide(Slab& slab, const float 
     slab.key[j * 64 + lane] = kf[j];           // fine keys   [0,128)
     slab.key[128 + j * 64 + lane] = kc[j];     // coarse keys [128,256)
   }
+  uint32_t* kpiv = reinterpret_cast<uint32_t*>(slab.piv);          // every eighth coarse key (16 pivots)
+#pragma unroll
+  for (int j = 0; j < 2; ++j) if ((lane & 7) == 7) kpiv[(j * 64 + lane) >> 3] = kc[j];
   wave_lds_fence();
   const uint4* kv = reinterpret_cast<const uint4*>(slab.key);
   const int n4 = (S + 3) >> 2;
   int cnt_a[2] = {0, 0}, cnt_b[2] = {0, 0}, cnt_c[2];
-  for (int i = 0; i < n4; ++i) {
-    const uint4 q = kv[i];
-    const uint32_t qq[4] = {q.x, q.y, q.z, q.w};
+  // all 32 quads of the fine keys in two batches of 16 LDS reads (padding keys never count; see merge_pair_scatter)
 #pragma unroll
-    for (int e = 0; e < 4; ++e)
+  for (int h = 0; h < 2; ++h) {
+    uint4 qv[16];
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        if (!NFI_MERGE_HIST) cnt_a[j] += (qq[e] < kc[j]) ? 1 : 0;
-        cnt_b[j] += (qq[e] < kf[j]) ? 1 : 0;
-      }
-  }
+    for (int i = 0; i < 16; ++i) qv[i] = kv[16 * h + i];
 #pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    int pos = 0;                        // #{coarse <= z}: upper bound over the ascending coarse keys
+    for (int i = 0; i < 16; ++i) {
+      const uint32_t qq[4] = {qv[i].x, qv[i].y, qv[i].z, qv[i].w};
 #pragma unroll
-    for (int step = 128; step >= 1; step >>= 1) {
-      const int idx = pos + step;
-      if (idx <= S && slab.key[128 + idx - 1] <= kf[j]) pos = idx;
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          if (!NFI_MERGE_HIST) cnt_a[j] += (qq[e] < kc[j]) ? 1 : 0;
+          cnt_b[j] += (qq[e] < kf[j]) ? 1 : 0;
+        }
     }
-    cnt_c[j] = pos;
+  }
+  {
+    // #{coarse <= z} over the ascending coarse keys: two-level 8-way search (merge_pair_scatter)
+    const uint4* pv = reinterpret_cast<const uint4*>(kpiv);
+    const uint4 pq[4] = {pv[0], pv[1], pv[2], pv[3]};
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      int b = 0;
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        b += (pq[i].x <= kf[j] ? 1 : 0) + (pq[i].y <= kf[j] ? 1 : 0) + (pq[i].z <= kf[j] ? 1 : 0) + (pq[i].w <= kf[j] ? 1 : 0);
+      const uint4* cv = reinterpret_cast<const uint4*>(slab.key + 128 + 8 * b);
+      const uint4 c0 = cv[0], c1 = cv[1];
+      const uint32_t c[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
+      int cnt = 0;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) cnt += (8 * b + e < 128 && c[e] <= kf[j]) ? 1 : 0;
+      cnt_c[j] = 8 * b + cnt;
+    }
   }
   if (NFI_MERGE_HIST) {
     // #{fine < t_e} for the ascending coarse keys = running sum over the histogram of the fine keys' upper bounds
@@ -1080,7 +1136,7 @@ __global__ __launch_bounds__(256) void sample_pdf_kernel(nfi_sample_pdf_args a) 
     if (e < K) {
       float u = a.u[ray * a.u_row_stride + e];
       int ind;
-      float z = invert_cdf(slab, M, u, ind);
+      float z = invert_cdf<16>(slab, M, u, ind);
       a.samples[ray * K + e] = z;
       if (a.inds) a.inds[ray * K + e] = ind;
     }

@@ -17,7 +17,8 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 OUT = os.path.join(ROOT, 'build', 'variants')
-VARIANTS = {'base': ['-DNFI_PLANEWISE=0'], 'pw_occ2': ['-DNFI_PLANEWISE=1'], 'pw_occ3': ['-DNFI_PLANEWISE=1', '-DNFI_RENDER_OCC=3'],
+VARIANTS = {'prev': None,      # a library built from an earlier tree, dropped into build/variants by hand
+            'base': ['-DNFI_PLANEWISE=0'], 'pw_occ2': ['-DNFI_PLANEWISE=1'], 'pw_occ3': ['-DNFI_PLANEWISE=1', '-DNFI_RENDER_OCC=3'],
             'occ3': ['-DNFI_PLANEWISE=0', '-DNFI_RENDER_OCC=3'],
             'pw_scalar': ['-DNFI_PLANEWISE=1', '-DNFI_SCALAR_RAY=1'],
             'pw_scalar_single': ['-DNFI_PLANEWISE=1', '-DNFI_SCALAR_RAY=1', '-DNFI_TILE_PAIR=0'],
