@@ -492,6 +492,55 @@ __device__ __forceinline__ void tile_bilinear(const TileTex<TEX>& T, float fx, f
   }
 }
 
+// fp16 texel storage: the texels stay PACKED (48 registers instead of 96) and the blend reads each half in place with
+// v_fma_mix_f32 - fma(w, float(texel), acc) in one instruction, the same arithmetic as conversion + fma - so 16-bit
+// storage costs no conversion instructions (round 2-3: 96 v_cvt_f32_f16 per tile on top of the blend made fp16 texels
+// slower than fp32 ones in an instruction-bound kernel).  (gfx950 has no bf16 form of the instruction.)
+#ifndef NFI_FP16_MIX
+#define NFI_FP16_MIX 1
+#endif
+#if NFI_FP16_MIX
+template <>
+struct TileTex<2> {
+  uint32_t r[3][4][4];
+};
+template <>
+__device__ __forceinline__ void tile_issue<2>(const FieldParams& P, int g, uint32_t xi, TileTex<2>& T) {
+  const uint32_t x0 = xi & 1023u, y0 = (xi >> 10) & 1023u, z0 = (xi >> 20) & 1023u;
+#pragma unroll
+  for (int pl = 0; pl < 3; ++pl) {
+    const uint32_t a0 = (pl == 2) ? y0 : x0, b0 = (pl == 0) ? y0 : z0;
+    const uint32_t voff = (uint32_t)pl * P.plane_bytes + __umul24(b0 * (uint32_t)P.res + a0, P.pix_bytes) + (uint32_t)g * 16u;
+    const uint32_t soff[4] = {0u, P.pix_bytes, P.row_bytes, P.row_pix_bytes};
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const u32x4 a = __builtin_amdgcn_raw_buffer_load_b128(P.rsrc, voff, soff[c], 0);
+      T.r[pl][c][0] = a.x; T.r[pl][c][1] = a.y; T.r[pl][c][2] = a.z; T.r[pl][c][3] = a.w;
+    }
+  }
+}
+template <>
+__device__ __forceinline__ void tile_bilinear<2>(const TileTex<2>& T, float fx, float fy, float fz, float (&feat)[8]) {
+#pragma unroll
+  for (int s = 0; s < 8; ++s) feat[s] = 0.0f;
+#pragma unroll
+  for (int pl = 0; pl < 3; ++pl) {
+    const float fa = (pl == 2) ? fy : fx;
+    const float fb = (pl == 0) ? fy : fz;
+    const float ga = 1.0f - fa, gb = 1.0f - fb;
+    const float w[4] = {ga * gb, fa * gb, ga * fb, fa * fb};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[0,1,0]" : "+v"(feat[2 * i]) : "v"(w[c]), "v"(T.r[pl][c][i]));
+        asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[0,1,0] op_sel_hi:[0,1,0]" : "+v"(feat[2 * i + 1]) : "v"(w[c]), "v"(T.r[pl][c][i]));
+      }
+    }
+  }
+}
+#endif
+
 // The same gather + blend one plane at a time (identical arithmetic and order: plane 0, 1, 2; corners 00, 10, 01, 11).
 template <int TEX>
 __device__ __forceinline__ void tile_gather_planewise(const FieldParams& P, int g, uint32_t xi, float fx, float fy, float fz,
