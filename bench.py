@@ -192,6 +192,9 @@ def extras(dev, ops):
         'b8_chairs_fp32_texels': (8, RADIUS, ops.TEXEL_F32, {}),
         'b8_all_rays_hit_fp32_texels': (8, 1.3, ops.TEXEL_F32, {}),
         'b8_chairs_bf16_texels': (8, RADIUS, ops.TEXEL_BF16, {}),
+        # fp16 plane storage (fp32 arithmetic): packed texels blended with v_fma_mix_f32, three blocks per CU
+        'b8_chairs_fp16_texels': (8, RADIUS, ops.TEXEL_F16, {}),
+        'b8_all_rays_hit_fp16_texels': (8, 1.3, ops.TEXEL_F16, {}),
         # the same kernels with the decoder MLP on exact-fp32 MFMA (v_mfma_f32_16x16x4_f32) instead of split fp16
         'b8_chairs_fp32_texels_mlp_exact_fp32': (8, RADIUS, ops.TEXEL_F32, {'tuning': 8}),
         'b8_all_rays_hit_fp32_texels_mlp_exact_fp32': (8, 1.3, ops.TEXEL_F32, {'tuning': 8}),

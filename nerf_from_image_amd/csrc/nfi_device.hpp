@@ -495,7 +495,9 @@ __device__ __forceinline__ void tile_bilinear(const TileTex<TEX>& T, float fx, f
 // fp16 texel storage: the texels stay PACKED (48 registers instead of 96) and the blend reads each half in place with
 // v_fma_mix_f32 - fma(w, float(texel), acc) in one instruction, the same arithmetic as conversion + fma - so 16-bit
 // storage costs no conversion instructions (round 2-3: 96 v_cvt_f32_f16 per tile on top of the blend made fp16 texels
-// slower than fp32 ones in an instruction-bound kernel).  (gfx950 has no bf16 form of the instruction.)
+// slower than fp32 ones in an instruction-bound kernel).  (gfx950 has no bf16 form of the instruction; a packed bf16 tile
+// with the widening shifts at the blend was tried: the compiler widens early anyway - 219 registers, 220 B of scratch when
+// capped at 168 - so bf16 texels stay converted at load time, two blocks per CU.)
 #ifndef NFI_FP16_MIX
 #define NFI_FP16_MIX 1
 #endif

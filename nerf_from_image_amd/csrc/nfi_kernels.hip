@@ -2074,10 +2074,13 @@ extern "C" int nfi_render_fwd(const nfi_render_args* a, nfi_stream_t stream) {
   // persistent 1-D grid: OCC blocks of 4 waves per CU, never more blocks than rays need
   // 2 blocks (8 waves) per CU: with the whole 256-VGPR budget the field tile keeps more loads and MFMA chains in
   // flight than at 3 blocks/CU (MI355X, 8 x 128^2: 0.96 vs 1.01-1.08 ms; 4 blocks/CU spill: 1.52 ms)
+  // (fp16 texel storage, plain inference: the texels stay packed - 168 registers - and THREE blocks per CU fit without a
+  //  spill: 0.705 vs 0.756 ms at 8 x 128^2, every ray hits 1.040 vs 1.174 ms)
   const int occ = NFI_RENDER_OCC;
-  int64_t blocks = (int64_t)256 * occ;
+  int64_t blocks = (int64_t)256 * occ, blocks3 = (int64_t)256 * 3;
   if (blocks > (n + 3) / 4) blocks = (n + 3) / 4;
-  dim3 grid((unsigned)blocks);
+  if (blocks3 > (n + 3) / 4) blocks3 = (n + 3) / 4;
+  dim3 grid((unsigned)blocks), grid3((unsigned)blocks3);
   bool att = a->n_attention > 0;
   if (a->event_start) (void)hipEventRecord((hipEvent_t)a->event_start, s);
   const bool strict = ((a->tuning >> 3) & 1) != 0;   // exact-fp32 MLP instead of the split-fp16 one
@@ -2088,6 +2091,7 @@ extern "C" int nfi_render_fwd(const nfi_render_args* a, nfi_stream_t stream) {
     else if (any_tap && strict) hipLaunchKernelGGL((render_fwd_kernel<TEX, ATT, NFI_RENDER_OCC, true, 0>), grid, dim3(256), 0, s, k); \
     else if (any_tap) hipLaunchKernelGGL((render_fwd_kernel<TEX, ATT, NFI_RENDER_OCC, true, 1>), grid, dim3(256), 0, s, k);          \
     else if (strict) hipLaunchKernelGGL((render_fwd_kernel<TEX, ATT, NFI_RENDER_OCC, false, 0>), grid, dim3(256), 0, s, k);          \
+    else if (TEX == 2 && NFI_FP16_MIX) hipLaunchKernelGGL((render_fwd_kernel<2, ATT, 3, false, 1>), grid3, dim3(256), 0, s, k);        \
     else hipLaunchKernelGGL((render_fwd_kernel<TEX, ATT, NFI_RENDER_OCC, false, 1>), grid, dim3(256), 0, s, k);                      \
   } while (0)
 #define NFI_LAUNCH_RENDER_WIDE(TEX, ATT)                                                                             \

@@ -1,6 +1,10 @@
+"""Render time with fp32 / fp16 / bf16 texel storage (NFI_PROBE_LIBRARY selects a variant build)."""
 import os, sys
-sys.path.insert(0, os.getcwd())
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch, bench
+from nerf_from_image_amd import _lib
+if os.environ.get('NFI_PROBE_LIBRARY'):
+    _lib.LIBRARY = os.environ['NFI_PROBE_LIBRARY']
 from nerf_from_image_amd import ops
 dev = torch.device('cuda:0')
 for name, (n, rad, dt, kw) in {'cfg2_b8_fp32': (8, bench.RADIUS, ops.TEXEL_F32, {}), 'cfg2_b8_fp16': (8, bench.RADIUS, ops.TEXEL_F16, {}),
