@@ -571,7 +571,11 @@ __device__ __forceinline__ void tile_gather_planewise(const FieldParams& P, int 
       acc = fmaf(w11, tv[3][s], acc);
       feat[s] = acc;
     }
-    __builtin_amdgcn_sched_barrier(0);       // keep the next plane's loads from being hoisted above this blend
+    // Pin the order: without it the IR optimiser sinks this plane's (pure) arithmetic below the next planes' loads - all
+    // 24 loads then go out first and the 96 texel registers are back (what the round-3 'plane-wise' experiments actually
+    // measured).  The empty volatile asm makes the eight sums exist here, its memory clobber keeps the next loads behind it.
+    asm volatile("" : "+v"(feat[0]), "+v"(feat[1]), "+v"(feat[2]), "+v"(feat[3]), "+v"(feat[4]), "+v"(feat[5]), "+v"(feat[6]), "+v"(feat[7]) : : "memory");
+    __builtin_amdgcn_sched_barrier(0);       // (and the machine scheduler from undoing it)
   }
 }
 
