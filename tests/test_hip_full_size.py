@@ -138,7 +138,8 @@ def _count_differences(run, n, keys):
     return int(bad), int(launches)
 
 
-@pytest.mark.parametrize('case,launches', [('chairs', 1000), ('all_hit', 1000), ('all_hit_density', 300), ('cfg5_fp16', 200)])
+@pytest.mark.parametrize('case,launches', [('chairs', 1000), ('all_hit', 1000), ('all_hit_density', 300), ('cfg5_fp16', 200),
+                                           ('all_hit_fp16', 1000)])
 def test_render_is_bit_reproducible_over_many_launches(gpu_device, case, launches):
     """The workloads bench.py times (8 x 128^2 chairs-like and with every ray crossing the cube, cfg5 256^2 x (128+128)
     with fp16 texels) plus the density branch, launched many times with identical inputs: every output must agree bit
@@ -151,7 +152,10 @@ def test_render_is_bit_reproducible_over_many_launches(gpu_device, case, launche
     res, samples, tdt, n_img = R, S, ops.TEXEL_F32, 8
     if case == 'chairs':
         kw = dict(radius=2.0, seed=6)
-    if case == 'cfg5_fp16':
+    if case == 'all_hit_fp16':
+        # packed fp16 texels blended with v_fma_mix_f32, three workgroups per CU (three waves per SIMD next to the K = 32 MFMA)
+        tdt = ops.TEXEL_F16
+    elif case == 'cfg5_fp16':
         res, samples, tdt, n_img = 256, 128, ops.TEXEL_F16, 2
     d = make_inputs(n_img, gpu_device, R=res, S=samples, **kw)
     texels = ops.planes_to_texels(d['planes'], tdt)
