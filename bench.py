@@ -111,11 +111,14 @@ def stats(xs):
     return {'min': xs[0], 'median': xs[len(xs) // 2], 'max': xs[-1]}
 
 
-def cpu_baseline_and_parity(seed, dev, ops):
+def cpu_baseline_and_parity(seed, dev, ops, texels='fp32'):
     """Oracle (kind 'port': the CPU restatement pinned bit-exactly to the reference) on one image of the workload; the
     same image, same noise, rendered by the timed HIP code path is compared with it (the bench's own parity figure)."""
     from oracle import nfi_oracle as orc
     d = synthetic_inputs(1, seed, 'cpu')
+    if texels != 'fp32':
+        # 16-bit plane storage: the oracle gets the SAME planes the kernels gather from (rounded to the storage type)
+        d['planes'] = d['planes'].to(torch.float16 if texels == 'fp16' else torch.bfloat16).to(torch.float32)
     g = torch.Generator().manual_seed(seed + 1)
     nc = torch.rand(1, R, R, S, generator=g)
     nf = torch.rand(R * R, S, generator=g)
@@ -132,9 +135,10 @@ def cpu_baseline_and_parity(seed, dev, ops):
     base = {'value': R * R / med, 'unit': 'rays/s', 'cores': torch.get_num_threads(), 'kind': 'port',
             'sample': '1 image 128x128, 64+64 samples, planes precomputed (render only), fp32, 1 warm-up + 3 timed runs, median'}
     dd = {k: v.to(dev) for k, v in d.items()}
-    texels = ops.planes_to_texels(dd['planes'])
-    image = ops.decoder_pack(dd['w1'], dd['b1'], dd['w2'], dd['b2'], A)
-    out = ops.render_fwd(dd['cam'], dd['focal'], R, R, S, texels, image, SCENE_RANGE, A, dd['att'], True, dd['beta'],
+    tdt = {'fp32': ops.TEXEL_F32, 'fp16': ops.TEXEL_F16, 'bf16': ops.TEXEL_BF16}[texels]
+    texel_t = ops.planes_to_texels(dd['planes'], tdt)
+    image = ops.decoder_pack(dd['w1'], dd['b1'], dd['w2'], dd['b2'], A, tdt)
+    out = ops.render_fwd(dd['cam'], dd['focal'], R, R, S, texel_t, image, SCENE_RANGE, A, dd['att'], True, dd['beta'],
                          dd['alpha'], noise_coarse=nc.to(dev), noise_fine=nf.to(dev), fine_sampling=True,
                          white_background=True, skip_missed_rays=True)
     # the same image through the oracle evaluated with PyTorch-ROCm ops on this GPU = the reference's own GPU numerics
@@ -149,7 +153,7 @@ def cpu_baseline_and_parity(seed, dev, ops):
     gap = {k: float((ref_gpu[k].cpu() - ref[k]).abs().max()) for k in keys}
     parity = dict(vs_cpu)                    # top-level rgb / depth / mask: against the pinned CPU oracle
     parity.update(budget=1e-4, against='CPU oracle (reference ATen numerics, pinned to the live reference), 1 image of this '
-                                       'workload, same noise',
+                                       'workload, same noise' + ('' if texels == 'fp32' else ', planes rounded to the %s storage' % texels),
                   vs_pytorch_rocm_oracle=vs_gpu, oracle_cpu_vs_pytorch_rocm_gap=gap,
                   ok=bool(max(vs_cpu.values()) <= 1e-4 and all(bool(torch.isfinite(out[k]).all()) for k in keys)),
                   ok_vs_pytorch_rocm=bool(all(vs_gpu[k] <= gap[k] + 1e-4 for k in keys)),
@@ -367,6 +371,10 @@ def main():
     ap.add_argument('--bucket-mb', type=int, default=32, help='train mode: gradient bucket size')
     ap.add_argument('--reduce-mode', choices=('all_reduce', 'reduce_scatter'), default='all_reduce')
     ap.add_argument('--no-overlap', action='store_true', help='train mode: launch the collectives after backward')
+    ap.add_argument('--texels', choices=('fp32', 'fp16', 'bf16'), default='fp32',
+                    help='render mode: storage type of the texels the kernels gather from (arithmetic stays fp32); fp16 is '
+                         'the fast storage: packed texels, three workgroups per CU')
+    ap.add_argument('--pipelined', action='store_true', help='render mode: force the two-stream schedule')
     ap.add_argument('--serial', action='store_true',
                     help='render mode: one stream, every step after the previous one (default: two HIP streams - the next '
                          "step's texel hand-off, decoder pack and noise draws overlap this step's render)")
@@ -407,10 +415,12 @@ def main():
 
     probe = torch.zeros(2, dtype=torch.int64, device=dev)
 
+    tdt = {'fp32': ops.TEXEL_F32, 'fp16': ops.TEXEL_F16, 'bf16': ops.TEXEL_BF16}[args.texels]
+
     def prepare(slot_ws=None):
         """Everything of a step in front of the render kernel: texel hand-off of the producer's planes, decoder operand
         image, the two noise draws, the ray set-up (rays, scene-cube test, miss-fill reduction) into the slot's workspace."""
-        return dict(texels=ops.planes_to_texels(d['planes']), image=ops.decoder_pack(d['w1'], d['b1'], d['w2'], d['b2'], A),
+        return dict(texels=ops.planes_to_texels(d['planes'], tdt), image=ops.decoder_pack(d['w1'], d['b1'], d['w2'], d['b2'], A, tdt),
                     noise_c=torch.rand((B, R, R, S), dtype=torch.float32, device=dev),
                     noise_f=torch.rand([n_rays, S], dtype=torch.float32, device=dev),
                     ws=ops.render_setup(d['cam'], d['focal'], R, R, SCENE_RANGE, workspace=slot_ws))
@@ -491,7 +501,9 @@ def main():
             elapsed = float(t.item())
         return elapsed, per_step, out
 
-    pipelined = not args.serial
+    # default schedule: two streams, except with fp16 texels - that kernel runs three workgroups per CU and leaves the
+    # front of the next step nothing to run on beside it (166 M rays/s pipelined, 173 M serial)
+    pipelined = args.pipelined or not (args.serial or args.texels == 'fp16')
     elapsed, per_step, out = timed(pipelined)
 
     # ---- dominant kernel, timed live with HIP events on its own stream (untimed extra launches) ----
@@ -527,16 +539,19 @@ def main():
                        'mlp': 'split-fp16: decoder MLP operands as fp16 hi+lo pairs (22 significand bits), products '
                               'hi*hi + hi*lo + lo*hi accumulated in fp32 on v_mfma_f32_16x16x32_f16; everything else '
                               'fp32 (exact-fp32 MFMA variant timed in extras.render_only.*_mlp_exact_fp32)',
+                       'texel_storage': args.texels + (' (arithmetic fp32)' if args.texels != 'fp32' else ''),
                        'images_per_gpu': B, 'resolution': R, 'samples': '64+64', 'plane_res': PLANE_RES,
                        'camera_radius': RADIUS, 'scene_range': SCENE_RANGE, 'rays_marched_fraction': marched / n_rays,
                        'skip_missed_rays': not args.no_skip, 'sharding': 'images across ranks, no collective'},
-            'roofline': roofline(kernel_ms, marched, B, live_clock),
+            'roofline': roofline(kernel_ms, marched, B, live_clock) if args.texels == 'fp32' else
+            {'bound': 'valu-issue', 'kernel': 'render_fwd_kernel', 'kernel_ms': kernel_ms, 'frac': None,
+             'note': 'the committed PMC profile is of the fp32-texel kernel; no issue-cycle count for this storage type'},
             'kernel_ms_stats': stats(k_ms),
         }
         if world == 1 and not args.no_extras:
             res['extras'] = extras(dev, ops)      # before the CPU leg: its OpenMP workers keep spinning for a while
         if world == 1 and not args.no_cpu_baseline:
-            res['cpu_baseline'], res['parity'] = cpu_baseline_and_parity(1234, dev, ops)
+            res['cpu_baseline'], res['parity'] = cpu_baseline_and_parity(1234, dev, ops, args.texels)
         else:
             res['cpu_baseline'] = None
         print(json.dumps(res))
