@@ -268,8 +268,8 @@ def extras(dev, ops):
     return ex
 
 
-def load_pmc_profile():
-    for rel in PMC_PROFILES:
+def load_pmc_profile(texels='fp32'):
+    for rel in (PMC_PROFILES if texels == 'fp32' else ('profiles/r3/pmc_render_fwd_%s.json' % texels,)):
         p = os.path.join(ROOT, rel)
         if os.path.exists(p):
             try:
@@ -281,12 +281,12 @@ def load_pmc_profile():
     return None, None
 
 
-def roofline(kernel_ms, marched, n_images, live_clock_hz=None):
+def roofline(kernel_ms, marched, n_images, live_clock_hz=None, texels='fp32'):
     """Roofline object of the fused render kernel (see the module docstring).  live_clock_hz: the shader clock measured
     INSIDE the timed launches (nfi_render_args.clock_probe: s_memtime / s_memrealtime of one persistent wave); the peak
     is priced at it, so that kernel time and clock come from the same run (without it: the profile's own clock)."""
     t = kernel_ms * 1e-3
-    src, prof = load_pmc_profile()
+    src, prof = load_pmc_profile(texels)
     gather_gbs = marched * GATHER_BYTES_PER_RAY / t / 1e9
     compulsory = n_images * (3 * 32 * PLANE_RES * PLANE_RES * 4 + R * R * (2 * S * 4 + 33 + 20))   # planes + noise + ray set-up + outputs
     mlp_tflops = marched * MLP_FLOP_PER_RAY / t / 1e12
@@ -323,6 +323,12 @@ def roofline(kernel_ms, marched, n_images, live_clock_hz=None):
                         'frac': fab / t / 1e9 / HBM_PEAK_GBS, 'x_compulsory': fab / compulsory,
                         'note': 'FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE; Infinity-Cache hits included; WRITE_SIZE '
                                 'is mostly the write-back of the preceding kernels\' dirty lines (texel hand-off, rand)'}
+    any_issue = None
+    if valu_per_ray is not None and ach > peak:
+        # three waves per SIMD (the fp16-texel kernel): the ANY-issue proxy sums ports that overlap between the resident
+        # waves and passes 1 - a roofline has to be a bound, so the fraction is then the vector ALU's own
+        any_issue = {'achieved': ach / 1e9, 'frac': ach / peak, 'note': 'SQ_ACTIVE_INST_ANY x4 per SIMD-cycle: over 1, not a bound'}
+        ach = valu_per_ray * marched / t
     r.update(achieved=ach / 1e9, peak=peak / 1e9, frac=ach / peak, traffic=fab,
              issue_cycles_per_marched_ray=prof['issue_cycles_per_marched_ray'], shader_clock_hz=clk,
              shader_clock_source='live: s_memtime / s_memrealtime of a persistent wave of the timed launches'
@@ -333,7 +339,7 @@ def roofline(kernel_ms, marched, n_images, live_clock_hz=None):
                         'note': 'SQ_ACTIVE_INST_VALU x4: the vector ALU alone; `frac` above also counts LDS / VMEM / SALU '
                                 'issue, which overlaps between the resident waves, so it is a utilisation proxy and this '
                                 'is the binding pipe'},
-             waves_per_simd=prof.get('waves_per_simd'),
+             waves_per_simd=prof.get('waves_per_simd'), any_issue_proxy=any_issue,
              note='instruction-issue bound: SQ_ACTIVE_INST_ANY (x4 cycles) per marched ray from the PMC profile, scaled by '
                   'the live ray count and kernel time, over 1024 SIMDs x the shader clock')
     return r
@@ -543,9 +549,9 @@ def main():
                        'images_per_gpu': B, 'resolution': R, 'samples': '64+64', 'plane_res': PLANE_RES,
                        'camera_radius': RADIUS, 'scene_range': SCENE_RANGE, 'rays_marched_fraction': marched / n_rays,
                        'skip_missed_rays': not args.no_skip, 'sharding': 'images across ranks, no collective'},
-            'roofline': roofline(kernel_ms, marched, B, live_clock) if args.texels == 'fp32' else
-            {'bound': 'valu-issue', 'kernel': 'render_fwd_kernel', 'kernel_ms': kernel_ms, 'frac': None,
-             'note': 'the committed PMC profile is of the fp32-texel kernel; no issue-cycle count for this storage type'},
+            'roofline': roofline(kernel_ms, marched, B, live_clock, args.texels) if load_pmc_profile(args.texels)[1] else
+            {'bound': 'valu-issue', 'kernel': 'render_fwd_kernel', 'kernel_ms': kernel_ms, 'rays_marched_per_launch': marched,
+             'frac': None, 'note': 'no committed PMC profile of the kernel for this texel storage type'},
             'kernel_ms_stats': stats(k_ms),
         }
         if world == 1 and not args.no_extras:
