@@ -16,7 +16,7 @@
 
 // build-time experiment knobs of the fused render kernels (product values below; tools/probes/render_variants.py)
 #ifndef NFI_PLANEWISE
-#define NFI_PLANEWISE 0          // 1: gather + blend one plane at a time (32 instead of 96 texel registers in flight)
+#define NFI_PLANEWISE 0          // 1: gather + blend one plane at a time (32 instead of 96 texel registers in flight); 2: planes 0+1, then 2; 3: tile pairs in three rounds of two planes
 #endif
 #ifndef NFI_TILE_PAIR
 #define NFI_TILE_PAIR 1          // 1: two field tiles go through the decoder MLP together; 0: one at a time
@@ -579,6 +579,55 @@ __device__ __forceinline__ void tile_gather_planewise(const FieldParams& P, int 
   }
 }
 
+// One plane of a tile: the four corner loads, and their blend into the running sums (the arithmetic and its order are
+// those of tile_bilinear: plane 0, 1, 2; corners 00, 10, 01, 11 - every gather form below gives the same bits).
+template <int TEX>
+__device__ __forceinline__ void plane_issue(const FieldParams& P, int g, uint32_t xi, int pl, float (&dst)[4][8]) {
+  const uint32_t x0 = xi & 1023u, y0 = (xi >> 10) & 1023u, z0 = (xi >> 20) & 1023u;
+  const uint32_t a0 = (pl == 2) ? y0 : x0, b0 = (pl == 0) ? y0 : z0;
+  const uint32_t voff = (uint32_t)pl * P.plane_bytes + __umul24(b0 * (uint32_t)P.res + a0, P.pix_bytes) + (uint32_t)g * 16u;
+  load_texel8<TEX>(P, voff, 0, 0, dst[0]);
+  load_texel8<TEX>(P, voff, P.pix_bytes, 0, dst[1]);
+  load_texel8<TEX>(P, voff, P.row_bytes, 0, dst[2]);
+  load_texel8<TEX>(P, voff, P.row_pix_bytes, 0, dst[3]);
+}
+__device__ __forceinline__ void plane_blend(int pl, float fx, float fy, float fz, const float (&src)[4][8], float (&feat)[8]) {
+  const float fa = (pl == 2) ? fy : fx, fb = (pl == 0) ? fy : fz;
+  const float ga = 1.0f - fa, gb = 1.0f - fb;
+  const float w00 = ga * gb, w10 = fa * gb, w01 = ga * fb, w11 = fa * fb;
+#pragma unroll
+  for (int s = 0; s < 8; ++s) {
+    float acc = feat[s];
+    acc = fmaf(w00, src[0][s], acc);
+    acc = fmaf(w10, src[1][s], acc);
+    acc = fmaf(w01, src[2][s], acc);
+    acc = fmaf(w11, src[3][s], acc);
+    feat[s] = acc;
+  }
+}
+// the running sums exist HERE and later loads stay behind them (see tile_gather_planewise)
+__device__ __forceinline__ void pin_sums(float (&feat)[8]) {
+  asm volatile("" : "+v"(feat[0]), "+v"(feat[1]), "+v"(feat[2]), "+v"(feat[3]), "+v"(feat[4]), "+v"(feat[5]), "+v"(feat[6]), "+v"(feat[7]) : : "memory");
+  __builtin_amdgcn_sched_barrier(0);
+}
+
+// Two rounds: planes 0 and 1 in flight together (64 texel registers), then plane 2 (32).  One dependent gather round
+// trip fewer per tile than plane by plane, 32 registers fewer than all at once.
+template <int TEX>
+__device__ __forceinline__ void tile_gather_two_rounds(const FieldParams& P, int g, uint32_t xi, float fx, float fy, float fz,
+                                                       float (&feat)[8]) {
+  float tv[2][4][8];
+#pragma unroll
+  for (int s = 0; s < 8; ++s) feat[s] = 0.0f;
+  plane_issue<TEX>(P, g, xi, 0, tv[0]);
+  plane_issue<TEX>(P, g, xi, 1, tv[1]);
+  plane_blend(0, fx, fy, fz, tv[0], feat);
+  plane_blend(1, fx, fy, fz, tv[1], feat);
+  pin_sums(feat);
+  plane_issue<TEX>(P, g, xi, 2, tv[0]);
+  plane_blend(2, fx, fy, fz, tv[0], feat);
+}
+
 // density / colour epilogue on the decoder outputs o (lane (g,j): rows 4g..4g+3 of point j; row 0 =
 // distance/density, rows 1.. = colour logits pre-scaled by log2e)
 template <bool ATT, int N>
@@ -1003,7 +1052,9 @@ __device__ __forceinline__ SampleOut field_wave(const FieldParams& P, float scen
     const uint32_t cxi = (uint32_t)__shfl(xi, srcL, 64);
     const int fcur = __shfl(flags, srcM, 64);
     float featL[8];
-#if NFI_PLANEWISE
+#if NFI_PLANEWISE >= 2
+    tile_gather_two_rounds<TEX>(P, lq, cxi, cfx, cfy, cfz, featL);
+#elif NFI_PLANEWISE
     // one plane at a time: 8 loads (32 texel registers) in flight instead of 24 (96) - the register budget of three
     // waves per SIMD (experiment of round 3)
     tile_gather_planewise<TEX>(P, lq, cxi, cfx, cfy, cfz, featL);
@@ -1053,6 +1104,67 @@ __device__ __forceinline__ SampleOut field_wave(const FieldParams& P, float scen
     const int tb = pair ? __builtin_ctz(tm) : ta;
     tm &= tm - 1;                                 // (no-op when tm is already 0)
     float feat[2][8];
+#if NFI_PLANEWISE == 3
+    // a PAIR of tiles in three rounds of two planes each (64 texel registers in flight throughout): A0 A1 | A2 B0 | B1 B2 -
+    // 1.5 dependent gather round trips per tile, and tile A's transpose rides under the third round
+    int fa, fb;
+    if (pair) {
+      const int srcA = 16 * ta + lp, srcB = 16 * tb + lp;
+      const float ax = __shfl(fx, srcA, 64), ay = __shfl(fy, srcA, 64), az = __shfl(fz, srcA, 64);
+      const uint32_t axi = (uint32_t)__shfl(xi, srcA, 64);
+      const float bx = __shfl(fx, srcB, 64), by = __shfl(fy, srcB, 64), bz = __shfl(fz, srcB, 64);
+      const uint32_t bxi = (uint32_t)__shfl(xi, srcB, 64);
+      fa = __shfl(flags, 16 * ta + j, 64);
+      fb = __shfl(flags, 16 * tb + j, 64);
+      float tv[2][4][8], fA[8], fB[8];
+#pragma unroll
+      for (int s8 = 0; s8 < 8; ++s8) { fA[s8] = 0.0f; fB[s8] = 0.0f; }
+      plane_issue<TEX>(P, lq, axi, 0, tv[0]);
+      plane_issue<TEX>(P, lq, axi, 1, tv[1]);
+      plane_blend(0, ax, ay, az, tv[0], fA);
+      plane_blend(1, ax, ay, az, tv[1], fA);
+      pin_sums(fA);
+      plane_issue<TEX>(P, lq, axi, 2, tv[0]);
+      plane_issue<TEX>(P, lq, bxi, 0, tv[1]);
+      plane_blend(2, ax, ay, az, tv[0], fA);
+      plane_blend(0, bx, by, bz, tv[1], fB);
+      pin_sums(fA);
+      pin_sums(fB);
+      plane_issue<TEX>(P, lq, bxi, 1, tv[0]);
+      plane_issue<TEX>(P, lq, bxi, 2, tv[1]);
+      {
+        f32x4* wr = reinterpret_cast<f32x4*>(stage + lp * 36 + lq * 4);
+        wr[0] = f32x4{fA[0], fA[1], fA[2], fA[3]};
+        wr[4] = f32x4{fA[4], fA[5], fA[6], fA[7]};
+        wave_lds_fence();
+        const f32x4* rd = reinterpret_cast<const f32x4*>(stage + j * 36 + g * 4);
+        const f32x4 lo = rd[0], hi = rd[4];
+        feat[0][0] = lo.x; feat[0][1] = lo.y; feat[0][2] = lo.z; feat[0][3] = lo.w;
+        feat[0][4] = hi.x; feat[0][5] = hi.y; feat[0][6] = hi.z; feat[0][7] = hi.w;
+        wave_lds_fence();
+      }
+      plane_blend(1, bx, by, bz, tv[0], fB);
+      plane_blend(2, bx, by, bz, tv[1], fB);
+      __builtin_amdgcn_sched_barrier(0);
+      {
+        f32x4* wr = reinterpret_cast<f32x4*>(stage + lp * 36 + lq * 4);
+        wr[0] = f32x4{fB[0], fB[1], fB[2], fB[3]};
+        wr[4] = f32x4{fB[4], fB[5], fB[6], fB[7]};
+        wave_lds_fence();
+        const f32x4* rd = reinterpret_cast<const f32x4*>(stage + j * 36 + g * 4);
+        const f32x4 lo = rd[0], hi = rd[4];
+        feat[1][0] = lo.x; feat[1][1] = lo.y; feat[1][2] = lo.z; feat[1][3] = lo.w;
+        feat[1][4] = hi.x; feat[1][5] = hi.y; feat[1][6] = hi.z; feat[1][7] = hi.w;
+        wave_lds_fence();
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    } else {
+      fa = gather_tile(ta, feat[0]);
+      fb = fa;
+#pragma unroll
+      for (int s8 = 0; s8 < 8; ++s8) feat[1][s8] = feat[0][s8];
+    }
+#else
     const int fa = gather_tile(ta, feat[0]);
     int fb = fa;
     if (pair) {
@@ -1061,6 +1173,7 @@ __device__ __forceinline__ SampleOut field_wave(const FieldParams& P, float scen
 #pragma unroll
       for (int s8 = 0; s8 < 8; ++s8) feat[1][s8] = feat[0][s8];
     }
+#endif
     unsigned long long c2 = prof ? __builtin_readcyclecounter() : 0;
     const float outs[2] = {(fa & 1) ? 1.0f : 0.0f, (fb & 1) ? 1.0f : 0.0f};
     float* const sems[2] = {

@@ -1447,6 +1447,17 @@ struct RayQueue {
 // first coarse sample whose transmittance fell below eps are dropped from the field query (sigma = 0, they stay in
 // the merge), and the surviving ones are compacted to the low lanes (wave ballot + popcount), so that whole 16-point
 // tiles disappear.  The exact path never takes these branches.
+// NFI_LEAN_RAY (register budget of a third wave per SIMD, tools/vgpr_liveness.py): every stage of a ray derives its
+// lane-dependent addresses from its OWN copy of the lane id, made opaque to the optimiser - otherwise ~27 loop-invariant
+// address values are hoisted out of the ray loop and held in registers across both gathers.
+#ifndef NFI_LEAN_RAY
+#define NFI_LEAN_RAY 0
+#endif
+#if NFI_LEAN_RAY
+#define NFI_STAGE_LANE(name) int name = lane; asm volatile("" : "+v"(name))
+#else
+#define NFI_STAGE_LANE(name) const int name = lane
+#endif
 template <int TEX, bool ATT, int OCC, bool TAPS, int PREC, bool PROF = false, bool VD = false, bool FAST = false>
 __global__ __launch_bounds__(256, OCC) void render_fwd_kernel(RenderKernelParams k) {
   constexpr int kImg = VD ? kVdImageFloats : kLdsImageFloats;
@@ -1491,13 +1502,14 @@ __global__ __launch_bounds__(256, OCC) void render_fwd_kernel(RenderKernelParams
   int cur_scene = -1;
 
   auto load_inputs = [&](uint32_t ray, RayInputs& in) {
+    NFI_STAGE_LANE(l_in);          // (the noise addresses are rebuilt per ray, not held across it)
     const size_t r3 = (size_t)ray * 3;
     in.hit = k.hit[ray];
     in.ox = k.ro[r3]; in.oy = k.ro[r3 + 1]; in.oz = k.ro[r3 + 2];
     in.dx = k.rd[r3]; in.dy = k.rd[r3 + 1]; in.dz = k.rd[r3 + 2];
     in.near = k.near_raw[ray]; in.far = k.far_raw[ray];
-    in.noise = (k.noise_c && valid) ? k.noise_c[(size_t)ray * S + lane] : 0.0f;
-    in.u = (k.fine && valid) ? k.noise_f[(size_t)ray * k.noise_f_stride + lane] : 0.0f;
+    in.noise = (k.noise_c && valid) ? k.noise_c[(size_t)ray * S + l_in] : 0.0f;
+    in.u = (k.fine && valid) ? k.noise_f[(size_t)ray * k.noise_f_stride + l_in] : 0.0f;
   };
 
   // ray indices: cur (being marched), nxt (inputs being loaded), and one more in flight
@@ -1563,7 +1575,8 @@ __global__ __launch_bounds__(256, OCC) void render_fwd_kernel(RenderKernelParams
 
       // ---- coarse pass ----
       float tc = 0.0f;
-      if (valid) tc = stratified_depth(near, far, lane, S, in.noise, k.noise_c != nullptr);
+      NFI_STAGE_LANE(l_c);
+      if (valid) tc = stratified_depth(near, far, l_c, S, in.noise, k.noise_c != nullptr);
       MergeIn c;
       unsigned long long t1 = PROF ? __builtin_readcyclecounter() : 0;
       float od_c = 0.0f;      // FAST: optical depth sigma * delta of this lane's coarse sample
@@ -1583,7 +1596,7 @@ __global__ __launch_bounds__(256, OCC) void render_fwd_kernel(RenderKernelParams
         c.t = tc; c.sigma = valid ? q.sigma : 0.0f; c.r = q.r; c.g = q.g; c.b = q.b;
         od_c = c.sigma * dl;
       } else {
-        SampleOut q = field_wave<TEX, ATT, true, PREC, VD>(P, k.scene_range, lane, ox + dx * tc, oy + dy * tc, oz + dz * tc, valid,
+        SampleOut q = field_wave<TEX, ATT, true, PREC, VD>(P, k.scene_range, l_c, ox + dx * tc, oy + dy * tc, oz + dz * tc, valid,
                                                      nullptr, nullptr, &slab.srt[0][0], PROF ? pc : nullptr, k.xray, (int)ray);
         c.t = tc; c.sigma = q.sigma; c.r = q.r; c.g = q.g; c.b = q.b;
       }
@@ -1592,7 +1605,8 @@ __global__ __launch_bounds__(256, OCC) void render_fwd_kernel(RenderKernelParams
       unsigned long long t2 = PROF ? __builtin_readcyclecounter() : 0, t3 = t2, t4 = t2, t5 = t2;
       if (k.fine) {
         // ---- hierarchical resampling + fine pass ----
-        float tf = resample_ray(slab, c.sigma, tc, S, dnorm, in.u, lane, nullptr);
+        NFI_STAGE_LANE(l_r);
+        float tf = resample_ray(slab, c.sigma, tc, S, dnorm, in.u, l_r, nullptr);
         MergeIn f;
         if (PROF) { asm volatile("" :: "v"(tf)); t3 = __builtin_readcyclecounter(); }
         if constexpr (FAST) {
@@ -1617,7 +1631,8 @@ __global__ __launch_bounds__(256, OCC) void render_fwd_kernel(RenderKernelParams
                                                              nullptr, nullptr, &slab.srt[0][0], nullptr, k.xray, (int)ray);
           f.t = tf; f.sigma = vf ? q.sigma : 0.0f; f.r = vf ? q.r : 0.0f; f.g = vf ? q.g : 0.0f; f.b = vf ? q.b : 0.0f;
         } else {
-          SampleOut q = field_wave<TEX, ATT, true, PREC, VD>(P, k.scene_range, lane, ox + dx * tf, oy + dy * tf, oz + dz * tf, valid,
+          NFI_STAGE_LANE(l_f);
+          SampleOut q = field_wave<TEX, ATT, true, PREC, VD>(P, k.scene_range, l_f, ox + dx * tf, oy + dy * tf, oz + dz * tf, valid,
                                                        nullptr, nullptr, &slab.srt[0][0], PROF ? pc : nullptr, k.xray, (int)ray);
           f.t = tf; f.sigma = q.sigma; f.r = q.r; f.g = q.g; f.b = q.b;
         }
@@ -1630,14 +1645,16 @@ __global__ __launch_bounds__(256, OCC) void render_fwd_kernel(RenderKernelParams
         }
         n = 2 * S;
         if (PROF) t4 = __builtin_readcyclecounter();
-        merge_pair_scatter(slab, c, f, S, lane, rank_c, rank_f);
+        NFI_STAGE_LANE(l_m);
+        merge_pair_scatter(slab, c, f, S, l_m, rank_c, rank_f);
         if (PROF) t5 = __builtin_readcyclecounter();
       } else {
         if (valid) { slab.srt[0][lane] = c.t; slab.srt[1][lane] = c.sigma; slab.srt[2][lane] = c.r; slab.srt[3][lane] = c.g; slab.srt[4][lane] = c.b; }
         wave_lds_fence();
       }
       float w[2];
-      CompositeOut o = composite_slab<2>(slab, n, dnorm, k.white, lane, w);
+      NFI_STAGE_LANE(l_o);
+      CompositeOut o = composite_slab<2>(slab, n, dnorm, k.white, l_o, w);
       if (lane == 0) {
         k.rgb[(size_t)ray * 3] = o.r; k.rgb[(size_t)ray * 3 + 1] = o.g; k.rgb[(size_t)ray * 3 + 2] = o.b;
         k.depth[ray] = o.depth; k.mask[ray] = o.mask;
@@ -1686,6 +1703,11 @@ __global__ __launch_bounds__(256, OCC) void render_fwd_kernel(RenderKernelParams
   clock.stop(k);
 }
 
+#ifdef NFI_SINGLE_KERNEL
+// register-budget work (tools/vgpr_liveness.py): compile ONLY the plain inference kernel of one texel storage type -
+// hipcc -S --cuda-device-only -DNFI_SINGLE_KERNEL=<TEX> -DNFI_RENDER_OCC=<waves per SIMD> ... - seconds instead of minutes
+template __global__ void render_fwd_kernel<NFI_SINGLE_KERNEL, true, NFI_RENDER_OCC, false, 1>(RenderKernelParams);
+#else
 // The same pipeline for 64 < S <= 128 samples per pass (BASELINE cfg5, ray_multiplier=2): every lane
 // owns two coarse and two fine samples (element e = slot*64 + lane), the field is marched 64 points
 // at a time, and the merge ranks all 2S keys against each other.
@@ -2136,3 +2158,4 @@ extern "C" int nfi_render_fwd(const nfi_render_args* a, nfi_stream_t stream) {
   if (a->event_stop) (void)hipEventRecord((hipEvent_t)a->event_stop, s);
   return check_launch("render_fwd");
 }
+#endif  // NFI_SINGLE_KERNEL

@@ -9,6 +9,8 @@
     occ3        all loads in flight, 3 workgroups per CU (the compiler has to fit 168 VGPRs)
     pw_scalar   pw_occ2 + the marched ray's origin / direction / near / far in scalar registers
     pw_scalar_single(_occ3)   + one field tile at a time through the decoder MLP (half the accumulators)
+    lean_pw_occ3 / two_rounds_occ3 / pair3_occ3   stage-local lane ids + plane by plane / planes 0+1 then 2 / tile pairs in
+                three rounds of two planes, 3 workgroups per CU          (NFI_VARIANT_SKIP=cfg5_b2 skips a case)
 """
 import os
 import subprocess
@@ -25,6 +27,11 @@ VARIANTS = {'prev': None,      # a library built from an earlier tree, dropped i
             'sched_max_ilp': ['-mllvm', '-amdgpu-sched-strategy=max-ilp'],
             'sched_max_clause': ['-mllvm', '-amdgpu-sched-strategy=max-memory-clause'],
             'no_slp': ['-fno-slp-vectorize'], 'reg_occ2': ['-DNFI_REG_OCC=2'], 'split_mix': ['-DNFI_SPLIT_MIX=1'], 'merge_cmp': ['-DNFI_MERGE_HIST=0'],
+            # end of round 3: stage-local lane ids (NFI_LEAN_RAY) + gathers that keep 64 texel registers in flight, three
+            # workgroups per CU without a spill inside the ray loop (tools/vgpr_liveness.py)
+            'lean_pw_occ3': ['-DNFI_PLANEWISE=1', '-DNFI_LEAN_RAY=1', '-DNFI_RENDER_OCC=3'],
+            'two_rounds_occ3': ['-DNFI_PLANEWISE=2', '-DNFI_LEAN_RAY=1', '-DNFI_RENDER_OCC=3'],
+            'pair3_occ3': ['-DNFI_PLANEWISE=3', '-DNFI_LEAN_RAY=1', '-DNFI_RENDER_OCC=3'],
             'pw_scalar_single_occ3': ['-DNFI_PLANEWISE=1', '-DNFI_SCALAR_RAY=1', '-DNFI_TILE_PAIR=0', '-DNFI_RENDER_OCC=3']}
 
 
@@ -62,6 +69,8 @@ def run(names, iters=60):
         ref = None
         for case, (n_img, radius, kw) in {'chairs_b8': (8, bench.RADIUS, {}), 'all_hit_b8': (8, 1.3, {}), 'chairs_b1': (1, bench.RADIUS, {}),
                                           'cfg5_b2': (2, bench.RADIUS, {'R': 256, 'S': 128})}.items():
+            if case in os.environ.get('NFI_VARIANT_SKIP', '').split(','):
+                continue
             r, out = bench.time_render(ops, dev, n_img, radius, ops.TEXEL_F32, iters=iters, **kw)
             res[case] = r['ms']['median']
             res[case + '_sum'] = float(out['rgb'].double().sum())
