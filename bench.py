@@ -381,6 +381,11 @@ def main():
                     help='render mode: storage type of the texels the kernels gather from (arithmetic stays fp32); fp16 is '
                          'the fast storage: packed texels, three workgroups per CU')
     ap.add_argument('--pipelined', action='store_true', help='render mode: force the two-stream schedule')
+    ap.add_argument('--prefetch-depth', type=int, default=2,
+                    help='render mode, two-stream schedule: how many steps ahead the front of a step is prepared '
+                         '(slots = depth + 1).  The persistent render kernel leaves the other stream few CU slots, so a front '
+                         'started one step ahead tends to finish only as that render drains and the next render waits for '
+                         'it; two steps ahead it never does (146 -> 150 M rays/s)')
     ap.add_argument('--serial', action='store_true',
                     help='render mode: one stream, every step after the previous one (default: two HIP streams - the next '
                          "step's texel hand-off, decoder pack and noise draws overlap this step's render)")
@@ -452,9 +457,9 @@ def main():
     prep_stream = torch.cuda.Stream(device=dev)
 
     def run_steps(n, pipelined, marks=None, timed_kernel=False, after=None):
-        """n steps.  Serial: one stream.  Pipelined: the front of step i + 1 runs on a second HIP stream while step i
-        renders (two slots; a slot is refilled only after the render that read it has finished).  Every step does all of
-        its work either way."""
+        """n steps.  Serial: one stream.  Pipelined: the front of step i + depth runs on a second HIP stream while step i
+        renders (depth + 1 slots; a slot is refilled only after the render that read it has finished).  Every step does
+        all of its work either way."""
         main = torch.cuda.current_stream(dev)
         if not pipelined:
             for i in range(n):
@@ -464,10 +469,11 @@ def main():
                 if after is not None:
                     after()
             return out
-        slots = [{}, {}]
+        depth = max(1, args.prefetch_depth)
+        slots = [{} for _ in range(depth + 1)]
 
         def fill(i):
-            slot = slots[i % 2]
+            slot = slots[i % (depth + 1)]
             with torch.cuda.stream(prep_stream):
                 if 'done' in slot:
                     prep_stream.wait_event(slot['done'])
@@ -475,11 +481,12 @@ def main():
                 slot['ready'] = torch.cuda.Event()
                 slot['ready'].record(prep_stream)
         prep_stream.wait_stream(main)
-        fill(0)
+        for j in range(min(depth, n)):
+            fill(j)
         for i in range(n):
-            if i + 1 < n:
-                fill(i + 1)
-            slot = slots[i % 2]
+            if i + depth < n:
+                fill(i + depth)
+            slot = slots[i % (depth + 1)]
             main.wait_event(slot['ready'])
             out = render(slot['pre'], timed_kernel)
             slot['done'] = torch.cuda.Event()
@@ -535,8 +542,9 @@ def main():
             'metric': 'rendered rays/sec (128x128, 64+64 samples)', 'value': value, 'unit': 'rays/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': elapsed / args.steps * 1e3,
             'ms_per_step_stats': stats(per_step),
-            'schedule': ('two HIP streams: texel hand-off + decoder pack + noise draws + ray set-up of step i+1 overlap the '
-                         'render kernel of step i (double-buffered; every step does all of its work)') if pipelined else 'one stream, serial steps',
+            'schedule': ('two HIP streams: texel hand-off + decoder pack + noise draws + ray set-up of step i+%d overlap the '
+                         'render kernel of step i (%d slots; every step does all of its work)'
+                         % (max(1, args.prefetch_depth), max(1, args.prefetch_depth) + 1)) if pipelined else 'one stream, serial steps',
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
             'config': {'workload': 'cfg2: shapenet_chairs-like forward render, %d images/GPU, 128x128 rays/image, '
                                    '64 coarse + 64 fine samples, 3x256x256x32 fp32 triplanes, SDF decoder, A=10; '

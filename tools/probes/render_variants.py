@@ -29,6 +29,7 @@ VARIANTS = {'prev': None,      # a library built from an earlier tree, dropped i
             'no_slp': ['-fno-slp-vectorize'], 'reg_occ2': ['-DNFI_REG_OCC=2'], 'split_mix': ['-DNFI_SPLIT_MIX=1'], 'merge_cmp': ['-DNFI_MERGE_HIST=0'],
             # end of round 3: stage-local lane ids (NFI_LEAN_RAY) + gathers that keep 64 texel registers in flight, three
             # workgroups per CU without a spill inside the ray loop (tools/vgpr_liveness.py)
+            'lean': ['-DNFI_LEAN_RAY=1'],
             'lean_pw_occ3': ['-DNFI_PLANEWISE=1', '-DNFI_LEAN_RAY=1', '-DNFI_RENDER_OCC=3'],
             'two_rounds_occ3': ['-DNFI_PLANEWISE=2', '-DNFI_LEAN_RAY=1', '-DNFI_RENDER_OCC=3'],
             'pair3_occ3': ['-DNFI_PLANEWISE=3', '-DNFI_LEAN_RAY=1', '-DNFI_RENDER_OCC=3'],
