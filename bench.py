@@ -386,6 +386,12 @@ def main():
                          '(slots = depth + 1).  The persistent render kernel leaves the other stream few CU slots, so a front '
                          'started one step ahead tends to finish only as that render drains and the next render waits for '
                          'it; two steps ahead it never does (146 -> 150 M rays/s)')
+    ap.add_argument('--render-streams', type=int, default=None,
+                    help='render mode, pipelined schedule: consecutive render kernels alternate over this many streams, so '
+                         'that the first workgroups of step i+1 take the slots the draining step i frees.  Default 1 with '
+                         'fp32 / bf16 texels (2: 143 vs 151 M rays/s), 2 with fp16 texels (that kernel fills every slot of '
+                         'the chip: with one render stream the front of the next steps only runs between renders - 166 M '
+                         'pipelined, 173 M serial, 180 M with two)')
     ap.add_argument('--serial', action='store_true',
                     help='render mode: one stream, every step after the previous one (default: two HIP streams - the next '
                          "step's texel hand-off, decoder pack and noise draws overlap this step's render)")
@@ -455,6 +461,8 @@ def main():
         torch.cuda.synchronize()
 
     prep_stream = torch.cuda.Stream(device=dev)
+    n_render_streams = args.render_streams or (2 if args.texels == 'fp16' else 1)
+    render_streams = [torch.cuda.current_stream(dev)] + [torch.cuda.Stream(device=dev) for _ in range(max(1, n_render_streams) - 1)]
 
     def run_steps(n, pipelined, marks=None, timed_kernel=False, after=None):
         """n steps.  Serial: one stream.  Pipelined: the front of step i + depth runs on a second HIP stream while step i
@@ -483,18 +491,24 @@ def main():
         prep_stream.wait_stream(main)
         for j in range(min(depth, n)):
             fill(j)
+        for rs in render_streams[1:]:
+            rs.wait_stream(main)
         for i in range(n):
             if i + depth < n:
                 fill(i + depth)
             slot = slots[i % (depth + 1)]
-            main.wait_event(slot['ready'])
-            out = render(slot['pre'], timed_kernel)
-            slot['done'] = torch.cuda.Event()
-            slot['done'].record(main)
-            if marks is not None:
-                marks[i + 1].record()
+            rs = render_streams[i % len(render_streams)]
+            rs.wait_event(slot['ready'])
+            with torch.cuda.stream(rs):
+                out = render(slot['pre'], timed_kernel)
+                slot['done'] = torch.cuda.Event()
+                slot['done'].record(rs)
+                if marks is not None:
+                    marks[i + 1].record(rs)
             if after is not None:
                 after()
+        for rs in render_streams[1:]:
+            main.wait_stream(rs)
         main.wait_stream(prep_stream)
         return out
 
@@ -514,9 +528,8 @@ def main():
             elapsed = float(t.item())
         return elapsed, per_step, out
 
-    # default schedule: two streams, except with fp16 texels - that kernel runs three workgroups per CU and leaves the
-    # front of the next step nothing to run on beside it (166 M rays/s pipelined, 173 M serial)
-    pipelined = args.pipelined or not (args.serial or args.texels == 'fp16')
+    # default schedule: the front of a step on a second stream two steps ahead; one render stream (fp16 texels: two)
+    pipelined = args.pipelined or not args.serial
     elapsed, per_step, out = timed(pipelined)
 
     # ---- dominant kernel, timed live with HIP events on its own stream (untimed extra launches) ----
@@ -543,8 +556,10 @@ def main():
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': elapsed / args.steps * 1e3,
             'ms_per_step_stats': stats(per_step),
             'schedule': ('two HIP streams: texel hand-off + decoder pack + noise draws + ray set-up of step i+%d overlap the '
-                         'render kernel of step i (%d slots; every step does all of its work)'
-                         % (max(1, args.prefetch_depth), max(1, args.prefetch_depth) + 1)) if pipelined else 'one stream, serial steps',
+                         'render kernel of step i (%d slots; every step does all of its work)%s'
+                         % (max(1, args.prefetch_depth), max(1, args.prefetch_depth) + 1,
+                            '; consecutive render kernels alternate over %d streams' % len(render_streams) if len(render_streams) > 1 else ''))
+                        if pipelined else 'one stream, serial steps',
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
             'config': {'workload': 'cfg2: shapenet_chairs-like forward render, %d images/GPU, 128x128 rays/image, '
                                    '64 coarse + 64 fine samples, 3x256x256x32 fp32 triplanes, SDF decoder, A=10; '
