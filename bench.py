@@ -501,10 +501,9 @@ def main():
             rs.wait_event(slot['ready'])
             with torch.cuda.stream(rs):
                 out = render(slot['pre'], timed_kernel)
-                slot['done'] = torch.cuda.Event()
+                # one event per step: the step's timing mark also says 'this slot may be refilled'
+                slot['done'] = marks[i + 1] if marks is not None else torch.cuda.Event()
                 slot['done'].record(rs)
-                if marks is not None:
-                    marks[i + 1].record(rs)
             if after is not None:
                 after()
         for rs in render_streams[1:]:
