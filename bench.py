@@ -11,18 +11,27 @@ IMAGES_PER_GPU images at 128x128 with 64 coarse + 64 fine samples (fp32 planes, 
 operands as split fp16 hi+lo pairs, see config.mlp).  Planes, decoder weights and cameras are synthetic and already
 resident in HBM.  Images are sharded across ranks (weak scaling, no collective on the render path: SURVEY.md 8(e)).
 
+`value` is the SERIAL schedule: one stream, every step after the previous one - what a caller of the drop-in render()
+gets.  The two-stream schedule of round 3 (the next steps' fronts prepared on a second stream) is still timed, as the side
+field `value_pipelined`; it is a property of this script, not of the API.
+
 Printed JSON (rank 0, one line) carries, besides the contract fields:
+  value_mlp_exact_fp32 / value_all_rays_hit / value_pipelined - the same whole step, same K, same protocol, with the
+                      decoder MLP on exact-fp32 MFMA (tuning bit 3) / with cameras at radius 1.3 (every ray crosses the
+                      scene cube, nothing is skipped) / under the two-stream schedule;
   ms_per_step_stats - min / median / max over the K timed steps (HIP events per step);
-  roofline          - the fused render kernel against the resource that binds it.  The kernel is bound by
-                      instruction issue (VALU + transcendentals), not by HBM: its algorithmic gather stream
-                      (196 608 B per marched ray) is served by L1 / L2 / Infinity Cache at about twice
-                      the HBM peak.  achieved = issue cycles per second = (issue cycles per marched ray, from the SQ
-                      counters of the committed rocprofv3 PMC profile named in `source`) x (rays marched per launch,
-                      live) / (kernel duration, live HIP events on the launch stream); peak = 1024 SIMDs x the shader
-                      clock measured in the same profile.  `levels` carries the byte-side figures, each against its
-                      own peak: L2 request bytes (34.5 TB/s), fabric bytes FETCH x2 + WRITE (8 TB/s; `traffic`),
-                      compulsory HBM bytes, the cache-served algorithmic gather stream (no peak: not a bound) and the
-                      MFMA rate;
+  roofline          - the fused render kernel against SURVEY.md 8(d)'s arithmetic: achieved = algorithmic decoder FLOPs
+                      (704 512 per marched ray x rays marched per launch) / kernel duration (live HIP events on the launch
+                      stream), peak = 157.3 TFLOP/s (fp32 matrix / vector peak), `traffic` = fabric bytes per launch
+                      (FETCH_SIZE x2 + WRITE_SIZE from the committed rocprofv3 PMC profile named in `source`, scaled by
+                      the live ray count).  The pipe that binds by the counters is the vector ALU: `valu_pipe.frac`
+                      = 4 x SQ_ACTIVE_INST_VALU per marched ray x rays / kernel time / (1024 SIMDs x the shader clock
+                      measured in the timed launches).  `any_issue_proxy` (SQ_ACTIVE_INST_ANY: VALU + LDS + VMEM + SALU
+                      issue of the resident waves, which overlap) is a utilisation figure, not a bound.  `levels` carries
+                      the byte-side figures, each against its own peak: L2 request bytes (34.5 TB/s), fabric bytes
+                      (8 TB/s), compulsory HBM bytes, the cache-served algorithmic gather stream (196 608 B per marched
+                      ray: above the HBM peak, so not a bound);
+  per_rank          - ms per step, kernel ms, fraction of rays marched for every rank (N > 1);
   parity            - max |error| of ONE image of this very workload rendered by the timed code path against the CPU
                       oracle (untimed; budget 1e-4 on rgb / depth / mask);
   cpu_baseline      - the oracle (CPU restatement of the reference, reference ATen numerics) timed on this box's host
@@ -50,7 +59,7 @@ MFMA_F32_PEAK_TFLOPS = 157.3
 MFMA_F16_PEAK_TFLOPS = 2500.0
 MLP_FLOP_PER_RAY = 704512
 N_SIMD = 1024
-PMC_PROFILES = ('profiles/r3/pmc_render_fwd.json', 'profiles/r2/pmc_render_fwd.json', 'profiles/r1/pmc_render_fwd_derived.json')
+PMC_PROFILES = ('profiles/r4/pmc_render_fwd.json', 'profiles/r3/pmc_render_fwd.json', 'profiles/r2/pmc_render_fwd.json', 'profiles/r1/pmc_render_fwd_derived.json')
 
 
 def cameras(n, radius, gen):
@@ -161,7 +170,7 @@ def cpu_baseline_and_parity(seed, dev, ops, texels='fp32'):
     return base, parity
 
 
-def time_render(ops, dev, n_img, radius, texel_dtype, iters=50, R=R, S=S, tuning=0, fast=0.0):
+def time_render(ops, dev, n_img, radius, texel_dtype, iters=50, R=R, S=S, tuning=0, **render_kw):
     """Render-only rays/s of one configuration: HIP events around every call (on the launch stream), `iters` calls."""
     dd = synthetic_inputs(n_img, 4321, dev)
     g = torch.Generator().manual_seed(77)
@@ -178,13 +187,54 @@ def time_render(ops, dev, n_img, radius, texel_dtype, iters=50, R=R, S=S, tuning
             evs[i - 5].record()
         out = ops.render_fwd(dd['cam'], dd['focal'], R, R, S, texels, image, SCENE_RANGE, A, dd['att'], True,
                              dd['beta'], dd['alpha'], noise_coarse=nc, noise_fine=nf, workspace=ws, tuning=tuning,
-                             fast_termination=fast)
+                             **render_kw)
         ws = out['_workspace']
     evs[iters].record()
     torch.cuda.synchronize()
     per = [evs[i].elapsed_time(evs[i + 1]) for i in range(iters)]
     n = n_img * R * R
     return {'rays_per_s': n * iters / (sum(per) * 1e-3), 'ms': stats(per), 'iters': iters}, out
+
+
+def time_staged_semantics(ops, dev, n_img, radius, iters=20):
+    """render(compute_semantics=True) as the STAGED path runs it (nerf_from_image_amd/render.py: ray set-up, near/far,
+    stratified points, field query with semantics, resampling, fine points, second field query, merge + composite of
+    rgb and the A-channel map): the per-sample tensors go through HBM.  Same inputs as time_render."""
+    from nerf_from_image_amd import nerf_utils
+    dd = synthetic_inputs(n_img, 4321, dev)
+    g = torch.Generator().manual_seed(77)
+    dd['cam'] = cameras(n_img, radius, g).to(dev)
+    texels = ops.planes_to_texels(dd['planes'])
+    image = ops.decoder_pack(dd['w1'], dd['b1'], dd['w2'], dd['b2'], A)
+    gn = torch.Generator(device=dev).manual_seed(99)
+    nc = torch.rand((n_img, R, R, S), device=dev, generator=gn)
+    nf = torch.rand((n_img * R * R, S), device=dev, generator=gn)
+
+    def query(pts):
+        q = ops.field_query(pts.reshape(n_img, -1, 3), texels, image, SCENE_RANGE, A, dd['att'], True, dd['beta'], dd['alpha'],
+                            want_semantics=True, mlp_precision=1)
+        shp = pts.shape[:-1]
+        return q['sigma'].view(*shp), q['rgb'].view(*shp, 3), q['semantics'].view(*shp, A)
+
+    def once():
+        ro, rd = nerf_utils.get_ray_bundle_normalized(R, R, dd['focal'], dd['cam'], None, None)
+        near, far = nerf_utils.compute_near_far_planes(ro, rd, SCENE_RANGE, strict=False)
+        pts, dep = nerf_utils.compute_query_points_from_rays(ro, rd, near, far, S, randomize=True, noise=nc)
+        sig, rgb, sem = query(pts)
+        z, _ = ops.resample(sig, rd, dep, nf)
+        z = z.view(*dep.shape[:3], S)
+        sig_f, rgb_f, sem_f = query(nerf_utils.points_on_rays(ro, rd, z))
+        return nerf_utils.merge_and_composite(rd, dep, sig, rgb, z, sig_f, rgb_f, None, None, sem, sem_f, white_background=True)
+    evs = [torch.cuda.Event(enable_timing=True) for _ in range(iters + 1)]
+    with torch.no_grad():
+        for i in range(iters + 3):
+            if i >= 3:
+                evs[i - 3].record()
+            once()
+        evs[iters].record()
+    torch.cuda.synchronize()
+    per = [evs[i].elapsed_time(evs[i + 1]) for i in range(iters)]
+    return {'rays_per_s': n_img * R * R * iters / (sum(per) * 1e-3), 'ms': stats(per), 'iters': iters}
 
 
 def extras(dev, ops):
@@ -209,16 +259,33 @@ def extras(dev, ops):
     exact_out = {}
     for name, (n_img, radius, tdt, kw) in cases.items():
         ex['render_only'][name], exact_out[name] = time_render(ops, dev, n_img, radius, tdt, **kw)
-    # opt-in fast mode (NOT parity; never the headline): transmittance-threshold termination + sample compaction
-    fast = {}
-    for name in ('b8_all_rays_hit_fp32_texels', 'b2_cfg5_256px_128+128_fp16_texels'):
+    # ray termination in the FINE pass at eps = 1e-5 (coarse pass, pdf and sample indices untouched; inside the 1e-4 parity
+    # budget: tests/test_hip_full_size.py) - BASELINE cfg5's "early termination + sample compaction"
+    term = {}
+    for name in ('b8_chairs_fp32_texels', 'b8_all_rays_hit_fp32_texels', 'b2_cfg5_256px_128+128_fp16_texels'):
         n_img, radius, tdt, kw = cases[name]
-        for eps in (1e-3, 1e-2):
-            r, out = time_render(ops, dev, n_img, radius, tdt, fast=eps, **kw)
+        for eps in (1e-5, 1e-3):
+            r, out = time_render(ops, dev, n_img, radius, tdt, termination_eps=eps, **kw)
             r['max_abs_drgb_vs_exact'] = float((out['rgb'] - exact_out[name]['rgb']).abs().max())
             r['max_abs_dmask_vs_exact'] = float((out['mask'] - exact_out[name]['mask']).abs().max())
-            fast['%s_eps%g' % (name, eps)] = r
-    ex['fast_termination_opt_in_not_parity'] = fast
+            r['speedup_vs_exact'] = r['rays_per_s'] / ex['render_only'][name]['rays_per_s']
+            term['%s_eps%g' % (name, eps)] = r
+    ex['fine_pass_termination'] = term
+    # the composited extra maps of run.py:312-338 from the SAME fused launch (compute_coords: every encoder-training
+    # iteration, run.py:1639-1646; compute_semantics: every inversion eval batch, run.py:2036-2051), with the staged path
+    # (one launch per stage, every per-sample tensor through HBM: what these calls cost before round 4) beside them
+    maps = {}
+    for name in ('b8_chairs_fp32_texels', 'b8_all_rays_hit_fp32_texels', 'b2_cfg5_256px_128+128_fp32_texels'):
+        n_img, radius, tdt, kw = cases[name]
+        for label, mkw in (('coords', dict(want_coords=True)), ('semantics', dict(want_semantics=True))):
+            r, out = time_render(ops, dev, n_img, radius, tdt, **mkw, **kw)
+            r['x_plain_rate'] = r['rays_per_s'] / ex['render_only'][name]['rays_per_s']
+            r['rgb_bit_identical_to_plain'] = bool(torch.equal(out['rgb'], exact_out[name]['rgb']))
+            maps['%s_%s' % (name, label)] = r
+    maps['b8_chairs_fp32_texels_semantics_staged_path'] = time_staged_semantics(ops, dev, 8, RADIUS)
+    maps['b8_chairs_fp32_texels_semantics_staged_path']['x_plain_rate'] = (
+        maps['b8_chairs_fp32_texels_semantics_staged_path']['rays_per_s'] / ex['render_only']['b8_chairs_fp32_texels']['rays_per_s'])
+    ex['extra_maps_fused'] = maps
     del exact_out
     # reference numerics on PyTorch-ROCm: the oracle with GPU ATen ops, 2 images, planes precomputed
     dd = synthetic_inputs(2, 4321, dev)
@@ -269,7 +336,7 @@ def extras(dev, ops):
 
 
 def load_pmc_profile(texels='fp32'):
-    for rel in (PMC_PROFILES if texels == 'fp32' else ('profiles/r3/pmc_render_fwd_%s.json' % texels,)):
+    for rel in (PMC_PROFILES if texels == 'fp32' else ('profiles/r4/pmc_render_fwd_%s.json' % texels, 'profiles/r3/pmc_render_fwd_%s.json' % texels)):
         p = os.path.join(ROOT, rel)
         if os.path.exists(p):
             try:
@@ -302,15 +369,21 @@ def roofline(kernel_ms, marched, n_images, live_clock_hz=None, texels='fp32'):
                          'FLOP against the 2.5 PFLOP/s fp16 peak',
                  'frac_of_fp16_matrix_peak_issued': 3 * mlp_tflops / MFMA_F16_PEAK_TFLOPS},
     }
-    r = {'bound': 'valu-issue', 'kernel': 'render_fwd_kernel', 'kernel_ms': kernel_ms, 'rays_marched_per_launch': marched,
-         'unit': 'Gcycle/s', 'source': src, 'levels': levels}
+    # algorithmic decoder FLOPs per launch / kernel time against the fp32 matrix / vector peak
+    r = {'bound': 'mfma', 'kernel': 'render_fwd_kernel', 'kernel_ms': kernel_ms, 'rays_marched_per_launch': marched,
+         'achieved': mlp_tflops, 'peak': MFMA_F32_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': mlp_tflops / MFMA_F32_PEAK_TFLOPS,
+         'frac_flops': mlp_tflops / MFMA_F32_PEAK_TFLOPS, 'flop_per_marched_ray': MLP_FLOP_PER_RAY, 'traffic': None,
+         'source': src, 'levels': levels,
+         'note': 'frac = 704 512 decoder FLOP x rays marched / kernel time / 157.3 TFLOP/s (SURVEY.md 8(d)); the binding pipe '
+                 'by the counters is the vector ALU (valu_pipe.frac): gather address + bilinear blend, hi/lo splits, '
+                 'quarter-rate softplus transcendentals and the per-ray stages all issue there, and on gfx950 MFMA time is '
+                 'VALU time (tools/probes/mfma_valu_overlap.hip)'}
     if prof is None:
-        r.update(achieved=None, peak=None, frac=None, traffic=None,
-                 note='no PMC profile with issue_cycles_per_marched_ray under profiles/: run tools/gpu_session.sh <tag> pmc (tools/pmc_collect.py)')
+        r.update(valu_pipe=None, note_pmc='no PMC profile with issue_cycles_per_marched_ray under profiles/: run '
+                                          'tools/gpu_session.sh <tag> pmc (tools/pmc_collect.py)')
         return r
     clk = live_clock_hz or prof['shader_clock_hz']
-    ach = prof['issue_cycles_per_marched_ray'] * marched / t
-    peak = N_SIMD * clk
+    peak_cycles = N_SIMD * clk
     units = prof['rays_marched_per_launch']
     valu_per_ray = prof.get('valu_cycles_per_marched_ray') or (
         4.0 * prof['raw']['SQ_ACTIVE_INST_VALU'] / units if prof.get('raw', {}).get('SQ_ACTIVE_INST_VALU') else None)
@@ -323,25 +396,21 @@ def roofline(kernel_ms, marched, n_images, live_clock_hz=None, texels='fp32'):
                         'frac': fab / t / 1e9 / HBM_PEAK_GBS, 'x_compulsory': fab / compulsory,
                         'note': 'FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE; Infinity-Cache hits included; WRITE_SIZE '
                                 'is mostly the write-back of the preceding kernels\' dirty lines (texel hand-off, rand)'}
-    any_issue = None
-    if valu_per_ray is not None and ach > peak:
-        # three waves per SIMD (the fp16-texel kernel): the ANY-issue proxy sums ports that overlap between the resident
-        # waves and passes 1 - a roofline has to be a bound, so the fraction is then the vector ALU's own
-        any_issue = {'achieved': ach / 1e9, 'frac': ach / peak, 'note': 'SQ_ACTIVE_INST_ANY x4 per SIMD-cycle: over 1, not a bound'}
-        ach = valu_per_ray * marched / t
-    r.update(achieved=ach / 1e9, peak=peak / 1e9, frac=ach / peak, traffic=fab,
-             issue_cycles_per_marched_ray=prof['issue_cycles_per_marched_ray'], shader_clock_hz=clk,
+    any_cycles = prof['issue_cycles_per_marched_ray'] * marched / t
+    r.update(traffic=fab, shader_clock_hz=clk,
              shader_clock_source='live: s_memtime / s_memrealtime of a persistent wave of the timed launches'
              if live_clock_hz else 'the PMC profile (GRBM_GUI_ACTIVE / 8 / kernel time of its clock pass)',
-             frac_in_profile_run=prof.get('issue_frac'),
              valu_pipe={'cycles_per_marched_ray': valu_per_ray,
-                        'frac': None if valu_per_ray is None else valu_per_ray * marched / t / peak,
-                        'note': 'SQ_ACTIVE_INST_VALU x4: the vector ALU alone; `frac` above also counts LDS / VMEM / SALU '
-                                'issue, which overlaps between the resident waves, so it is a utilisation proxy and this '
-                                'is the binding pipe'},
-             waves_per_simd=prof.get('waves_per_simd'), any_issue_proxy=any_issue,
-             note='instruction-issue bound: SQ_ACTIVE_INST_ANY (x4 cycles) per marched ray from the PMC profile, scaled by '
-                  'the live ray count and kernel time, over 1024 SIMDs x the shader clock')
+                        'achieved_gcycles_per_s': None if valu_per_ray is None else valu_per_ray * marched / t / 1e9,
+                        'peak_gcycles_per_s': peak_cycles / 1e9,
+                        'frac': None if valu_per_ray is None else valu_per_ray * marched / t / peak_cycles,
+                        'note': '4 x SQ_ACTIVE_INST_VALU per marched ray (PMC profile) x rays marched (live) / kernel time '
+                                '(live) over 1024 SIMDs x the live shader clock: the binding pipe'},
+             any_issue_proxy={'cycles_per_marched_ray': prof['issue_cycles_per_marched_ray'],
+                              'frac': any_cycles / peak_cycles, 'frac_in_profile_run': prof.get('issue_frac'),
+                              'note': '4 x SQ_ACTIVE_INST_ANY: VALU + LDS + VMEM + SALU issue of the resident waves, which '
+                                      'overlap - a utilisation proxy (passes 1 at three waves per SIMD), NOT a bound'},
+             waves_per_simd=prof.get('waves_per_simd'))
     return r
 
 
@@ -380,7 +449,11 @@ def main():
     ap.add_argument('--texels', choices=('fp32', 'fp16', 'bf16'), default='fp32',
                     help='render mode: storage type of the texels the kernels gather from (arithmetic stays fp32); fp16 is '
                          'the fast storage: packed texels, three workgroups per CU')
-    ap.add_argument('--pipelined', action='store_true', help='render mode: force the two-stream schedule')
+    ap.add_argument('--pipelined', action='store_true',
+                    help='render mode: `value` under the two-stream schedule (the next steps\' texel hand-off, decoder pack, '
+                         'noise draws and ray set-up on a second HIP stream) instead of the serial one')
+    ap.add_argument('--no-variants', action='store_true',
+                    help='render mode: skip the value_mlp_exact_fp32 / value_all_rays_hit / value_pipelined legs')
     ap.add_argument('--prefetch-depth', type=int, default=2,
                     help='render mode, two-stream schedule: how many steps ahead the front of a step is prepared '
                          '(slots = depth + 1).  The persistent render kernel leaves the other stream few CU slots, so a front '
@@ -392,9 +465,7 @@ def main():
                          'fp32 / bf16 texels (2: 143 vs 151 M rays/s), 2 with fp16 texels (that kernel fills every slot of '
                          'the chip: with one render stream the front of the next steps only runs between renders - 166 M '
                          'pipelined, 173 M serial, 180 M with two)')
-    ap.add_argument('--serial', action='store_true',
-                    help='render mode: one stream, every step after the previous one (default: two HIP streams - the next '
-                         "step's texel hand-off, decoder pack and noise draws overlap this step's render)")
+    ap.add_argument('--serial', action='store_true', help='render mode: one stream, every step after the previous one (the default)')
     args = ap.parse_args()
 
     if 'WORLD_SIZE' not in os.environ and (args.gpus > 1 or args.force_dist):
@@ -426,34 +497,29 @@ def main():
 
     B = args.images_per_gpu or IMAGES_PER_GPU
     d = synthetic_inputs(B, 1234 + rank, dev)
+    # the every-ray-hits variant of the workload: the same scenes seen from radius 1.3 (the cube fills the image)
+    d_hit = dict(d, cam=cameras(B, 1.3, torch.Generator().manual_seed(77 + rank)).to(dev))
     n_rays = B * R * R
     ev = HipEvents()
-    state = {'ws': None}
-
     probe = torch.zeros(2, dtype=torch.int64, device=dev)
-
     tdt = {'fp32': ops.TEXEL_F32, 'fp16': ops.TEXEL_F16, 'bf16': ops.TEXEL_BF16}[args.texels]
 
-    def prepare(slot_ws=None):
+    def prepare(v, slot_ws=None):
         """Everything of a step in front of the render kernel: texel hand-off of the producer's planes, decoder operand
         image, the two noise draws, the ray set-up (rays, scene-cube test, miss-fill reduction) into the slot's workspace."""
-        return dict(texels=ops.planes_to_texels(d['planes'], tdt), image=ops.decoder_pack(d['w1'], d['b1'], d['w2'], d['b2'], A, tdt),
+        dv = v['d']
+        return dict(texels=ops.planes_to_texels(dv['planes'], tdt), image=ops.decoder_pack(dv['w1'], dv['b1'], dv['w2'], dv['b2'], A, tdt),
                     noise_c=torch.rand((B, R, R, S), dtype=torch.float32, device=dev),
                     noise_f=torch.rand([n_rays, S], dtype=torch.float32, device=dev),
-                    ws=ops.render_setup(d['cam'], d['focal'], R, R, SCENE_RANGE, workspace=slot_ws))
+                    ws=ops.render_setup(dv['cam'], dv['focal'], R, R, SCENE_RANGE, workspace=slot_ws))
 
-    def render(pre, timed_kernel=False):
-        out = ops.render_fwd(d['cam'], d['focal'], R, R, S, pre['texels'], pre['image'], SCENE_RANGE, A, d['att'], True,
-                             d['beta'], d['alpha'], noise_coarse=pre['noise_c'], noise_fine=pre['noise_f'],
-                             fine_sampling=True, white_background=True, skip_missed_rays=not args.no_skip,
-                             workspace=pre['ws'], rays_ready=True, events=ev.pair() if timed_kernel else None,
-                             clock_probe=probe if timed_kernel else None)
-        return out
-
-    def step(timed_kernel=False):
-        pre = prepare(state['ws'])
-        state['ws'] = pre['ws']
-        return render(pre, timed_kernel)
+    def render(v, pre, timed_kernel=False):
+        dv = v['d']
+        return ops.render_fwd(dv['cam'], dv['focal'], R, R, S, pre['texels'], pre['image'], SCENE_RANGE, A, dv['att'], True,
+                              dv['beta'], dv['alpha'], noise_coarse=pre['noise_c'], noise_fine=pre['noise_f'],
+                              fine_sampling=True, white_background=True, skip_missed_rays=not args.no_skip,
+                              workspace=pre['ws'], rays_ready=True, events=ev.pair() if timed_kernel else None,
+                              clock_probe=probe if timed_kernel else None, tuning=v['tuning'])
 
     def fence():
         if use_dist:
@@ -464,14 +530,16 @@ def main():
     n_render_streams = args.render_streams or (2 if args.texels == 'fp16' else 1)
     render_streams = [torch.cuda.current_stream(dev)] + [torch.cuda.Stream(device=dev) for _ in range(max(1, n_render_streams) - 1)]
 
-    def run_steps(n, pipelined, marks=None, timed_kernel=False, after=None):
-        """n steps.  Serial: one stream.  Pipelined: the front of step i + depth runs on a second HIP stream while step i
-        renders (depth + 1 slots; a slot is refilled only after the render that read it has finished).  Every step does
-        all of its work either way."""
+    def run_steps(v, n, pipelined, marks=None, timed_kernel=False, after=None):
+        """n steps of workload variant v.  Serial: one stream, what a caller of render() gets.  Pipelined: the front of step
+        i + depth runs on a second HIP stream while step i renders (depth + 1 slots; a slot is refilled only after the
+        render that read it has finished).  Every step does all of its work either way."""
         main = torch.cuda.current_stream(dev)
         if not pipelined:
             for i in range(n):
-                out = step(timed_kernel)
+                pre = prepare(v, v.get('ws'))
+                v['ws'] = pre['ws']
+                out = render(v, pre, timed_kernel)
                 if marks is not None:
                     marks[i + 1].record()
                 if after is not None:
@@ -485,7 +553,7 @@ def main():
             with torch.cuda.stream(prep_stream):
                 if 'done' in slot:
                     prep_stream.wait_event(slot['done'])
-                slot['pre'] = prepare(slot['pre']['ws'] if 'pre' in slot else None)
+                slot['pre'] = prepare(v, slot['pre']['ws'] if 'pre' in slot else None)
                 slot['ready'] = torch.cuda.Event()
                 slot['ready'].record(prep_stream)
         prep_stream.wait_stream(main)
@@ -500,7 +568,7 @@ def main():
             rs = render_streams[i % len(render_streams)]
             rs.wait_event(slot['ready'])
             with torch.cuda.stream(rs):
-                out = render(slot['pre'], timed_kernel)
+                out = render(v, slot['pre'], timed_kernel)
                 # one event per step: the step's timing mark also says 'this slot may be refilled'
                 slot['done'] = marks[i + 1] if marks is not None else torch.cuda.Event()
                 slot['done'].record(rs)
@@ -511,25 +579,35 @@ def main():
         main.wait_stream(prep_stream)
         return out
 
-    def timed(pipelined):
-        run_steps(args.warmup, pipelined)
+    def timed(v, pipelined):
+        """W untimed + exactly K timed steps of variant v, barrier + synchronize on both sides, max over ranks."""
+        run_steps(v, args.warmup, pipelined)
         marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
         fence()
         t0 = time.perf_counter()
         marks[0].record()
-        out = run_steps(args.steps, pipelined, marks)
+        run_steps(v, args.steps, pipelined, marks)
         fence()
-        elapsed = time.perf_counter() - t0
+        local = time.perf_counter() - t0
         per_step = [marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps)]
+        elapsed = local
         if use_dist:
-            t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+            t = torch.tensor([local], dtype=torch.float64, device=dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed = float(t.item())
-        return elapsed, per_step, out
+        return elapsed, per_step, local
 
-    # default schedule: the front of a step on a second stream two steps ahead; one render stream (fp16 texels: two)
-    pipelined = args.pipelined or not args.serial
-    elapsed, per_step, out = timed(pipelined)
+    headline = {'d': d, 'tuning': 0}
+    pipelined = bool(args.pipelined) and not args.serial
+    elapsed, per_step, local_elapsed = timed(headline, pipelined)
+
+    variants = {}
+    if not args.no_variants:
+        for name, v, pl in (('mlp_exact_fp32', {'d': d, 'tuning': 8}, pipelined), ('all_rays_hit', {'d': d_hit, 'tuning': 0}, pipelined),
+                            ('pipelined' if not pipelined else 'serial', {'d': d, 'tuning': 0}, not pipelined)):
+            e_v, per_v, _ = timed(v, pl)
+            variants[name] = {'value': world * n_rays * args.steps / e_v, 'ms_per_step': e_v / args.steps * 1e3,
+                              'ms_per_step_stats': stats(per_v)}
 
     # ---- dominant kernel, timed live with HIP events on its own stream (untimed extra launches) ----
     k_ms, k_clk = [], []
@@ -539,26 +617,35 @@ def main():
         cyc, ticks = (int(v) for v in probe.tolist())
         if ticks > 0:
             k_clk.append(cyc / ticks * 1e8)                # s_memrealtime ticks at 100 MHz
-    run_steps(min(50, max(5, args.steps)), pipelined, timed_kernel=True, after=read_kernel_events)    # same schedule as the timed steps
+    run_steps(headline, min(50, max(5, args.steps)), pipelined, timed_kernel=True, after=read_kernel_events)    # same schedule as the timed steps
     kernel_ms = sum(k_ms) / len(k_ms)
     live_clock = sum(k_clk) / len(k_clk) if k_clk else None
     # rays the kernel marches = rays whose line meets the cube inflated by 1e-4 (the kernel's own skip test, fp32)
     import numpy as np
-    ro, rd = ops.raygen(R, R, d['focal'], d['cam'], normalize=True)
     wide = float(np.float32(SCENE_RANGE) * np.float32(1.0001))
-    marched = int(ops.near_far(ro, rd, wide, strict=False)[2].sum().item()) if not args.no_skip else n_rays
+
+    def marched_rays(dv):
+        ro, rd = ops.raygen(R, R, dv['focal'], dv['cam'], normalize=True)
+        return int(ops.near_far(ro, rd, wide, strict=False)[2].sum().item()) if not args.no_skip else n_rays
+    marched = marched_rays(d)
+    mine = {'rank': rank, 'ms_per_step': local_elapsed / args.steps * 1e3, 'ms_per_step_stats': stats(per_step),
+            'kernel_ms': kernel_ms, 'rays_marched_fraction': marched / n_rays, 'shader_clock_hz': live_clock}
+    per_rank = [mine]
+    if use_dist:
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, mine)
 
     if rank == 0:
         value = world * n_rays * args.steps / elapsed
+        two_stream = ('two HIP streams: texel hand-off + decoder pack + noise draws + ray set-up of step i+%d overlap the '
+                      'render kernel of step i (%d slots; every step does all of its work)%s'
+                      % (max(1, args.prefetch_depth), max(1, args.prefetch_depth) + 1,
+                         '; consecutive render kernels alternate over %d streams' % len(render_streams) if len(render_streams) > 1 else ''))
         res = {
             'metric': 'rendered rays/sec (128x128, 64+64 samples)', 'value': value, 'unit': 'rays/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': elapsed / args.steps * 1e3,
             'ms_per_step_stats': stats(per_step),
-            'schedule': ('two HIP streams: texel hand-off + decoder pack + noise draws + ray set-up of step i+%d overlap the '
-                         'render kernel of step i (%d slots; every step does all of its work)%s'
-                         % (max(1, args.prefetch_depth), max(1, args.prefetch_depth) + 1,
-                            '; consecutive render kernels alternate over %d streams' % len(render_streams) if len(render_streams) > 1 else ''))
-                        if pipelined else 'one stream, serial steps',
+            'schedule': two_stream if pipelined else 'one stream, serial steps: what a caller of the drop-in render() gets',
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
             'config': {'workload': 'cfg2: shapenet_chairs-like forward render, %d images/GPU, 128x128 rays/image, '
                                    '64 coarse + 64 fine samples, 3x256x256x32 fp32 triplanes, SDF decoder, A=10; '
@@ -566,16 +653,26 @@ def main():
                                    % B,
                        'mlp': 'split-fp16: decoder MLP operands as fp16 hi+lo pairs (22 significand bits), products '
                               'hi*hi + hi*lo + lo*hi accumulated in fp32 on v_mfma_f32_16x16x32_f16; everything else '
-                              'fp32 (exact-fp32 MFMA variant timed in extras.render_only.*_mlp_exact_fp32)',
+                              'fp32 (the same whole step with the exact-fp32 MFMA: value_mlp_exact_fp32)',
                        'texel_storage': args.texels + (' (arithmetic fp32)' if args.texels != 'fp32' else ''),
                        'images_per_gpu': B, 'resolution': R, 'samples': '64+64', 'plane_res': PLANE_RES,
                        'camera_radius': RADIUS, 'scene_range': SCENE_RANGE, 'rays_marched_fraction': marched / n_rays,
                        'skip_missed_rays': not args.no_skip, 'sharding': 'images across ranks, no collective'},
-            'roofline': roofline(kernel_ms, marched, B, live_clock, args.texels) if load_pmc_profile(args.texels)[1] else
-            {'bound': 'valu-issue', 'kernel': 'render_fwd_kernel', 'kernel_ms': kernel_ms, 'rays_marched_per_launch': marched,
-             'frac': None, 'note': 'no committed PMC profile of the kernel for this texel storage type'},
-            'kernel_ms_stats': stats(k_ms),
         }
+        if variants:
+            other = 'pipelined' if not pipelined else 'serial'
+            res['value_serial' if not pipelined else 'value_pipelined'] = value
+            res['value_' + other] = variants[other]['value']
+            res['value_mlp_exact_fp32'] = variants['mlp_exact_fp32']['value']
+            res['value_all_rays_hit'] = variants['all_rays_hit']['value']
+            res['variants'] = dict(variants, note='the SAME whole step, K, warm-up and max-over-ranks protocol as `value`: '
+                                   'mlp_exact_fp32 = decoder MLP on v_mfma_f32_16x16x4_f32 (tuning bit 3), the strictly-fp32 '
+                                   'rate; all_rays_hit = cameras at radius 1.3, every ray crosses the scene cube (rays '
+                                   'marched fraction %.3f); %s = %s' % (marched_rays(d_hit) / n_rays, other,
+                                                                       two_stream if other == 'pipelined' else 'one stream'))
+        res['roofline'] = roofline(kernel_ms, marched, B, live_clock, args.texels)
+        res['kernel_ms_stats'] = stats(k_ms)
+        res['per_rank'] = per_rank
         if world == 1 and not args.no_extras:
             res['extras'] = extras(dev, ops)      # before the CPU leg: its OpenMP workers keep spinning for a while
         if world == 1 and not args.no_cpu_baseline:

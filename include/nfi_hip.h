@@ -410,7 +410,8 @@ typedef struct nfi_render_args {
   float* rgb;        /* [N,3] */
   float* depth;      /* [N] */
   float* mask;       /* [N] */
-  float* semantics;  /* [N,A] or NULL */
+  float* semantics;  /* [N,A] or NULL: composited softmax probabilities, sum_k w_k softmax(features_k) over the merged
+                      * samples (compute_semantics: run.py:231-233, 312-335; lib/nerf_utils.py:153-156); n_attention > 0 */
   /* optional stage taps (any may be NULL) */
   float* ray_origins; float* ray_directions; float* near_plane; float* far_plane; uint8_t* hit;
   float* t_coarse; float* sigma_coarse; float* rgb_coarse;   /* [N,S], [N,S], [N,S,3] */
@@ -429,8 +430,7 @@ typedef struct nfi_render_args {
    * split-fp16 (hi+lo, 22 significand bits) MFMA; both meet the 1e-4 parity budget.  bit 4: ONE device-wide work
    * counter instead of the per-XCD queues over square pixel blocks (results identical; the per-XCD queues take the
    * largest of 32 / 16 / 8 pixels that divides both image sides, two positions per atomic, and fall back to the single
-   * counter when not even 8 does).  bits 5-8: measurement knobs of those queues (5-6: block side 1 -> 8, 2 -> 32,
-   * 3 -> 16 pixels; bit 7: 4, bit 8: 1 position per atomic), results identical. */
+   * counter when not even 8 does). */
   int tuning;
   /* optional uint64[12] device array: per-phase shader-cycle sums over all waves (profiling build of
    * the kernel; NULL = off): field tile {issue, wait+interp, mlp, count}, ray set-up, coarse field,
@@ -439,13 +439,15 @@ typedef struct nfi_render_args {
   /* view-direction decoder: NULL, or [N, NFI_RAY_FEATURE_PITCH] (decoder_image from nfi_decoder_pack_viewdir;
    * the MLP then runs in exact fp32) */
   const float* ray_features;
-  /* OPT-IN, NOT PARITY (0 = off, the exact path): transmittance threshold eps in (0,1).  Coarse samples are marched
-   * front to back in steps of 32 and marching stops once the transmittance behind them is below eps; fine samples
-   * behind the first coarse sample with transmittance < eps are not evaluated (sigma = 0) and the surviving ones are
-   * compacted by wave ballot so that whole 16-point tiles drop out (BASELINE cfg5: "wavefront early-termination +
-   * sample compaction").  Changes rgb / mask by O(eps); sample indices differ from the reference.  Not available
-   * together with stage taps, the cycle profile, the view-direction decoder or the exact-fp32 MLP. */
-  float fast_termination;
+  /* Ray termination in the FINE pass (0 = off; BASELINE cfg5: "wavefront early-termination + sample compaction").  eps in
+   * (0,1): the coarse pass - hence the resampling pdf, every sample index and every depth - is untouched; fine samples
+   * that lie behind the first coarse sample in front of which the COARSE transmittance prod(1 - alpha_j + 1e-10) has
+   * fallen below eps are not evaluated (sigma = 0; they stay in the merge with their depth), and the surviving fine
+   * samples are compacted to the low lanes by wave ballot + popcount so that whole 16-point field tiles drop out.
+   * What is dropped carries at most the merged transmittance at that depth (about eps) of compositing weight:
+   * |d rgb|, |d mask| <= ~eps; tests hold eps = 1e-5 to the 1e-4 parity budget at full size.  Not available together
+   * with stage taps, extra maps, the cycle profile, the view-direction decoder or the exact-fp32 MLP. */
+  float termination_eps;
   int texel_layout;              /* NFI_TEXELS_PLANAR (0) / NFI_TEXELS_INTERLEAVED */
   /* optional uint64[2] device array (NULL = off): shader cycles (s_memtime) and 100 MHz reference ticks
    * (s_memrealtime) between the start and the end of workgroup 0 / wave 0 of the render kernel, i.e. the shader clock
@@ -453,8 +455,13 @@ typedef struct nfi_render_args {
   void* clock_probe;
   /* pixel-row window: this call renders rows [row_offset, row_offset + height) of an image that is full_height rows
    * tall (full_height 0 = height: the whole image).  Rays, samples and pixels are bit-identical to the same rows of the
-   * full render (the pixel coordinate of get_ray_bundle, lib/nerf_utils.py:36-39, is (row_offset + row) / full_height);
-   * outputs, noise and taps are sized for the window.  One image sharded over the ranks of a node: SURVEY.md 8(e),
+   * full render (the pixel coordinate of get_ray_bundle, lib/nerf_utils.py:36-39, is (row_offset + row) / full_height)
+   * - with ONE exception: the batch-wide miss-fill of lib/nerf_utils.py:258-259 (min near / max far over the hit rays,
+   * the first two cells of the workspace after nfi_render_setup) is taken over the WINDOW's rays, so rays that are
+   * marched although they miss the exact cube (inside the 1e-4 inflated one, or any missed ray with skip_missed_rays =
+   * 0) get the window's fill, not the image's.  A caller that shards one image max-reduces those two cells (and sums
+   * the third, the hit count) over the windows between nfi_render_setup and nfi_render_fwd(rays_ready = 1):
+   * parallel.allreduce_ray_setup.  Outputs, noise and taps are sized for the window.  One image sharded over the ranks of a node: SURVEY.md 8(e),
    * run.py:598-605 (res_multiplier renders). */
   int row_offset; int full_height;
   /* training stash (all three or none; fine_sampling only): the per-sample state the backward needs, ray-major with
@@ -468,6 +475,12 @@ typedef struct nfi_render_args {
    * camera, shape, scene_range and workspace arguments, ordered before this call): nfi_render_fwd then launches the render
    * kernel only.  Lets a caller run the set-up of the NEXT batch on another stream while this one renders. */
   int rays_ready;
+  /* [N,3] or NULL: composited query points, sum_k w_k (o + d t_k) over the merged samples - the sampler's 'coords'
+   * output (models/generator.py:643) in the semantics slot of render_volume_density (compute_coords: run.py:234-235,
+   * 337-338; the encoder-training loop asks for it every iteration, run.py:1639-1646).  Like `semantics` it comes out of
+   * the SAME render launch (rgb / depth / mask bit-identical to a call without it); neither is available together with
+   * stage taps, the cycle profile, the view-direction decoder or the exact-fp32 MLP. */
+  float* coords;
 } nfi_render_args;
 size_t nfi_render_workspace_bytes(int64_t n_rays);
 int nfi_render_fwd(const nfi_render_args* a, nfi_stream_t stream);

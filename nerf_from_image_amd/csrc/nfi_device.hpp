@@ -15,18 +15,6 @@
 #include <stdint.h>
 
 // build-time experiment knobs of the fused render kernels (product values below; tools/probes/render_variants.py)
-#ifndef NFI_PLANEWISE
-#define NFI_PLANEWISE 0          // 1: gather + blend one plane at a time (32 instead of 96 texel registers in flight); 2: planes 0+1, then 2; 3: tile pairs in three rounds of two planes
-#endif
-#ifndef NFI_TILE_PAIR
-#define NFI_TILE_PAIR 1          // 1: two field tiles go through the decoder MLP together; 0: one at a time
-#endif
-#ifndef NFI_SCALAR_RAY
-#define NFI_SCALAR_RAY 0         // 1: the marched ray's origin / direction / near / far through v_readfirstlane into SGPRs
-#endif
-#ifndef NFI_PREFETCH_RAY
-#define NFI_PREFETCH_RAY 1       // 1: the next ray's inputs are loaded into registers while the current ray is marched
-#endif
 #ifndef NFI_RENDER_OCC
 #define NFI_RENDER_OCC 2         // workgroups of 4 waves per CU the render kernels are compiled and launched for
 #endif
@@ -498,10 +486,6 @@ __device__ __forceinline__ void tile_bilinear(const TileTex<TEX>& T, float fx, f
 // slower than fp32 ones in an instruction-bound kernel).  (gfx950 has no bf16 form of the instruction; a packed bf16 tile
 // with the widening shifts at the blend was tried: the compiler widens early anyway - 219 registers, 220 B of scratch when
 // capped at 168 - so bf16 texels stay converted at load time, two blocks per CU.)
-#ifndef NFI_FP16_MIX
-#define NFI_FP16_MIX 1
-#endif
-#if NFI_FP16_MIX
 template <>
 struct TileTex<2> {
   uint32_t r[3][4][4];
@@ -541,7 +525,6 @@ __device__ __forceinline__ void tile_bilinear<2>(const TileTex<2>& T, float fx, 
     }
   }
 }
-#endif
 
 // The same gather + blend one plane at a time (identical arithmetic and order: plane 0, 1, 2; corners 00, 10, 01, 11).
 template <int TEX>
@@ -630,7 +613,10 @@ __device__ __forceinline__ void tile_gather_two_rounds(const FieldParams& P, int
 
 // density / colour epilogue on the decoder outputs o (lane (g,j): rows 4g..4g+3 of point j; row 0 =
 // distance/density, rows 1.. = colour logits pre-scaled by log2e)
-template <bool ATT, int N>
+// SEMP: where the softmax probabilities of a point go.  0: sem[n] is a global row [A] (the sampler closure's
+// 'semantics' output); > 0: sem[n] addresses the point's column of a per-wave LDS table [A][SEMP] (attribute-major, the
+// fused renderer composites it after the merge; the pitch makes the four channel groups' stores conflict-free).
+template <bool ATT, int N, int SEMP = 0>
 __device__ __forceinline__ void tile_epilogue(const FieldParams& P, int lane, const f32x4 (&o)[N], const float (&outside)[N],
                                               float* const (&sem)[N], TileOut (&res)[N]) {
   const int g = lane >> 4;
@@ -683,7 +669,13 @@ __device__ __forceinline__ void tile_epilogue(const FieldParams& P, int lane, co
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           int row = 4 * g + r;
-          if (row >= 1 && row <= A) sem[n][row - 1] = e4[r] * inv;
+          if constexpr (SEMP > 0) {
+            // explicit LDS address space: a ds_write, ordered with the wave's other LDS traffic (a flat store is not)
+            auto* q = (__attribute__((address_space(3))) float*)sem[n];
+            if (row >= 1 && row <= A) q[(row - 1) * SEMP] = e4[r] * inv;
+          } else {
+            if (row >= 1 && row <= A) sem[n][row - 1] = e4[r] * inv;
+          }
         }
       }
     } else {
@@ -707,25 +699,16 @@ __device__ __forceinline__ void tile_epilogue(const FieldParams& P, int lane, co
 // order one.  The resolution is ABSOLUTE, 2^-24 (the fp16 subnormal spacing; subnormals are preserved by the MFMA in
 // the default kernel mode): fine for activations, whose products accumulate with O(1) terms, NOT for operands of
 // arbitrary scale such as gradients - those are brought to [1, 2) first (pow2_normaliser below).
-#ifndef NFI_SPLIT_MIX
-#define NFI_SPLIT_MIX 1     // 1: residual x - float(hi) as one v_fma_mix_f32 per value (reads the fp16 half in place) instead of cvt + sub
-#endif
 __device__ __forceinline__ void split_f16x8(const float (&x)[8], f16x8& hi, f16x8& lo) {
   typedef float f32x2 __attribute__((ext_vector_type(2)));
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     auto h = __builtin_amdgcn_cvt_pkrtz(x[2 * i], x[2 * i + 1]);
-#if NFI_SPLIT_MIX
     float r0, r1;
     const uint32_t hb = __builtin_bit_cast(uint32_t, h);
     asm("v_fma_mix_f32 %0, -%1, 1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(r0) : "v"(hb), "v"(x[2 * i]));
     asm("v_fma_mix_f32 %0, -%1, 1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r1) : "v"(hb), "v"(x[2 * i + 1]));
     auto l = __builtin_amdgcn_cvt_pkrtz(r0, r1);
-#else
-    const f32x2 xv = {x[2 * i], x[2 * i + 1]}, hv = {(float)h[0], (float)h[1]};
-    const f32x2 r = xv - hv;                                  // one v_pk_add_f32 (exact: Sterbenz-like residual)
-    auto l = __builtin_amdgcn_cvt_pkrtz(r[0], r[1]);
-#endif
     hi[2 * i] = h[0]; hi[2 * i + 1] = h[1];
     lo[2 * i] = l[0]; lo[2 * i + 1] = l[1];
   }
@@ -792,7 +775,7 @@ __device__ __forceinline__ uint32_t ratio_f16x2(int es, float inv_pt) {
 //         fp32's 2^-24, an order of magnitude below the 1e-4 parity budget, at 1/5 of the matrix-pipe time.
 //         On gfx950 the f32-input MFMA runs at the f32 VECTOR rate and does not overlap with VALU work of
 //         other waves (tools/probes/mfma_valu_overlap.hip), so this time comes straight off the kernel.
-template <bool ATT, int N, int PREC>
+template <bool ATT, int N, int PREC, int SEMP = 0>
 __device__ __forceinline__ void tile_mlp(const FieldParams& P, int lane, const float (&feat)[N][8],
                                          const float (&outside)[N], float* const (&sem)[N], TileOut (&res)[N]) {
   const int g = lane >> 4;
@@ -902,7 +885,7 @@ __device__ __forceinline__ void tile_mlp(const FieldParams& P, int lane, const f
     for (int n = 0; n < N; ++n) o[n] = o0[n] + o1[n];   // lane (j,g): outputs 4g..4g+3 of point j; row 0 = sdf/density
   }
 
-  tile_epilogue<ATT, N>(P, lane, o, outside, sem, res);
+  tile_epilogue<ATT, N, SEMP>(P, lane, o, outside, sem, res);
 }
 
 // View-direction variant of the decoder (exact fp32 MFMA): layer 1 as above, layer 2 with 33 outputs
@@ -1001,12 +984,13 @@ struct SampleOut {
 // (or invalid) are skipped: sigma is exactly 0 there (the reference multiplies by (1-mask),
 // generator.py:633) and rgb is reported as 0 (its compositing weight is exactly 0).  Without SKIP
 // (the sampler closure) outside points get the border-clamped colour/distance the reference returns.
-// sem_base: null or global pointer to this wave's [64][A] semantics rows (written for valid points).
+// sem_base: null, or global pointer to this wave's [64][A] semantics rows (written for valid points); with SEMP > 0
+// the wave's LDS table [A][SEMP] at the column of this call's point 0 (tile_epilogue).
 // stage: 16 x 36 floats of LDS owned by this wave (feature-tile transpose).
 // prof: null, or 4 cycle accumulators {tile set-up + load issue, load wait + interpolation,
 // transpose + MLP + epilogue, tiles} filled with s_memtime deltas (profiling builds only)
 // VD: view-direction decoder; xray = padded per-ray features [rays][kRayFeatPad], ray_idx = this lane's ray.
-template <int TEX, bool ATT, bool SKIP, int PREC = 0, bool VD = false>
+template <int TEX, bool ATT, bool SKIP, int PREC = 0, bool VD = false, int SEMP = 0>
 __device__ __forceinline__ SampleOut field_wave(const FieldParams& P, float scene_range, int lane, float px, float py,
                                                 float pz, bool valid, float* sem_base, bool* outside_flag,
                                                 float* stage, unsigned long long* prof = nullptr,
@@ -1052,17 +1036,9 @@ __device__ __forceinline__ SampleOut field_wave(const FieldParams& P, float scen
     const uint32_t cxi = (uint32_t)__shfl(xi, srcL, 64);
     const int fcur = __shfl(flags, srcM, 64);
     float featL[8];
-#if NFI_PLANEWISE >= 2
-    tile_gather_two_rounds<TEX>(P, lq, cxi, cfx, cfy, cfz, featL);
-#elif NFI_PLANEWISE
-    // one plane at a time: 8 loads (32 texel registers) in flight instead of 24 (96) - the register budget of three
-    // waves per SIMD (experiment of round 3)
-    tile_gather_planewise<TEX>(P, lq, cxi, cfx, cfy, cfz, featL);
-#else
     TileTex<TEX> T;
     tile_issue<TEX>(P, lq, cxi, T);
     tile_bilinear<TEX>(T, cfx, cfy, cfz, featL);
-#endif
     // pitch 36 floats: conflict-free for both the 16-byte writes and the 16-byte reads
     __builtin_amdgcn_sched_barrier(0);
     f32x4* wr = reinterpret_cast<f32x4*>(stage + lp * 36 + lq * 4);
@@ -1077,24 +1053,6 @@ __device__ __forceinline__ SampleOut field_wave(const FieldParams& P, float scen
     __builtin_amdgcn_sched_barrier(0);
     return fcur;
   };
-#if !NFI_TILE_PAIR
-  // one tile at a time (half the accumulator registers of the pair form; experiment knob of round 3)
-  if constexpr (!VD) {
-#pragma unroll 1
-    while (tm != 0) {
-      const int ta = __builtin_ctz(tm);
-      tm &= tm - 1;
-      float feat1[1][8];
-      const int fa = gather_tile(ta, feat1[0]);
-      const float outs1[1] = {(fa & 1) ? 1.0f : 0.0f};
-      float* const sems1[1] = {(sem_base && (fa & 2)) ? sem_base + (size_t)(16 * ta + j) * P.n_attention : nullptr};
-      TileOut to1[1];
-      tile_mlp<ATT, 1, PREC>(P, lane, feat1, outs1, sems1, to1);
-      if (g == ta) { so.sdf = to1[0].sdf; so.sigma = to1[0].sigma; so.r = to1[0].r; so.g = to1[0].g; so.b = to1[0].b; }
-    }
-    return so;
-  }
-#endif
 #pragma unroll 1
   while (tm != 0) {
     unsigned long long c0 = prof ? __builtin_readcyclecounter() : 0;
@@ -1104,67 +1062,6 @@ __device__ __forceinline__ SampleOut field_wave(const FieldParams& P, float scen
     const int tb = pair ? __builtin_ctz(tm) : ta;
     tm &= tm - 1;                                 // (no-op when tm is already 0)
     float feat[2][8];
-#if NFI_PLANEWISE == 3
-    // a PAIR of tiles in three rounds of two planes each (64 texel registers in flight throughout): A0 A1 | A2 B0 | B1 B2 -
-    // 1.5 dependent gather round trips per tile, and tile A's transpose rides under the third round
-    int fa, fb;
-    if (pair) {
-      const int srcA = 16 * ta + lp, srcB = 16 * tb + lp;
-      const float ax = __shfl(fx, srcA, 64), ay = __shfl(fy, srcA, 64), az = __shfl(fz, srcA, 64);
-      const uint32_t axi = (uint32_t)__shfl(xi, srcA, 64);
-      const float bx = __shfl(fx, srcB, 64), by = __shfl(fy, srcB, 64), bz = __shfl(fz, srcB, 64);
-      const uint32_t bxi = (uint32_t)__shfl(xi, srcB, 64);
-      fa = __shfl(flags, 16 * ta + j, 64);
-      fb = __shfl(flags, 16 * tb + j, 64);
-      float tv[2][4][8], fA[8], fB[8];
-#pragma unroll
-      for (int s8 = 0; s8 < 8; ++s8) { fA[s8] = 0.0f; fB[s8] = 0.0f; }
-      plane_issue<TEX>(P, lq, axi, 0, tv[0]);
-      plane_issue<TEX>(P, lq, axi, 1, tv[1]);
-      plane_blend(0, ax, ay, az, tv[0], fA);
-      plane_blend(1, ax, ay, az, tv[1], fA);
-      pin_sums(fA);
-      plane_issue<TEX>(P, lq, axi, 2, tv[0]);
-      plane_issue<TEX>(P, lq, bxi, 0, tv[1]);
-      plane_blend(2, ax, ay, az, tv[0], fA);
-      plane_blend(0, bx, by, bz, tv[1], fB);
-      pin_sums(fA);
-      pin_sums(fB);
-      plane_issue<TEX>(P, lq, bxi, 1, tv[0]);
-      plane_issue<TEX>(P, lq, bxi, 2, tv[1]);
-      {
-        f32x4* wr = reinterpret_cast<f32x4*>(stage + lp * 36 + lq * 4);
-        wr[0] = f32x4{fA[0], fA[1], fA[2], fA[3]};
-        wr[4] = f32x4{fA[4], fA[5], fA[6], fA[7]};
-        wave_lds_fence();
-        const f32x4* rd = reinterpret_cast<const f32x4*>(stage + j * 36 + g * 4);
-        const f32x4 lo = rd[0], hi = rd[4];
-        feat[0][0] = lo.x; feat[0][1] = lo.y; feat[0][2] = lo.z; feat[0][3] = lo.w;
-        feat[0][4] = hi.x; feat[0][5] = hi.y; feat[0][6] = hi.z; feat[0][7] = hi.w;
-        wave_lds_fence();
-      }
-      plane_blend(1, bx, by, bz, tv[0], fB);
-      plane_blend(2, bx, by, bz, tv[1], fB);
-      __builtin_amdgcn_sched_barrier(0);
-      {
-        f32x4* wr = reinterpret_cast<f32x4*>(stage + lp * 36 + lq * 4);
-        wr[0] = f32x4{fB[0], fB[1], fB[2], fB[3]};
-        wr[4] = f32x4{fB[4], fB[5], fB[6], fB[7]};
-        wave_lds_fence();
-        const f32x4* rd = reinterpret_cast<const f32x4*>(stage + j * 36 + g * 4);
-        const f32x4 lo = rd[0], hi = rd[4];
-        feat[1][0] = lo.x; feat[1][1] = lo.y; feat[1][2] = lo.z; feat[1][3] = lo.w;
-        feat[1][4] = hi.x; feat[1][5] = hi.y; feat[1][6] = hi.z; feat[1][7] = hi.w;
-        wave_lds_fence();
-      }
-      __builtin_amdgcn_sched_barrier(0);
-    } else {
-      fa = gather_tile(ta, feat[0]);
-      fb = fa;
-#pragma unroll
-      for (int s8 = 0; s8 < 8; ++s8) feat[1][s8] = feat[0][s8];
-    }
-#else
     const int fa = gather_tile(ta, feat[0]);
     int fb = fa;
     if (pair) {
@@ -1173,15 +1070,16 @@ __device__ __forceinline__ SampleOut field_wave(const FieldParams& P, float scen
 #pragma unroll
       for (int s8 = 0; s8 < 8; ++s8) feat[1][s8] = feat[0][s8];
     }
-#endif
     unsigned long long c2 = prof ? __builtin_readcyclecounter() : 0;
     const float outs[2] = {(fa & 1) ? 1.0f : 0.0f, (fb & 1) ? 1.0f : 0.0f};
+    // a point's semantics: row [A] of the global output, or its column of the wave's LDS table (SEMP > 0)
+    const size_t sem_pt = SEMP > 0 ? (size_t)1 : (size_t)P.n_attention;
     float* const sems[2] = {
-        (sem_base && (fa & 2)) ? sem_base + (size_t)(16 * ta + j) * P.n_attention : nullptr,
-        (sem_base && pair && (fb & 2)) ? sem_base + (size_t)(16 * tb + j) * P.n_attention : nullptr};
+        (sem_base && (fa & 2)) ? sem_base + (size_t)(16 * ta + j) * sem_pt : nullptr,
+        (sem_base && pair && (fb & 2)) ? sem_base + (size_t)(16 * tb + j) * sem_pt : nullptr};
     TileOut to[2];
     if constexpr (VD) {
-      static_assert(PREC == 0, "the view-direction decoder exists in exact fp32 only");
+      static_assert(PREC == 0 && SEMP == 0, "the view-direction decoder exists in exact fp32 only, without the LDS semantics table");
       const int ra = __shfl(ray_idx, 16 * ta + j, 64), rb = __shfl(ray_idx, 16 * tb + j, 64);
       f32x4 xr[2][3];
 #pragma unroll
@@ -1191,7 +1089,7 @@ __device__ __forceinline__ SampleOut field_wave(const FieldParams& P, float scen
       }
       tile_mlp_vd<ATT, 2>(P, lane, feat, xr, outs, sems, to);
     } else {
-      tile_mlp<ATT, 2, PREC>(P, lane, feat, outs, sems, to);
+      tile_mlp<ATT, 2, PREC, SEMP>(P, lane, feat, outs, sems, to);
     }
     if (g == ta) { so.sdf = to[0].sdf; so.sigma = to[0].sigma; so.r = to[0].r; so.g = to[0].g; so.b = to[0].b; }
     if (pair && g == tb) { so.sdf = to[1].sdf; so.sigma = to[1].sigma; so.r = to[1].r; so.g = to[1].g; so.b = to[1].b; }
@@ -1206,9 +1104,10 @@ __device__ __forceinline__ SampleOut field_wave(const FieldParams& P, float scen
 
 // ---- per-ray weights (lib/nerf_utils.py:164-180) ------------------------------------------------
 // sigma/t hold n elements (invalid slots: sigma = 0).  dnorm = ||ray direction||.
+// T: the exclusive transmittance in front of every sample.
 template <int SPL>
 __device__ __forceinline__ void ray_weights(const float (&sigma)[SPL], const float (&t)[SPL], int n, float dnorm,
-                                            int lane, float (&w)[SPL]) {
+                                            int lane, float (&w)[SPL], float (&T)[SPL]) {
   float tn[SPL], om[SPL], alpha[SPL];
   next_elem<SPL>(t, tn, lane);
 #pragma unroll
@@ -1221,10 +1120,15 @@ __device__ __forceinline__ void ray_weights(const float (&sigma)[SPL], const flo
     alpha[j] = a;
     om[j] = (1.0f - a) + 1e-10f;
   }
-  float T[SPL];
   excl_cumprod<SPL>(om, T, lane);
 #pragma unroll
   for (int j = 0; j < SPL; ++j) w[j] = alpha[j] * T[j];
+}
+template <int SPL>
+__device__ __forceinline__ void ray_weights(const float (&sigma)[SPL], const float (&t)[SPL], int n, float dnorm,
+                                            int lane, float (&w)[SPL]) {
+  float T[SPL];
+  ray_weights<SPL>(sigma, t, n, dnorm, lane, w, T);
 }
 
 // count of cdf entries <= u (searchsorted right=True) over the M sorted floats at cdf[] (LDS)

@@ -697,11 +697,11 @@ __device__ __forceinline__ float smooth_weights(float w, int S, int lane) {
 
 // hierarchical resampling for S <= 64: coarse weights -> smooth -> pdf over smooth[1..S-2] on the
 // S-1 bin mid-points -> S fine depths.  Returns the fine depth for this lane's u.
-struct ResampleTaps { float w, smooth; int ind; };
+struct ResampleTaps { float w, smooth, T; int ind; };
 __device__ __forceinline__ float resample_ray(WaveSlab& slab, float sigma, float t, int S, float dnorm, float u, int lane,
                                               ResampleTaps* taps) {
-  float sg[1] = {lane < S ? sigma : 0.0f}, tt[1] = {t}, w[1];
-  ray_weights<1>(sg, tt, S, dnorm, lane, w);
+  float sg[1] = {lane < S ? sigma : 0.0f}, tt[1] = {t}, w[1], T[1];
+  ray_weights<1>(sg, tt, S, dnorm, lane, w, T);
   float sm = smooth_weights(w[0], S, lane);
   float tn = lane_next(t, 0.0f);
   float mid[1] = {0.5f * (tn + t)};                       // bins e = 0..S-2
@@ -709,7 +709,7 @@ __device__ __forceinline__ float resample_ray(WaveSlab& slab, float sigma, float
   build_cdf<1>(slab, mid, wts, S - 1, lane);
   int ind;
   float z = invert_cdf<8>(slab, S - 1, u, ind);
-  if (taps) { taps->w = w[0]; taps->smooth = sm; taps->ind = ind; }
+  if (taps) { taps->w = w[0]; taps->smooth = sm; taps->ind = ind; taps->T = T[0]; }
   return z;
 }
 
@@ -731,11 +731,11 @@ __device__ __forceinline__ void smooth_weights_wide(const float (&w)[SP], int S,
 template <int SP, class Slab>
 __device__ __forceinline__ void resample_ray_wide(Slab& slab, const float (&sigma)[SP], const float (&t)[SP], int S, float dnorm,
                                                   const float (&u)[SP], int lane, float (&z)[SP], float (&w)[SP],
-                                                  float (&sm)[SP], int (&ind)[SP]) {
+                                                  float (&sm)[SP], int (&ind)[SP], float (&T)[SP]) {
   float sg[SP];
 #pragma unroll
   for (int j = 0; j < SP; ++j) sg[j] = (j * 64 + lane < S) ? sigma[j] : 0.0f;
-  ray_weights<SP>(sg, t, S, dnorm, lane, w);
+  ray_weights<SP>(sg, t, S, dnorm, lane, w, T);
   smooth_weights_wide<SP>(w, S, lane, sm);
   float tn[SP], mid[SP], wts[SP];
   next_elem<SP>(t, tn, lane);
@@ -802,9 +802,6 @@ __device__ __forceinline__ void merge_scatter(Slab& slab, const float (&dep)[NS]
 // i.e. the stable ascending order of cat(coarse, fine) (coarse first on ties), ~4x fewer compares
 // than ranking all 2S keys against all 2S keys.  Falls back to the general count when the coarse
 // depths are not ascending (possible only through 1-ulp rounding of the jittered depths).
-#ifndef NFI_MERGE_HIST
-#define NFI_MERGE_HIST 1      // 0: the coarse samples' ranks by a second comparison per fine key (round 2 / start of round 3)
-#endif
 struct MergeIn { float t, sigma, r, g, b; };
 __device__ __forceinline__ void merge_pair_scatter(WaveSlab& slab, const MergeIn& c, const MergeIn& f, int S, int lane,
                                                    int& rank_c, int& rank_f) {
@@ -821,7 +818,7 @@ __device__ __forceinline__ void merge_pair_scatter(WaveSlab& slab, const MergeIn
   const uint4* kv = reinterpret_cast<const uint4*>(slab.key);
   const int n4 = (S + 3) >> 2;
   int cnt_a = 0, cnt_b = 0, cnt_c = 0;
-  if (ascending && NFI_MERGE_HIST) {
+  if (ascending) {
     // #{fine < z_k} against all fine keys; the coarse side needs no second comparison per key: with the coarse keys
     // ascending, a fine key f is below coarse key k exactly when #{coarse <= f} <= k, so #{fine < t_k} is the running sum
     // over the histogram of the fine keys' upper bounds (one LDS add per lane + one wave scan instead of 64 compares)
@@ -891,15 +888,6 @@ __device__ __forceinline__ void merge_pair_scatter(WaveSlab& slab, const MergeIn
     }
   }
   if (ascending) {
-    if (!NFI_MERGE_HIST) {
-      int pos = 0;
-#pragma unroll
-      for (int step = 64; step >= 1; step >>= 1) {
-        int idx = pos + step;
-        if (idx <= S && slab.key[64 + idx - 1] <= kf) pos = idx;
-      }
-      cnt_c = pos;
-    }
     rank_c = lane + cnt_a;
   } else {
     int cnt_d = 0;   // coarse j before coarse k
@@ -970,7 +958,6 @@ __device__ __forceinline__ bool merge_pair_scatter_wide(Slab& slab, const float 
       for (int e = 0; e < 4; ++e)
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-          if (!NFI_MERGE_HIST) cnt_a[j] += (qq[e] < kc[j]) ? 1 : 0;
           cnt_b[j] += (qq[e] < kf[j]) ? 1 : 0;
         }
     }
@@ -994,7 +981,7 @@ __device__ __forceinline__ bool merge_pair_scatter_wide(Slab& slab, const float 
       cnt_c[j] = 8 * b + cnt;
     }
   }
-  if (NFI_MERGE_HIST) {
+  {
     // #{fine < t_e} for the ascending coarse keys = running sum over the histogram of the fine keys' upper bounds
     // (merge_pair_scatter): entries 0 .. S of the bins row, element e = slot * 64 + lane
     uint32_t* hist = reinterpret_cast<uint32_t*>(slab.bins);
@@ -1193,7 +1180,8 @@ __global__ __launch_bounds__(256) void resample_wide_kernel(nfi_resample_args a)
     u[j] = e < S ? a.u[ray * a.u_row_stride + e] : 0.0f;
   }
   float dn = norm3(a.ray_directions[ray * 3], a.ray_directions[ray * 3 + 1], a.ray_directions[ray * 3 + 2]);
-  resample_ray_wide<2>(slab, sigma, t, S, dn, u, lane, z, w, sm, ind);
+  float Tc[2];
+  resample_ray_wide<2>(slab, sigma, t, S, dn, u, lane, z, w, sm, ind, Tc);
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
     const int e = j * 64 + lane;
@@ -1354,7 +1342,9 @@ struct RenderKernelParams {
   int skip_missed;
   unsigned long long* prof;
   const float* xray;   // view-direction decoder: padded per-ray features [N][kRayFeatPad], or null
-  float fast_od;       // FAST kernels: optical depth -ln(eps) behind which a ray is no longer marched
+  float term_eps;      // kRenderTerm kernels: coarse transmittance below which fine samples are no longer evaluated
+  float* semantics;    // kRenderExtra kernels: composited softmax probabilities [N][A], or null
+  float* coords;       // kRenderExtra kernels: composited query points [N][3], or null
   unsigned long long* clock_probe;   // null, or {shader cycles, 100 MHz ticks} lived by workgroup 0 / wave 0
   FastDiv div_hw, div_bps, div_bw;   // division by rays per image, blocks per scene, blocks per image row (nfi_device.hpp)
   int tap_stride;      // entries per ray in the per-sample tap arrays: S, or 2S for the training stash (fine half at +S)
@@ -1441,25 +1431,47 @@ struct RayQueue {
   }
 };
 
-// FAST (opt-in, NOT parity; nfi_render_args.fast_termination): transmittance-threshold termination + sample
-// compaction.  Coarse pass: the front 32 samples are marched first and the back 32 only if the optical depth so far
-// is below -ln(eps) (the transmittance behind them is still above eps); fine pass: fine samples that lie behind the
-// first coarse sample whose transmittance fell below eps are dropped from the field query (sigma = 0, they stay in
-// the merge), and the surviving ones are compacted to the low lanes (wave ballot + popcount), so that whole 16-point
-// tiles disappear.  The exact path never takes these branches.
-// NFI_LEAN_RAY (register budget of a third wave per SIMD, tools/vgpr_liveness.py): every stage of a ray derives its
-// lane-dependent addresses from its OWN copy of the lane id, made opaque to the optimiser - otherwise ~27 loop-invariant
-// address values are hoisted out of the ray loop and held in registers across both gathers.
-#ifndef NFI_LEAN_RAY
-#define NFI_LEAN_RAY 0
-#endif
-#if NFI_LEAN_RAY
-#define NFI_STAGE_LANE(name) int name = lane; asm volatile("" : "+v"(name))
-#else
-#define NFI_STAGE_LANE(name) const int name = lane
-#endif
-template <int TEX, bool ATT, int OCC, bool TAPS, int PREC, bool PROF = false, bool VD = false, bool FAST = false>
+// Variants of the persistent render kernels (one template argument; they exclude each other):
+//   kRenderPlain  rgb / depth / mask only - the inference kernel
+//   kRenderTaps   + the optional stage taps or the training stash
+//   kRenderProf   + per-phase cycle counters (S <= 64)
+//   kRenderTerm   ray termination in the FINE pass (nfi_render_args.termination_eps): the coarse pass, hence the pdf and
+//                 every sample index, is untouched; fine samples that lie behind the first coarse sample in front of
+//                 which the coarse transmittance has fallen below eps are not evaluated (sigma = 0; they stay in the
+//                 merge with their depth) and the surviving ones are compacted to the low lanes (wave ballot +
+//                 popcount) so that whole 16-point tiles drop out
+//   kRenderExtra  + the composited per-sample attributes of run.py:312-338 / lib/nerf_utils.py:147-159: `semantics`
+//                 (softmax probabilities, parked per sample in a per-wave LDS table [A][pitch] by the field epilogue and
+//                 composited with the merged weights brought back to source order) and `coords` (the query point
+//                 o + d t of every merged sample)
+constexpr int kRenderPlain = 0, kRenderTaps = 1, kRenderProf = 2, kRenderTerm = 3, kRenderExtra = 4;
+constexpr int kSemPitch = 2 * 64 + 4, kSemPitchWide = 2 * 128 + 4;   // pitch = 4 (mod 64): conflict-free stores from the MFMA layout
+extern __shared__ __attribute__((aligned(16))) float nfi_dyn_lds[];   // kRenderExtra: 4 waves x A x pitch floats
+
+typedef __attribute__((address_space(3))) float lds_float;
+
+// sum_e w_e (o + d t_e) over the merged samples (coords = x_in of the sampler, generator.py:643; run.py:337 puts it in the
+// semantics slot of render_volume_density)
+template <int NS, class Slab>
+__device__ __forceinline__ void composite_coords(const Slab& slab, const float (&w)[NS], int n, int lane, float ox, float oy,
+                                                 float oz, float dx, float dy, float dz, float* out3) {
+  float cx = 0.0f, cy = 0.0f, cz = 0.0f;
+#pragma unroll
+  for (int j = 0; j < NS; ++j) {
+    const int e = j * 64 + lane;
+    if (e < n) {
+      const float t = slab.srt[0][e];
+      cx += w[j] * (ox + dx * t); cy += w[j] * (oy + dy * t); cz += w[j] * (oz + dz * t);
+    }
+  }
+  cx = wave_sum(cx); cy = wave_sum(cy); cz = wave_sum(cz);
+  if (lane == 0) { out3[0] = cx; out3[1] = cy; out3[2] = cz; }
+}
+
+template <int TEX, bool ATT, int OCC, int MODE, int PREC, bool VD = false>
 __global__ __launch_bounds__(256, OCC) void render_fwd_kernel(RenderKernelParams k) {
+  constexpr bool TAPS = MODE == kRenderTaps, PROF = MODE == kRenderProf, TERM = MODE == kRenderTerm, EXTRA = MODE == kRenderExtra;
+  constexpr int SEMP = (EXTRA && ATT) ? kSemPitch : 0;
   constexpr int kImg = VD ? kVdImageFloats : kLdsImageFloats;
   __shared__ __attribute__((aligned(16))) float lds[kImg];
   __shared__ __attribute__((aligned(16))) float vfs[4][64];
@@ -1484,7 +1496,6 @@ __global__ __launch_bounds__(256, OCC) void render_fwd_kernel(RenderKernelParams
   const float bg = k.white ? 1.0f : 0.0f;
   const size_t tb = TEX == 0 ? 128 : 64;
   const uint32_t n_rays = (uint32_t)k.n_scenes * (uint32_t)k.hw;
-  uint32_t* counter = k.counter;
   // queue position -> ray id.  Tile order: consecutive positions walk 8x8 pixel tiles, so the few
   // thousand rays in flight at any time cover a compact image region (a compact part of the three
   // planes) instead of a band of scanlines - better L2/Infinity-Cache reuse of the gather stream.
@@ -1501,15 +1512,26 @@ __global__ __launch_bounds__(256, OCC) void render_fwd_kernel(RenderKernelParams
   P.vf = vf;
   int cur_scene = -1;
 
+  // kRenderExtra: this wave's semantics table [A][kSemPitch]: column = sample (coarse [0,64), fine [64,128)).  Zeroed once:
+  // a tile the field skips (all 16 points outside the cube) leaves an earlier ray's probabilities behind, and those meet
+  // weights that are exactly 0 - finite stale values are harmless, uninitialised LDS would not be.
+  float* semT = nullptr;
+  if constexpr (SEMP > 0) {
+    if (k.semantics) {
+      semT = nfi_dyn_lds + wave * (k.A * kSemPitch);
+      for (int i = lane; i < k.A * kSemPitch; i += 64) ((lds_float*)semT)[i] = 0.0f;
+      wave_lds_fence();
+    }
+  }
+
   auto load_inputs = [&](uint32_t ray, RayInputs& in) {
-    NFI_STAGE_LANE(l_in);          // (the noise addresses are rebuilt per ray, not held across it)
     const size_t r3 = (size_t)ray * 3;
     in.hit = k.hit[ray];
     in.ox = k.ro[r3]; in.oy = k.ro[r3 + 1]; in.oz = k.ro[r3 + 2];
     in.dx = k.rd[r3]; in.dy = k.rd[r3 + 1]; in.dz = k.rd[r3 + 2];
     in.near = k.near_raw[ray]; in.far = k.far_raw[ray];
-    in.noise = (k.noise_c && valid) ? k.noise_c[(size_t)ray * S + l_in] : 0.0f;
-    in.u = (k.fine && valid) ? k.noise_f[(size_t)ray * k.noise_f_stride + l_in] : 0.0f;
+    in.noise = (k.noise_c && valid) ? k.noise_c[(size_t)ray * S + lane] : 0.0f;
+    in.u = (k.fine && valid) ? k.noise_f[(size_t)ray * k.noise_f_stride + lane] : 0.0f;
   };
 
   // ray indices: cur (being marched), nxt (inputs being loaded), and one more in flight
@@ -1524,9 +1546,7 @@ __global__ __launch_bounds__(256, OCC) void render_fwd_kernel(RenderKernelParams
   if (cur < n_rays) load_inputs(ray_of(cur), in);
   while (cur < n_rays) {
     fly = fetch();
-#if NFI_PREFETCH_RAY
     if (nxt < n_rays) load_inputs(ray_of(nxt), pre);
-#endif
     const uint32_t ray = ray_of(cur);
     const uint32_t hitb = in.hit;
     if (k.skip_missed && !(hitb & 2)) {
@@ -1535,13 +1555,20 @@ __global__ __launch_bounds__(256, OCC) void render_fwd_kernel(RenderKernelParams
         k.rgb[(size_t)ray * 3] = bg; k.rgb[(size_t)ray * 3 + 1] = bg; k.rgb[(size_t)ray * 3 + 2] = bg;
         k.depth[ray] = 0.0f; k.mask[ray] = 0.0f;
       }
+      if constexpr (EXTRA) {
+        if (k.coords && lane < 3) k.coords[(size_t)ray * 3 + lane] = 0.0f;
+        if (k.semantics && lane < k.A) k.semantics[(size_t)ray * k.A + lane] = 0.0f;
+      }
       if constexpr (TAPS) {
         if (k.stash && valid) {
           // an all-zero row: its composite backward is exactly zero and its points (the ray origin) carry no gradient
           const size_t zs = (size_t)ray * (size_t)k.tap_stride + lane;
-          k.t_coarse[zs] = 0.0f; k.sigma_coarse[zs] = 0.0f; k.t_fine[zs] = 0.0f; k.sigma_fine[zs] = 0.0f;
+          k.t_coarse[zs] = 0.0f; k.sigma_coarse[zs] = 0.0f;
           float* q = k.rgb_coarse + zs * 3; q[0] = 0.0f; q[1] = 0.0f; q[2] = 0.0f;
-          q = k.rgb_fine + zs * 3; q[0] = 0.0f; q[1] = 0.0f; q[2] = 0.0f;
+          if (k.fine) {
+            k.t_fine[zs] = 0.0f; k.sigma_fine[zs] = 0.0f;
+            q = k.rgb_fine + zs * 3; q[0] = 0.0f; q[1] = 0.0f; q[2] = 0.0f;
+          }
         }
       }
     } else {
@@ -1560,44 +1587,21 @@ __global__ __launch_bounds__(256, OCC) void render_fwd_kernel(RenderKernelParams
         }
         wave_lds_fence();
       }
-#if NFI_SCALAR_RAY
-      // the ray is the same for all 64 lanes: keep its eight inputs in scalar registers
-      const float ox = uniform_f32(in.ox), oy = uniform_f32(in.oy), oz = uniform_f32(in.oz), dx = uniform_f32(in.dx),
-                  dy = uniform_f32(in.dy), dz = uniform_f32(in.dz);
-      float near = uniform_f32(in.near), far = uniform_f32(in.far);
-#else
       const float ox = in.ox, oy = in.oy, oz = in.oz, dx = in.dx, dy = in.dy, dz = in.dz;
       float near = in.near, far = in.far;
-#endif
       finish_planes((hitb & 1) != 0, fill_near, fill_far, near, far);
       const float dnorm = norm3(dx, dy, dz);
       const size_t rs = (size_t)ray * (size_t)k.tap_stride;      // row of this ray in the per-sample tap / stash arrays
 
       // ---- coarse pass ----
       float tc = 0.0f;
-      NFI_STAGE_LANE(l_c);
-      if (valid) tc = stratified_depth(near, far, l_c, S, in.noise, k.noise_c != nullptr);
+      if (valid) tc = stratified_depth(near, far, lane, S, in.noise, k.noise_c != nullptr);
       MergeIn c;
       unsigned long long t1 = PROF ? __builtin_readcyclecounter() : 0;
-      float od_c = 0.0f;      // FAST: optical depth sigma * delta of this lane's coarse sample
-      if constexpr (FAST) {
-        const bool front = lane < 32;
-        SampleOut q = field_wave<TEX, ATT, true, PREC, VD>(P, k.scene_range, lane, ox + dx * tc, oy + dy * tc, oz + dz * tc,
-                                                           valid && front, nullptr, nullptr, &slab.srt[0][0], nullptr, k.xray, (int)ray);
-        const float dl = (lane < S - 1) ? (lane_next(tc, 0.0f) - tc) * dnorm : 0.0f;
-        const float od_front = uniform_f32(wave_sum((valid && front) ? q.sigma * dl : 0.0f));
-        if (od_front <= k.fast_od) {
-          SampleOut q2 = field_wave<TEX, ATT, true, PREC, VD>(P, k.scene_range, lane, ox + dx * tc, oy + dy * tc, oz + dz * tc,
-                                                              valid && !front, nullptr, nullptr, &slab.srt[0][0], nullptr, k.xray, (int)ray);
-          if (!front) q = q2;
-        } else if (!front) {
-          q.sigma = 0.0f; q.r = 0.0f; q.g = 0.0f; q.b = 0.0f;
-        }
-        c.t = tc; c.sigma = valid ? q.sigma : 0.0f; c.r = q.r; c.g = q.g; c.b = q.b;
-        od_c = c.sigma * dl;
-      } else {
-        SampleOut q = field_wave<TEX, ATT, true, PREC, VD>(P, k.scene_range, l_c, ox + dx * tc, oy + dy * tc, oz + dz * tc, valid,
-                                                     nullptr, nullptr, &slab.srt[0][0], PROF ? pc : nullptr, k.xray, (int)ray);
+      {
+        SampleOut q = field_wave<TEX, ATT, true, PREC, VD, SEMP>(P, k.scene_range, lane, ox + dx * tc, oy + dy * tc, oz + dz * tc,
+                                                                 valid, semT, nullptr, &slab.srt[0][0], PROF ? pc : nullptr,
+                                                                 k.xray, (int)ray);
         c.t = tc; c.sigma = q.sigma; c.r = q.r; c.g = q.g; c.b = q.b;
       }
       int n = S;
@@ -1605,14 +1609,13 @@ __global__ __launch_bounds__(256, OCC) void render_fwd_kernel(RenderKernelParams
       unsigned long long t2 = PROF ? __builtin_readcyclecounter() : 0, t3 = t2, t4 = t2, t5 = t2;
       if (k.fine) {
         // ---- hierarchical resampling + fine pass ----
-        NFI_STAGE_LANE(l_r);
-        float tf = resample_ray(slab, c.sigma, tc, S, dnorm, in.u, l_r, nullptr);
+        ResampleTaps rt;
+        float tf = resample_ray(slab, c.sigma, tc, S, dnorm, in.u, lane, TERM ? &rt : nullptr);
         MergeIn f;
         if (PROF) { asm volatile("" :: "v"(tf)); t3 = __builtin_readcyclecounter(); }
-        if constexpr (FAST) {
-          // depth of the first coarse sample in front of which the transmittance is already below eps
-          const float inc = wave_incl_scan_add_f32(od_c);
-          const uint64_t dm = __ballot(valid && (inc - od_c) > k.fast_od);
+        if constexpr (TERM) {
+          // depth of the first coarse sample in front of which the coarse transmittance is already below eps
+          const uint64_t dm = __ballot(valid && rt.T < k.term_eps);
           float t_dead = INFINITY;
           if (dm) t_dead = bits2f((uint32_t)__builtin_amdgcn_readlane((int)f2bits(tc), (int)__builtin_ctzll(dm)));
           // compaction: live fine samples to the low lanes, dropped ones behind them (they keep their depth)
@@ -1626,14 +1629,14 @@ __global__ __launch_bounds__(256, OCC) void render_fwd_kernel(RenderKernelParams
           wave_lds_fence();
           tf = slab.cdf[lane];
           wave_lds_fence();
-          const bool vf = lane < nl;
-          SampleOut q = field_wave<TEX, ATT, true, PREC, VD>(P, k.scene_range, lane, ox + dx * tf, oy + dy * tf, oz + dz * tf, vf,
+          const bool vl = lane < nl;
+          SampleOut q = field_wave<TEX, ATT, true, PREC, VD>(P, k.scene_range, lane, ox + dx * tf, oy + dy * tf, oz + dz * tf, vl,
                                                              nullptr, nullptr, &slab.srt[0][0], nullptr, k.xray, (int)ray);
-          f.t = tf; f.sigma = vf ? q.sigma : 0.0f; f.r = vf ? q.r : 0.0f; f.g = vf ? q.g : 0.0f; f.b = vf ? q.b : 0.0f;
+          f.t = tf; f.sigma = vl ? q.sigma : 0.0f; f.r = vl ? q.r : 0.0f; f.g = vl ? q.g : 0.0f; f.b = vl ? q.b : 0.0f;
         } else {
-          NFI_STAGE_LANE(l_f);
-          SampleOut q = field_wave<TEX, ATT, true, PREC, VD>(P, k.scene_range, l_f, ox + dx * tf, oy + dy * tf, oz + dz * tf, valid,
-                                                       nullptr, nullptr, &slab.srt[0][0], PROF ? pc : nullptr, k.xray, (int)ray);
+          SampleOut q = field_wave<TEX, ATT, true, PREC, VD, SEMP>(P, k.scene_range, lane, ox + dx * tf, oy + dy * tf, oz + dz * tf,
+                                                                   valid, semT ? semT + 64 : nullptr, nullptr, &slab.srt[0][0],
+                                                                   PROF ? pc : nullptr, k.xray, (int)ray);
           f.t = tf; f.sigma = q.sigma; f.r = q.r; f.g = q.g; f.b = q.b;
         }
         if constexpr (TAPS) {
@@ -1645,19 +1648,37 @@ __global__ __launch_bounds__(256, OCC) void render_fwd_kernel(RenderKernelParams
         }
         n = 2 * S;
         if (PROF) t4 = __builtin_readcyclecounter();
-        NFI_STAGE_LANE(l_m);
-        merge_pair_scatter(slab, c, f, S, l_m, rank_c, rank_f);
+        merge_pair_scatter(slab, c, f, S, lane, rank_c, rank_f);
         if (PROF) t5 = __builtin_readcyclecounter();
       } else {
         if (valid) { slab.srt[0][lane] = c.t; slab.srt[1][lane] = c.sigma; slab.srt[2][lane] = c.r; slab.srt[3][lane] = c.g; slab.srt[4][lane] = c.b; }
         wave_lds_fence();
       }
       float w[2];
-      NFI_STAGE_LANE(l_o);
-      CompositeOut o = composite_slab<2>(slab, n, dnorm, k.white, l_o, w);
+      CompositeOut o = composite_slab<2>(slab, n, dnorm, k.white, lane, w);
       if (lane == 0) {
         k.rgb[(size_t)ray * 3] = o.r; k.rgb[(size_t)ray * 3 + 1] = o.g; k.rgb[(size_t)ray * 3 + 2] = o.b;
         k.depth[ray] = o.depth; k.mask[ray] = o.mask;
+      }
+      if constexpr (EXTRA) {
+        if (k.coords) composite_coords<2>(slab, w, n, lane, ox, oy, oz, dx, dy, dz, k.coords + (size_t)ray * 3);
+        if constexpr (SEMP > 0) {
+          if (semT) {
+            // the merged weights back in source order (lane = sample): the cdf row is free after the merge
+            wave_lds_fence();
+            slab.cdf[lane] = w[0]; slab.cdf[64 + lane] = w[1];
+            wave_lds_fence();
+            const float wc = valid ? slab.cdf[rank_c] : 0.0f;
+            const float wf = (valid && k.fine) ? slab.cdf[rank_f] : 0.0f;
+            const lds_float* sl = (const lds_float*)semT;
+            float mine = 0.0f;
+            for (int a = 0; a < k.A; ++a) {
+              const float sa = wave_sum(wc * sl[a * kSemPitch + lane] + wf * sl[a * kSemPitch + 64 + lane]);
+              if (lane == a) mine = sa;
+            }
+            if (lane < k.A) k.semantics[(size_t)ray * k.A + lane] = mine;
+          }
+        }
       }
       if constexpr (TAPS) {
         if (lane == 0) {
@@ -1688,11 +1709,7 @@ __global__ __launch_bounds__(256, OCC) void render_fwd_kernel(RenderKernelParams
         pc[4] += t1 - t0; pc[5] += t2 - t1; pc[6] += t3 - t2; pc[7] += t4 - t3; pc[8] += t5 - t4; pc[9] += t6 - t5; pc[10] += 1;
       }
     }
-#if NFI_PREFETCH_RAY
     in = pre;
-#else
-    if (nxt < n_rays) load_inputs(ray_of(nxt), in);      // (experiment: no register-resident prefetch of the next ray)
-#endif
     cur = nxt;
     nxt = fly;
   }
@@ -1705,14 +1722,20 @@ __global__ __launch_bounds__(256, OCC) void render_fwd_kernel(RenderKernelParams
 
 #ifdef NFI_SINGLE_KERNEL
 // register-budget work (tools/vgpr_liveness.py): compile ONLY the plain inference kernel of one texel storage type -
-// hipcc -S --cuda-device-only -DNFI_SINGLE_KERNEL=<TEX> -DNFI_RENDER_OCC=<waves per SIMD> ... - seconds instead of minutes
-template __global__ void render_fwd_kernel<NFI_SINGLE_KERNEL, true, NFI_RENDER_OCC, false, 1>(RenderKernelParams);
+// hipcc -S --cuda-device-only -DNFI_SINGLE_KERNEL=<TEX> [-DNFI_SINGLE_MODE=<kRender...>] -DNFI_RENDER_OCC=<waves per SIMD> ... -
+// seconds instead of minutes
+#ifndef NFI_SINGLE_MODE
+#define NFI_SINGLE_MODE 0     // kRenderPlain ... kRenderExtra
+#endif
+template __global__ void render_fwd_kernel<NFI_SINGLE_KERNEL, true, NFI_RENDER_OCC, NFI_SINGLE_MODE, 1>(RenderKernelParams);
 #else
 // The same pipeline for 64 < S <= 128 samples per pass (BASELINE cfg5, ray_multiplier=2): every lane
 // owns two coarse and two fine samples (element e = slot*64 + lane), the field is marched 64 points
 // at a time, and the merge ranks all 2S keys against each other.
-template <int TEX, bool ATT, bool TAPS, int PREC, bool VD = false, bool FAST = false>
+template <int TEX, bool ATT, int MODE, int PREC, bool VD = false>
 __global__ __launch_bounds__(256, NFI_RENDER_OCC) void render_fwd_wide_kernel(RenderKernelParams k) {
+  constexpr bool TAPS = MODE == kRenderTaps, TERM = MODE == kRenderTerm, EXTRA = MODE == kRenderExtra;
+  constexpr int SEMP = (EXTRA && ATT) ? kSemPitchWide : 0;
   constexpr int kImg = VD ? kVdImageFloats : kLdsImageFloats;
   __shared__ __attribute__((aligned(16))) float lds[kImg];
   __shared__ __attribute__((aligned(16))) float vfs[4][64];
@@ -1746,6 +1769,15 @@ __global__ __launch_bounds__(256, NFI_RENDER_OCC) void render_fwd_wide_kernel(Re
   FieldParams P = make_field_params(k.texels, k.res, TEX, k.A, k.use_sdf, k.beta, k.alpha, lds, kImg, k.layout);
   P.vf = vf;
   int cur_scene = -1;
+  // kRenderExtra: this wave's semantics table [A][kSemPitchWide], column = sample: coarse [0,128), fine [128,256)
+  float* semT = nullptr;
+  if constexpr (SEMP > 0) {
+    if (k.semantics) {
+      semT = nfi_dyn_lds + wave * (k.A * kSemPitchWide);
+      for (int i = lane; i < k.A * kSemPitchWide; i += 64) ((lds_float*)semT)[i] = 0.0f;
+      wave_lds_fence();
+    }
+  }
   RayQueue queue(k, lane);
   uint32_t cur = queue.fetch(), nxt = 0;
   while (cur < n_rays) {
@@ -1757,15 +1789,22 @@ __global__ __launch_bounds__(256, NFI_RENDER_OCC) void render_fwd_wide_kernel(Re
         k.rgb[(size_t)ray * 3] = bg; k.rgb[(size_t)ray * 3 + 1] = bg; k.rgb[(size_t)ray * 3 + 2] = bg;
         k.depth[ray] = 0.0f; k.mask[ray] = 0.0f;
       }
+      if constexpr (EXTRA) {
+        if (k.coords && lane < 3) k.coords[(size_t)ray * 3 + lane] = 0.0f;
+        if (k.semantics && lane < k.A) k.semantics[(size_t)ray * k.A + lane] = 0.0f;
+      }
       if constexpr (TAPS) {
         if (k.stash) {
 #pragma unroll
           for (int j = 0; j < 2; ++j) {
             if (j * 64 + lane < S) {
               const size_t zs = (size_t)ray * (size_t)k.tap_stride + j * 64 + lane;
-              k.t_coarse[zs] = 0.0f; k.sigma_coarse[zs] = 0.0f; k.t_fine[zs] = 0.0f; k.sigma_fine[zs] = 0.0f;
+              k.t_coarse[zs] = 0.0f; k.sigma_coarse[zs] = 0.0f;
               float* q = k.rgb_coarse + zs * 3; q[0] = 0.0f; q[1] = 0.0f; q[2] = 0.0f;
-              q = k.rgb_fine + zs * 3; q[0] = 0.0f; q[1] = 0.0f; q[2] = 0.0f;
+              if (k.fine) {
+                k.t_fine[zs] = 0.0f; k.sigma_fine[zs] = 0.0f;
+                q = k.rgb_fine + zs * 3; q[0] = 0.0f; q[1] = 0.0f; q[2] = 0.0f;
+              }
             }
           }
         }
@@ -1805,36 +1844,12 @@ __global__ __launch_bounds__(256, NFI_RENDER_OCC) void render_fwd_wide_kernel(Re
         const float nz = (k.noise_c && val[j]) ? k.noise_c[rs + e] : 0.0f;
         tc[j] = val[j] ? stratified_depth(near, far, e, S, nz, k.noise_c != nullptr) : 0.0f;
       }
-      float odc[2] = {0.0f, 0.0f};   // FAST: optical depth of each coarse sample
-      if constexpr (FAST) {
-        // front to back in steps of 32 samples; stop once the optical depth so far exceeds -ln(eps)
-        float tn[2];
-        next_elem<2>(tc, tn, lane);
-        float od_run = 0.0f;
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          sc[j] = rc[j] = gc[j] = bc[j] = 0.0f;
-          const float dl = (j * 64 + lane < S - 1) ? (tn[j] - tc[j]) * dnorm : 0.0f;
-#pragma unroll
-          for (int h = 0; h < 2; ++h) {
-            const bool mine = (lane >> 5) == h;
-            if (od_run <= k.fast_od) {
-              SampleOut q = field_wave<TEX, ATT, true, PREC, VD>(P, k.scene_range, lane, ox + dx * tc[j], oy + dy * tc[j],
-                                                                 oz + dz * tc[j], val[j] && mine, nullptr, nullptr, stage,
-                                                                 nullptr, k.xray, (int)ray);
-              if (mine && val[j]) { sc[j] = q.sigma; rc[j] = q.r; gc[j] = q.g; bc[j] = q.b; }
-              od_run += uniform_f32(wave_sum((mine && val[j]) ? q.sigma * dl : 0.0f));
-            }
-          }
-          odc[j] = sc[j] * dl;
-        }
-      } else {
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          SampleOut q = field_wave<TEX, ATT, true, PREC, VD>(P, k.scene_range, lane, ox + dx * tc[j], oy + dy * tc[j], oz + dz * tc[j],
-                                                             val[j], nullptr, nullptr, stage, nullptr, k.xray, (int)ray);
-          sc[j] = q.sigma; rc[j] = q.r; gc[j] = q.g; bc[j] = q.b;
-        }
+      for (int j = 0; j < 2; ++j) {
+        SampleOut q = field_wave<TEX, ATT, true, PREC, VD, SEMP>(P, k.scene_range, lane, ox + dx * tc[j], oy + dy * tc[j],
+                                                                 oz + dz * tc[j], val[j], semT ? semT + j * 64 : nullptr, nullptr,
+                                                                 stage, nullptr, k.xray, (int)ray);
+        sc[j] = q.sigma; rc[j] = q.r; gc[j] = q.g; bc[j] = q.b;
       }
       int n = S;
       float dep[4], sig[4], cr[4], cg[4], cb[4];
@@ -1849,20 +1864,17 @@ __global__ __launch_bounds__(256, NFI_RENDER_OCC) void render_fwd_wide_kernel(Re
       }
       if (k.fine) {
         // ---- hierarchical resampling + fine pass ----
-        float u[2], tf[2], wtap[2], smtap[2];
+        float u[2], tf[2], wtap[2], smtap[2], Tc[2];
         int ind[2];
 #pragma unroll
         for (int j = 0; j < 2; ++j) u[j] = val[j] ? k.noise_f[(size_t)ray * k.noise_f_stride + j * 64 + lane] : 0.0f;
         wave_lds_fence();
-        resample_ray_wide<2>(slab, sc, tc, S, dnorm, u, lane, tf, wtap, smtap, ind);
+        resample_ray_wide<2>(slab, sc, tc, S, dnorm, u, lane, tf, wtap, smtap, ind, Tc);
         bool vfine[2] = {val[0], val[1]};
-        if constexpr (FAST) {
-          // first coarse sample in front of which the transmittance is below eps; fine samples behind it are dropped
-          const float inc0 = wave_incl_scan_add_f32(odc[0]);
-          const float carry = bits2f((uint32_t)__builtin_amdgcn_readlane((int)f2bits(inc0), 63));
-          const float inc1 = carry + wave_incl_scan_add_f32(odc[1]);
-          const uint64_t dm0 = __ballot(val[0] && (inc0 - odc[0]) > k.fast_od);
-          const uint64_t dm1 = __ballot(val[1] && (inc1 - odc[1]) > k.fast_od);
+        if constexpr (TERM) {
+          // first coarse sample in front of which the coarse transmittance is below eps; fine samples behind it are dropped
+          const uint64_t dm0 = __ballot(val[0] && Tc[0] < k.term_eps);
+          const uint64_t dm1 = __ballot(val[1] && Tc[1] < k.term_eps);
           float t_dead = INFINITY;
           if (dm0) t_dead = bits2f((uint32_t)__builtin_amdgcn_readlane((int)f2bits(tc[0]), (int)__builtin_ctzll(dm0)));
           else if (dm1) t_dead = bits2f((uint32_t)__builtin_amdgcn_readlane((int)f2bits(tc[1]), (int)__builtin_ctzll(dm1)));
@@ -1885,9 +1897,10 @@ __global__ __launch_bounds__(256, NFI_RENDER_OCC) void render_fwd_wide_kernel(Re
         }
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-          SampleOut q = field_wave<TEX, ATT, true, PREC, VD>(P, k.scene_range, lane, ox + dx * tf[j], oy + dy * tf[j], oz + dz * tf[j],
-                                                             vfine[j], nullptr, nullptr, stage, nullptr, k.xray, (int)ray);
-          if (FAST && !vfine[j]) { q.sigma = 0.0f; q.r = 0.0f; q.g = 0.0f; q.b = 0.0f; }
+          SampleOut q = field_wave<TEX, ATT, true, PREC, VD, SEMP>(P, k.scene_range, lane, ox + dx * tf[j], oy + dy * tf[j],
+                                                                   oz + dz * tf[j], vfine[j], semT ? semT + 128 + j * 64 : nullptr,
+                                                                   nullptr, stage, nullptr, k.xray, (int)ray);
+          if (TERM && !vfine[j]) { q.sigma = 0.0f; q.r = 0.0f; q.g = 0.0f; q.b = 0.0f; }
           dep[2 + j] = tf[j]; sig[2 + j] = q.sigma; cr[2 + j] = q.r; cg[2 + j] = q.g; cb[2 + j] = q.b;
           eidx[2 + j] = val[j] ? S + j * 64 + lane : 0x7fffffff;
           if constexpr (TAPS) {
@@ -1917,6 +1930,32 @@ __global__ __launch_bounds__(256, NFI_RENDER_OCC) void render_fwd_wide_kernel(Re
       if (lane == 0) {
         k.rgb[(size_t)ray * 3] = o.r; k.rgb[(size_t)ray * 3 + 1] = o.g; k.rgb[(size_t)ray * 3 + 2] = o.b;
         k.depth[ray] = o.depth; k.mask[ray] = o.mask;
+      }
+      if constexpr (EXTRA) {
+        if (k.coords) composite_coords<4>(slab, w, n, lane, ox, oy, oz, dx, dy, dz, k.coords + (size_t)ray * 3);
+        if constexpr (SEMP > 0) {
+          if (semT) {
+            // the merged weights back in source order (the cdf row is free after the merge)
+            wave_lds_fence();
+#pragma unroll
+            for (int j = 0; j < 4; ++j) slab.cdf[j * 64 + lane] = w[j];
+            wave_lds_fence();
+            float ws[4];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+              ws[j] = val[j] ? slab.cdf[rank[j]] : 0.0f;
+              ws[2 + j] = (val[j] && k.fine) ? slab.cdf[rank[2 + j]] : 0.0f;
+            }
+            const lds_float* sl = (const lds_float*)semT;
+            float mine = 0.0f;
+            for (int a = 0; a < k.A; ++a) {
+              const lds_float* row = sl + a * kSemPitchWide + lane;
+              const float sa = wave_sum((ws[0] * row[0] + ws[1] * row[64]) + (ws[2] * row[128] + ws[3] * row[192]));
+              if (lane == a) mine = sa;
+            }
+            if (lane < k.A) k.semantics[(size_t)ray * k.A + lane] = mine;
+          }
+        }
       }
       if constexpr (TAPS) {
         if (lane == 0) {
@@ -2006,7 +2045,7 @@ extern "C" int nfi_render_fwd(const nfi_render_args* a, nfi_stream_t stream) {
   REQUIRE(a->n_samples >= 4 && a->n_samples <= NFI_MAX_SAMPLES, "render: n_samples must be in [4,128] per pass");
   REQUIRE(a->n_samples <= 64 || !a->profile_cycles, "render: the cycle profile exists for n_samples <= 64 only");
   REQUIRE(!a->fine_sampling || a->noise_fine, "render: fine sampling needs u (noise_fine)");
-  REQUIRE(!a->semantics, "render: composited semantics are produced by nfi_composite_fwd, not the fused kernel");
+  REQUIRE(!a->semantics || a->n_attention > 0, "render: composited semantics need attention values (A > 0)");
   int rc = check_field_common(a->texels, a->plane_res, a->texel_dtype, a->decoder_image, a->n_attention,
                                a->attention_values, a->use_sdf, a->beta, a->alpha, a->texel_layout);
   if (rc) return rc;
@@ -2019,6 +2058,8 @@ extern "C" int nfi_render_fwd(const nfi_render_args* a, nfi_stream_t stream) {
   uint32_t* xcd_counter = w.xcd_counter;
   float *ro = w.ro, *rd = w.rd, *near_raw = w.near_raw, *far_raw = w.far_raw;
   uint8_t* hit = w.hit;
+  REQUIRE(!(a->rays_ready && (a->ray_origins || a->ray_directions || a->hit || a->stash_t)),
+          "render: rays_ready needs the ray set-up in the workspace (no ray_origins / ray_directions / hit taps, no stash)");
   if (!a->rays_ready) {
     rc = render_setup(a, w, s);
     if (rc) return rc;
@@ -2059,39 +2100,39 @@ extern "C" int nfi_render_fwd(const nfi_render_args* a, nfi_stream_t stream) {
   k.width = a->width;
   // per-XCD queues (tuning bit 4 switches them off): square pixel blocks, needs image sides that are multiples of 8
   {
-    // defaults: the largest of 32 / 16 / 8-pixel blocks that divides both image sides, TWO positions per atomic.
-    // MI355X, 8 x 128^2 x (64+64), ms per launch chairs-like / every ray hits / one image (tools/quick_bench.py with
-    // NFI_TUNING, warm clocks): 32x32 + 2: 0.854 / 1.299 / 0.164; 8x8 + 2: 0.848 / 1.328 / 0.167; 16x16 + 2:
-    // 0.891 / 1.301 / 0.170; 16x16 + 1 (the round-1 default): 0.933 / 1.311 / 0.185; 32x32 + 1: 0.882 / 1.317 / 0.174;
-    // 4 per atomic: 0.88-0.90 / 1.33-1.38; one device-wide counter 1.82 / 2.10.  Halving the atomics matters on every
-    // workload (the wave waits for each one's result); the block side mostly through the balance of the chairs-like
-    // images, whose rays that cross the cube are clustered.  Experiment knobs: bits 5-6 = 1 -> 8x8, 2 -> 32x32,
-    // 3 -> 16x16 blocks; bit 7 -> 4, bit 8 -> 1 position per atomic.
-    k.fetch_batch = ((a->tuning >> 7) & 1) ? 4 : (((a->tuning >> 8) & 1) ? 1 : 2);
-    const int sel = (a->tuning >> 5) & 3;
+    // the largest of 32 / 16 / 8-pixel blocks that divides both image sides, TWO positions per atomic.
+    // MI355X, 8 x 128^2 x (64+64), ms per launch chairs-like / every ray hits / one image (round 3, build-time variants):
+    // 32x32 + 2: 0.854 / 1.299 / 0.164; 8x8 + 2: 0.848 / 1.328 / 0.167; 16x16 + 2: 0.891 / 1.301 / 0.170; 16x16 + 1 (the
+    // round-1 default): 0.933 / 1.311 / 0.185; 32x32 + 1: 0.882 / 1.317 / 0.174; 4 per atomic: 0.88-0.90 / 1.33-1.38; one
+    // device-wide counter 1.82 / 2.10.  Halving the atomics matters on every workload (the wave waits for each one's
+    // result); the block side mostly through the balance of the chairs-like images, whose rays that cross the cube are
+    // clustered.
+    k.fetch_batch = 2;
     const int both = a->width | a->height;
-    k.xcd_block_shift = sel == 1 ? 3 : (sel == 2 ? 5 : (sel == 3 ? 4 : ((both & 31) == 0 ? 5 : ((both & 15) == 0 ? 4 : 3))));
+    k.xcd_block_shift = (both & 31) == 0 ? 5 : ((both & 15) == 0 ? 4 : 3);
     const int side = 1 << k.xcd_block_shift;
     k.xcd_blocks = (((a->tuning >> 4) & 1) == 0 && (a->width % side == 0) && (a->height % side == 0)) ? 1 : 0;
     const uint32_t bw = (uint32_t)a->width >> k.xcd_block_shift, bh = (uint32_t)a->height >> k.xcd_block_shift;
     k.div_hw = make_fastdiv((uint32_t)k.hw);
     k.div_bw = make_fastdiv(bw > 0 ? bw : 1u);
     k.div_bps = make_fastdiv(bw * bh > 0 ? bw * bh : 1u);
-    // (A scene-per-XCD hand-out - queue q holding the blocks of scenes q, q+8, ... so that every XCD's L2 holds one
-    // scene's texels - was tried in round 2 and is slower: the shared scene keeps the eight L2s' misses on lines another
-    // XCD has just pulled into the Infinity Cache.  Even as a run-time option it cost the default path 13 %, the extra
-    // division in the per-ray position decode; removed, DESIGN.md "negative results".)
   }
   k.xcd_counter = xcd_counter;
   k.tile_order = (((a->tuning >> 2) & 1) == 0 && (a->width % 8 == 0) && (a->height % 8 == 0)) ? 1 : 0;
   k.prof = (unsigned long long*)a->profile_cycles;
   k.xray = a->ray_features;
   k.clock_probe = reinterpret_cast<unsigned long long*>(a->clock_probe);
-  const bool fast = a->fast_termination > 0.0f;
-  REQUIRE(a->fast_termination >= 0.0f && a->fast_termination < 1.0f, "render: fast_termination must be in [0,1)");
-  REQUIRE(!fast || !(any_tap || a->profile_cycles || a->ray_features || ((a->tuning >> 3) & 1)),
-          "render: fast_termination cannot be combined with stage taps, the cycle profile, the view-direction decoder or the exact-fp32 MLP");
-  k.fast_od = fast ? -logf(a->fast_termination) : 0.0f;
+  const bool strict = ((a->tuning >> 3) & 1) != 0;   // exact-fp32 MLP instead of the split-fp16 one
+  const bool term = a->termination_eps > 0.0f;
+  const bool extra = a->semantics || a->coords;
+  REQUIRE(a->termination_eps >= 0.0f && a->termination_eps < 1.0f, "render: termination_eps must be in [0,1)");
+  REQUIRE(!term || a->fine_sampling, "render: termination_eps acts on the fine pass (fine_sampling)");
+  REQUIRE(!term || !(any_tap || extra || a->profile_cycles || a->ray_features || strict),
+          "render: termination_eps cannot be combined with stage taps, extra maps, the cycle profile, the view-direction decoder or the exact-fp32 MLP");
+  REQUIRE(!extra || !(any_tap || a->profile_cycles || a->ray_features || strict),
+          "render: semantics / coords maps cannot be combined with stage taps, the cycle profile, the view-direction decoder or the exact-fp32 MLP");
+  k.term_eps = a->termination_eps;
+  k.semantics = a->semantics; k.coords = a->coords;
   REQUIRE(!(a->ray_features && a->profile_cycles), "render: no cycle profile with the view-direction decoder");
   // persistent 1-D grid: OCC blocks of 4 waves per CU, never more blocks than rays need
   // 2 blocks (8 waves) per CU: with the whole 256-VGPR budget the field tile keeps more loads and MFMA chains in
@@ -2104,30 +2145,40 @@ extern "C" int nfi_render_fwd(const nfi_render_args* a, nfi_stream_t stream) {
   if (blocks3 > (n + 3) / 4) blocks3 = (n + 3) / 4;
   dim3 grid((unsigned)blocks), grid3((unsigned)blocks3);
   bool att = a->n_attention > 0;
+  // kRenderExtra with semantics: the per-wave tables [A][pitch] in dynamic LDS
+  const bool wide = a->n_samples > 64;
+  const size_t sem_lds = a->semantics ? (size_t)4 * a->n_attention * (wide ? kSemPitchWide : kSemPitch) * sizeof(float) : 0;
+  constexpr size_t kSemLdsMax = (size_t)4 * NFI_MAX_ATTENTION * kSemPitch * sizeof(float);
+  constexpr size_t kSemLdsMaxWide = (size_t)4 * NFI_MAX_ATTENTION * kSemPitchWide * sizeof(float);
   if (a->event_start) (void)hipEventRecord((hipEvent_t)a->event_start, s);
-  const bool strict = ((a->tuning >> 3) & 1) != 0;   // exact-fp32 MLP instead of the split-fp16 one
 #define NFI_LAUNCH_RENDER(TEX, ATT)                                                                                   \
   do {                                                                                                                \
-    if (fast) hipLaunchKernelGGL((render_fwd_kernel<TEX, ATT, NFI_RENDER_OCC, false, 1, false, false, true>), grid, dim3(256), 0, s, k); \
-    else if (k.prof) hipLaunchKernelGGL((render_fwd_kernel<TEX, ATT, NFI_RENDER_OCC, false, 1, true>), grid, dim3(256), 0, s, k);    \
-    else if (any_tap && strict) hipLaunchKernelGGL((render_fwd_kernel<TEX, ATT, NFI_RENDER_OCC, true, 0>), grid, dim3(256), 0, s, k); \
-    else if (any_tap) hipLaunchKernelGGL((render_fwd_kernel<TEX, ATT, NFI_RENDER_OCC, true, 1>), grid, dim3(256), 0, s, k);          \
-    else if (strict) hipLaunchKernelGGL((render_fwd_kernel<TEX, ATT, NFI_RENDER_OCC, false, 0>), grid, dim3(256), 0, s, k);          \
-    else if (TEX == 2 && NFI_FP16_MIX) hipLaunchKernelGGL((render_fwd_kernel<2, ATT, 3, false, 1>), grid3, dim3(256), 0, s, k);        \
-    else hipLaunchKernelGGL((render_fwd_kernel<TEX, ATT, NFI_RENDER_OCC, false, 1>), grid, dim3(256), 0, s, k);                      \
+    if (extra) {                                                                                                      \
+      NFI_ENSURE_DYNAMIC_LDS((render_fwd_kernel<TEX, ATT, NFI_RENDER_OCC, kRenderExtra, 1>), kSemLdsMax, "render");    \
+      hipLaunchKernelGGL((render_fwd_kernel<TEX, ATT, NFI_RENDER_OCC, kRenderExtra, 1>), grid, dim3(256), sem_lds, s, k); \
+    } else if (term) hipLaunchKernelGGL((render_fwd_kernel<TEX, ATT, NFI_RENDER_OCC, kRenderTerm, 1>), grid, dim3(256), 0, s, k); \
+    else if (k.prof) hipLaunchKernelGGL((render_fwd_kernel<TEX, ATT, NFI_RENDER_OCC, kRenderProf, 1>), grid, dim3(256), 0, s, k);    \
+    else if (any_tap && strict) hipLaunchKernelGGL((render_fwd_kernel<TEX, ATT, NFI_RENDER_OCC, kRenderTaps, 0>), grid, dim3(256), 0, s, k); \
+    else if (any_tap) hipLaunchKernelGGL((render_fwd_kernel<TEX, ATT, NFI_RENDER_OCC, kRenderTaps, 1>), grid, dim3(256), 0, s, k);          \
+    else if (strict) hipLaunchKernelGGL((render_fwd_kernel<TEX, ATT, NFI_RENDER_OCC, kRenderPlain, 0>), grid, dim3(256), 0, s, k);          \
+    else if (TEX == 2) hipLaunchKernelGGL((render_fwd_kernel<2, ATT, 3, kRenderPlain, 1>), grid3, dim3(256), 0, s, k);        \
+    else hipLaunchKernelGGL((render_fwd_kernel<TEX, ATT, NFI_RENDER_OCC, kRenderPlain, 1>), grid, dim3(256), 0, s, k);                      \
   } while (0)
 #define NFI_LAUNCH_RENDER_WIDE(TEX, ATT)                                                                             \
   do {                                                                                                                \
-    if (fast) hipLaunchKernelGGL((render_fwd_wide_kernel<TEX, ATT, false, 1, false, true>), grid, dim3(256), 0, s, k);   \
-    else if (any_tap && strict) hipLaunchKernelGGL((render_fwd_wide_kernel<TEX, ATT, true, 0>), grid, dim3(256), 0, s, k); \
-    else if (any_tap) hipLaunchKernelGGL((render_fwd_wide_kernel<TEX, ATT, true, 1>), grid, dim3(256), 0, s, k);        \
-    else if (strict) hipLaunchKernelGGL((render_fwd_wide_kernel<TEX, ATT, false, 0>), grid, dim3(256), 0, s, k);        \
-    else hipLaunchKernelGGL((render_fwd_wide_kernel<TEX, ATT, false, 1>), grid, dim3(256), 0, s, k);                    \
+    if (extra) {                                                                                                      \
+      NFI_ENSURE_DYNAMIC_LDS((render_fwd_wide_kernel<TEX, ATT, kRenderExtra, 1>), kSemLdsMaxWide, "render");           \
+      hipLaunchKernelGGL((render_fwd_wide_kernel<TEX, ATT, kRenderExtra, 1>), grid, dim3(256), sem_lds, s, k);         \
+    } else if (term) hipLaunchKernelGGL((render_fwd_wide_kernel<TEX, ATT, kRenderTerm, 1>), grid, dim3(256), 0, s, k);   \
+    else if (any_tap && strict) hipLaunchKernelGGL((render_fwd_wide_kernel<TEX, ATT, kRenderTaps, 0>), grid, dim3(256), 0, s, k); \
+    else if (any_tap) hipLaunchKernelGGL((render_fwd_wide_kernel<TEX, ATT, kRenderTaps, 1>), grid, dim3(256), 0, s, k);        \
+    else if (strict) hipLaunchKernelGGL((render_fwd_wide_kernel<TEX, ATT, kRenderPlain, 0>), grid, dim3(256), 0, s, k);        \
+    else hipLaunchKernelGGL((render_fwd_wide_kernel<TEX, ATT, kRenderPlain, 1>), grid, dim3(256), 0, s, k);                    \
   } while (0)
 #define NFI_LAUNCH_RENDER_VD(TEX, ATT)                                                                                        \
   do {                                                                                                                      \
-    if (a->n_samples > 64) hipLaunchKernelGGL((render_fwd_wide_kernel<TEX, ATT, true, 0, true>), grid, dim3(256), 0, s, k);   \
-    else hipLaunchKernelGGL((render_fwd_kernel<TEX, ATT, NFI_RENDER_OCC, true, 0, false, true>), grid, dim3(256), 0, s, k);                \
+    if (wide) hipLaunchKernelGGL((render_fwd_wide_kernel<TEX, ATT, kRenderTaps, 0, true>), grid, dim3(256), 0, s, k);   \
+    else hipLaunchKernelGGL((render_fwd_kernel<TEX, ATT, NFI_RENDER_OCC, kRenderTaps, 0, true>), grid, dim3(256), 0, s, k);                \
   } while (0)
   if (a->ray_features) {
     if (a->texel_dtype == NFI_TEXEL_F32) {
@@ -2137,7 +2188,7 @@ extern "C" int nfi_render_fwd(const nfi_render_args* a, nfi_stream_t stream) {
     } else {
       if (att) NFI_LAUNCH_RENDER_VD(2, true); else NFI_LAUNCH_RENDER_VD(2, false);
     }
-  } else if (a->n_samples > 64) {
+  } else if (wide) {
     if (a->texel_dtype == NFI_TEXEL_F32) {
       if (att) NFI_LAUNCH_RENDER_WIDE(0, true); else NFI_LAUNCH_RENDER_WIDE(0, false);
     } else if (a->texel_dtype == NFI_TEXEL_BF16) {

@@ -77,37 +77,36 @@ class _distance_head:
         self.training = getattr(decoder, 'training', False)
 
 
-def texels_of(planes, texel_dtype=ops.TEXEL_F32):
+def texels_of(planes, texel_dtype=ops.TEXEL_F32, cache=None):
     """The hand-off (generator.py:475-477 -> the kernels): a producer whose [B,96,R,R] output is channels-last in memory
     is read in place (interleaved texel layout, no kernel, no copy); an NCHW producer goes through the one transposition
-    launch nfi_planes_to_texels."""
+    launch nfi_planes_to_texels.
+
+    cache: a dict that lives for ONE forward call.  One forward asks twice (the sampler and the regulariser branch) and
+    the planes cannot change in between; nothing is kept beyond the call, so a planes tensor that a caller updates
+    through ``.data`` (EMA / inversion code in the style of run.py's ``z_.data[:] = ...``: no _version bump) can never
+    meet a stale transposed copy."""
     p = planes.detach()
     v = ops.planes_view_as_texels(p) if p.dtype == torch.float32 else None
     if v is not None:
         return v if texel_dtype == ops.TEXEL_F32 else v.to(ops._TEXEL_TORCH[texel_dtype])
-    # one forward asks twice (the sampler and the regulariser branch): the transposed copy stays with the planes tensor
-    # object (and goes away with it); an in-place update of the planes bumps _version and invalidates it
-    key = (planes._version, texel_dtype)
-    hit = getattr(planes, '_nfi_texels', None)
-    if hit is not None and hit[0] == key:
-        return hit[1]
-    t = ops.planes_to_texels(p, texel_dtype)
-    try:
-        planes._nfi_texels = (key, t)
-    except AttributeError:           # (a tensor subclass with __slots__)
-        pass
-    return t
+    if cache is None:
+        return ops.planes_to_texels(p, texel_dtype)
+    key = (id(planes), texel_dtype)
+    if key not in cache:
+        cache[key] = (planes, ops.planes_to_texels(p, texel_dtype))      # (the tensor is held so that its id stays its own)
+    return cache[key][1]
 
 
 def make_sampler(planes, decoder, scene_range, n_attention, attention_values, use_sdf, beta, alpha,
-                 texel_dtype=ops.TEXEL_F32, request_model_outputs=(), viewdir=None):
+                 texel_dtype=ops.TEXEL_F32, request_model_outputs=(), viewdir=None, texel_cache=None):
     """Builds the ``sampler(x_in, request_sampler_outputs)`` closure over HIP kernels.
 
     planes [B,3,32,R,R] (view of the synthesis output), decoder: module with .net[0]/.net[2].
     viewdir (--use_viewdir): (ray_feature [B,H,W,1,32] = output of ViewDirectionMapper.fc6, output_layer =
     the mapper's `output` EqualizedLinear); the closure of generator.py:243-251 is then part of the kernels."""
     w1, b1, w2, b2 = decoder_parameters(decoder)
-    texels = texels_of(planes, texel_dtype)
+    texels = texels_of(planes, texel_dtype, texel_cache)
     ray_feature = w3 = b3 = ray_pad = None
     if viewdir is not None:
         ray_feature, out_layer = viewdir
@@ -120,6 +119,7 @@ def make_sampler(planes, decoder, scene_range, n_attention, attention_values, us
     fused = FusedField(texels, image, attention_values, n_attention, use_sdf, beta, alpha, scene_range,
                        planes=planes, decoder_params=(w1, b1, w2, b2) + ((ray_feature, w3, b3) if viewdir is not None else ()))
     fused.ray_features = ray_pad
+    fused.bbox_overlay = 'bbox' in request_model_outputs      # the coords request then edits sigma (generator.py:645-659)
 
     def sampler(x_in, request_sampler_outputs=['sigma', 'rgb'], mlp_split_fp16=False):
         # mlp_split_fp16 (not in the reference's signature; render() sets it): the decoder arithmetic of the fused
@@ -203,13 +203,13 @@ def sample_volume_stratified(batch_size, nstrata, scene_range, device=None):
     return ((cell + jitter) / n * 2 - 1).reshape(batch_size, n ** 3, 3) * scene_range
 
 
-def sdf_and_gradient(points, planes, decoder, scene_range):
+def sdf_and_gradient(points, planes, decoder, scene_range, texel_cache=None):
     """(sdf [B,P], d sdf / d points [B,P,3]) at fixed points as ONE autograd node (HIP forward + HIP backward): the
     gradient output replaces torch.autograd.grad(..., create_graph=True) of generator.py:534-540, its backward is the
     double backward lib/ops.grid_sample2d exists for.  Differentiable w.r.t. planes and the decoder parameters."""
     w1, b1, w2, b2 = decoder_parameters(decoder)
     pts = points.detach()
-    texels = texels_of(planes)
+    texels = texels_of(planes, cache=texel_cache)
 
     def fwd(pl, a_w1, a_b1, a_w2, a_b2):
         return ops.sdf_gradient_fwd(pts, texels, a_w1, a_b1, a_w2, a_b2, scene_range)
@@ -221,14 +221,14 @@ def sdf_and_gradient(points, planes, decoder, scene_range):
     return differentiable('sdf_gradient', fwd, planes, w1, b1, w2, b2, bwd=bwd)
 
 
-def regulariser_outputs(self, planes, request_model_outputs):
+def regulariser_outputs(self, planes, request_model_outputs, texel_cache=None):
     """generator.py:505-585 on HIP kernels: eikonal / distance / total-variation / entropy terms of the SDF."""
     out = {}
     assert torch.is_grad_enabled()
     bins_in = sample_volume_stratified(planes.shape[0], 32, self.scene_range, device=planes.device)
     if 'sdf_eikonal_loss' in request_model_outputs:
         assert self.use_sdf and self.training
-    d, g = sdf_and_gradient(bins_in, planes, self.decoder, self.scene_range)
+    d, g = sdf_and_gradient(bins_in, planes, self.decoder, self.scene_range, texel_cache)
     if 'sdf_eikonal_loss' in request_model_outputs:
         out['sdf_eikonal_loss'] = ((g.norm(dim=-1) - 1) ** 2).flatten(1).mean(dim=1)
     if 'sdf_distance_loss' in request_model_outputs:
@@ -248,7 +248,8 @@ def regulariser_outputs(self, planes, request_model_outputs):
             n_att = 0 if self.use_viewdir else self.attention_values
             smp = make_sampler(planes, dec, self.scene_range, n_att,
                                torch.zeros((planes.shape[0], max(n_att, 1), 3), device=planes.device),
-                               self.use_sdf, self.beta if self.use_sdf else None, self.alpha if self.use_sdf else None)
+                               self.use_sdf, self.beta if self.use_sdf else None, self.alpha if self.use_sdf else None,
+                               texel_cache=texel_cache)
             d_p = smp((coords_p * self.scene_range).detach(), ['sdf_distance'])['sdf_distance'][..., 0]
         if self.use_sdf:
             beta = self.beta
@@ -322,6 +323,7 @@ def hip_forward(self, viewdir, c, request_model_outputs=['sampler'], model_input
     planes = planes.view(batch, 3, 32, planes.shape[-2], planes.shape[-1])
 
     model_outputs = {}
+    texel_cache = {}                 # the transposed texels of THIS forward (sampler + regulariser branch), see texels_of
     if 'attention_values' in request_model_outputs:
         assert self.attention_values > 0
         model_outputs['attention_values'] = attention_values
@@ -337,7 +339,7 @@ def hip_forward(self, viewdir, c, request_model_outputs=['sampler'], model_input
 
     if any(r in request_model_outputs for r in ('sdf_eikonal_loss', 'total_variation_loss', 'entropy_loss')):
         # (as in the reference, 'sdf_distance_loss' is only produced together with one of these three, 505-506 / 542)
-        model_outputs.update(regulariser_outputs(self, planes, request_model_outputs))
+        model_outputs.update(regulariser_outputs(self, planes, request_model_outputs, texel_cache))
 
     if 'sampler' in request_model_outputs:
         vd = None
@@ -350,7 +352,7 @@ def hip_forward(self, viewdir, c, request_model_outputs=['sampler'], model_input
             planes, self.decoder, self.scene_range, self.attention_values, attention_values, self.use_sdf,
             self.beta if self.use_sdf else None, self.alpha if self.use_sdf else None,
             texel_dtype=getattr(self, 'nfi_texel_dtype', ops.TEXEL_F32), request_model_outputs=request_model_outputs,
-            viewdir=vd)
+            viewdir=vd, texel_cache=texel_cache)
     return model_outputs
 
 
@@ -404,15 +406,16 @@ def wrapped_forward(self, viewdir, c, request_model_outputs=['sampler'], model_i
     planes = captured.get('planes')
     if planes is not None:
         planes = planes.view(planes.shape[0], 3, 32, planes.shape[-2], planes.shape[-1])
+    texel_cache = {}
     if hip_reg:
-        model_outputs.update(regulariser_outputs(self, planes, request_model_outputs))
+        model_outputs.update(regulariser_outputs(self, planes, request_model_outputs, texel_cache))
     if want_sampler:
         att = model_outputs.get('attention_values') if self.attention_values > 0 else None
         model_outputs['sampler'] = make_sampler(
             planes, self.decoder, self.scene_range, self.attention_values, att, self.use_sdf,
             self.beta if self.use_sdf else None, self.alpha if self.use_sdf else None,
             texel_dtype=getattr(self, 'nfi_texel_dtype', ops.TEXEL_F32), request_model_outputs=request_model_outputs,
-            viewdir=(cap['x'], self.viewdir_mapper.output) if use_vd else None)
+            viewdir=(cap['x'], self.viewdir_mapper.output) if use_vd else None, texel_cache=texel_cache)
     if added_att:
         del model_outputs['attention_values']
     return model_outputs

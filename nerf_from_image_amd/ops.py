@@ -380,7 +380,8 @@ def render_fwd(cam2world, focal, height, width, num_samples, texels, decoder_ima
                attention_values=None, use_sdf=True, beta=None, alpha=None, bbox=None, center=None,
                noise_coarse=None, noise_fine=None, fine_sampling=True, white_background=True, taps=(),
                skip_missed_rays=True, workspace=None, events=None, tuning=0, profile_cycles=None, ray_features=None,
-               fast_termination=0.0, row_window=None, clock_probe=None, stash=False, rays_ready=False):
+               termination_eps=0.0, row_window=None, clock_probe=None, stash=False, rays_ready=False,
+               want_semantics=False, want_coords=False):
     """Fused forward render.  Returns dict(rgb [B,H,W,3], depth, mask [B,H,W], + requested taps).
     row_window: None, or (row_offset, full_height): `height` rows starting at row_offset of an image full_height rows tall
     (bit-identical to those rows of the full render; noise / outputs / taps are sized for the window).
@@ -389,8 +390,11 @@ def render_fwd(cam2world, focal, height, width, num_samples, texels, decoder_ima
     (coarse samples in [..., :S], fine in [..., S:], source order; skipped rays hold zeros) and 'ray_origins' /
     'ray_directions' - what composite_bwd(list_row_stride=2S) + field_query_bwd need for the backward of the render.
     ray_features: padded [B,H,W,48] per-ray view-direction features (decoder_pack_viewdir image).
-    fast_termination: 0 = exact; eps in (0,1) = opt-in transmittance-threshold termination + sample compaction (NOT
-    parity: rgb/mask change by O(eps), see include/nfi_hip.h)."""
+    termination_eps: 0 = off; eps in (0,1): fine samples behind the depth at which the COARSE transmittance has fallen
+    below eps are not evaluated and the rest is compacted by wave ballot (the coarse pass, the pdf and every sample index
+    are untouched; |d rgb| <= ~eps, see include/nfi_hip.h).
+    want_semantics / want_coords: also return 'semantics' [B,H,W,A] (composited softmax probabilities, run.py:312-335)
+    / 'coords' [B,H,W,3] (composited query points, run.py:337-338) from the SAME launch."""
     cam2world = _f32c(cam2world, 'tform_cam2world')
     B = cam2world.shape[0]
     dev = cam2world.device
@@ -427,7 +431,20 @@ def render_fwd(cam2world, focal, height, width, num_samples, texels, decoder_ima
         tap_t['stash_t'] = torch.empty((B, height, width, 2 * S), dtype=torch.float32, device=dev)
         tap_t['stash_sigma'] = torch.empty((B, height, width, 2 * S), dtype=torch.float32, device=dev)
         tap_t['stash_rgb'] = torch.empty((B, height, width, 2 * S, 3), dtype=torch.float32, device=dev)
+    if want_semantics:
+        if n_attention <= 0:
+            raise ValueError('render_fwd: semantics need attention values (n_attention > 0)')
+        tap_t['semantics'] = torch.empty((B, height, width, n_attention), dtype=torch.float32, device=dev)
+    if want_coords:
+        tap_t['coords'] = torch.empty((B, height, width, 3), dtype=torch.float32, device=dev)
     ws_bytes = lib.nfi_render_workspace_bytes(n)
+    if rays_ready:
+        # the kernel would march whatever the workspace holds: refuse anything that is not nfi_render_setup's own result
+        if workspace is None or workspace.numel() < ws_bytes:
+            raise ValueError('render_fwd(rays_ready=True) needs the workspace render_setup filled (%d bytes)' % ws_bytes)
+        if stash or any(name in tap_t for name in ('ray_origins', 'ray_directions', 'hit')):
+            raise ValueError('render_fwd(rays_ready=True) cannot be combined with the stash or the ray_origins / '
+                             'ray_directions / hit taps (they redirect the ray set-up away from the workspace)')
     if workspace is None or workspace.numel() < ws_bytes:
         workspace = torch.empty((ws_bytes,), dtype=torch.uint8, device=dev)
     if fine_sampling:
@@ -454,7 +471,7 @@ def render_fwd(cam2world, focal, height, width, num_samples, texels, decoder_ima
             workspace=workspace, workspace_bytes=workspace.numel(), skip_missed_rays=int(skip_missed_rays),
             event_start=None if events is None else events[0], event_stop=None if events is None else events[1],
             tuning=int(tuning), profile_cycles=profile_cycles, ray_features=ray_features,
-            fast_termination=float(fast_termination), clock_probe=clock_probe,
+            termination_eps=float(termination_eps), clock_probe=clock_probe,
             row_offset=0 if row_window is None else int(row_window[0]),
             full_height=0 if row_window is None else int(row_window[1]), rays_ready=int(bool(rays_ready)), **tap_t)
     out.update(tap_t)

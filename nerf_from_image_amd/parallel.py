@@ -66,15 +66,63 @@ def gather_rows(window, dim=1):
     return full.movedim(0, dim).contiguous()
 
 
+def allreduce_ray_setup(workspace, group=None):
+    """Makes the batch-wide miss-fill of a row-sharded render the FULL image's (lib/nerf_utils.py:258-259: missed rays take
+    min(near) / max(far) over the rays of the batch that hit the cube).  `workspace` is what ops.render_setup filled for
+    this rank's row window; its first three 32-bit cells hold order-preserving keys of (min near, max far) over the
+    window's hit rays and their count (csrc: raygen_kernel).  Max-reducing the two keys and summing the count over the
+    ranks between the set-up and ops.render_fwd(rays_ready=True) gives every band the fill of the whole image, so a
+    band is bit-identical to the same rows of the full render even for rays that are marched although they miss the
+    exact cube (or with skip_missed_rays off).  Without it the identity holds only where no such ray is marched."""
+    rank, w = world()
+    if group is not None:
+        w = dist.get_world_size(group)
+    if w == 1:
+        return
+    cells = workspace[:12].view(torch.int32)
+    v = cells.to(torch.int64) & 0xFFFFFFFF            # the cells are unsigned
+    dist.all_reduce(v[:2], op=dist.ReduceOp.MAX, group=group)
+    dist.all_reduce(v[2:], op=dist.ReduceOp.SUM, group=group)
+    cells.copy_(torch.where(v >= 2 ** 31, v - 2 ** 32, v).to(torch.int32))
+
+
 def render_image_rows(render_rows, height, dim=1):
     """One image over all ranks: `render_rows(row0, row1)` renders this rank's band (e.g. a render bound with
     ``make_render(..., row_window=(row0, row1 - row0))`` or ops.render_fwd(row_window=(row0, height))) and returns a tensor
-    or a tuple of tensors with the rows along `dim`; the bands are gathered into full images on every rank."""
+    or a tuple of tensors with the rows along `dim`; the bands are gathered into full images on every rank.
+
+    A rank whose band is EMPTY (more ranks than 8-row strips: a 32-row image on 8 ranks) does not call `render_rows` -
+    the render kernels refuse a zero-row image - and contributes zero-row tensors instead; their shapes and dtypes come
+    from a small metadata exchange with the ranks that did render, so every rank still enters the same collectives."""
     r0, r1 = shard_rows(height)
-    out = render_rows(r0, r1)
-    if isinstance(out, (tuple, list)):
-        return tuple(None if o is None else gather_rows(o, dim) for o in out)
-    return gather_rows(out, dim)
+    rank, w = world()
+    out = render_rows(r0, r1) if r1 > r0 else None
+    if w == 1:
+        if out is None:
+            raise ValueError('render_image_rows: the image has no rows')
+        return tuple(out) if isinstance(out, (tuple, list)) else out
+    single = out is not None and not isinstance(out, (tuple, list))
+    items = None if out is None else ([out] if single else list(out))
+    spec = None if items is None else dict(
+        single=single, device=str(next(o.device for o in items if o is not None).type),
+        items=[None if o is None else (tuple(o.shape), str(o.dtype).replace('torch.', '')) for o in items])
+    specs = [None] * w
+    dist.all_gather_object(specs, spec)
+    have = next((sp for sp in specs if sp is not None), None)
+    if have is None:
+        raise ValueError('render_image_rows: no rank has rows to render (height %d)' % height)
+    if items is None:
+        dev = torch.device('cuda', torch.cuda.current_device()) if have['device'] == 'cuda' else torch.device(have['device'])
+        items = []
+        for it in have['items']:
+            if it is None:
+                items.append(None)
+                continue
+            shape = list(it[0])
+            shape[dim] = 0
+            items.append(torch.zeros(shape, dtype=getattr(torch, it[1]), device=dev))
+    res = tuple(None if o is None else gather_rows(o, dim) for o in items)
+    return res[0] if have['single'] else res
 
 
 class GradientBuckets:

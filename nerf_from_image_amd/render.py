@@ -6,14 +6,16 @@
     render = nfi_render.render                           # replaces run.py's own def
 
 Three execution paths, all HIP through the C ABI:
-  * fused          - one persistent launch for the whole pipeline (no gradient, no per-sample extras);
+  * fused          - one persistent launch for the whole pipeline (no gradient); the composited `semantics` and `coords`
+                     maps (compute_semantics / compute_coords: run.py:1639-1646, 2036-2051) come out of the same launch;
   * fused + stash  - the SAME launch when a gradient is needed (training / inversion, fine sampling on): the kernel also
                      writes a per-sample stash (depths, sigma, rgb of the 2S samples of every ray, ray-major), and the
                      whole render is ONE autograd node whose backward is compositing backward on the stash -> one field
                      backward launch over the 2S points of every ray (+ its binned plane-gradient scatter) -> ray /
                      camera backward.  Replaces the ~20 launches of the staged graph;
-  * staged         - one launch per stage through ``nerf_utils`` and the ``sampler`` closure: normals / semantics /
-                     coords maps, the view-direction decoder with a gradient, or no fine sampling with a gradient.
+  * staged         - one launch per stage through ``nerf_utils`` and the ``sampler`` closure: the normals map, extra maps
+                     with a gradient / the view-direction decoder / the 'bbox' overlay, the view-direction decoder with a
+                     gradient, or no fine sampling with a gradient.
 Randomness follows the reference, in its order: ``torch.rand`` of [B,H,W,S] for the stratified
 jitter (nerf_utils.py:115) BEFORE the model is called (its synthesis network draws noise of its own
 in training), then ``torch.rand`` of [B*H*W,S] for the inverse-CDF draws (nerf_utils.py:202), even
@@ -21,13 +23,19 @@ in eval (``randomize`` defaults to True and no caller overrides it).
 
 Options (``configure(..., **options)`` / ``make_render(..., **options)``; per bound render function, nothing
 process-wide - the reference calls render from one thread per GPU):
-  fast_termination  0 = exact (default).  eps in (0,1): opt-in, NOT parity - transmittance threshold below which the
-                    fused inference kernel stops marching a ray (ops.render_fwd(fast_termination=...), DESIGN.md);
+  termination_eps   0 = off (default).  eps in (0,1): the fused inference kernel does not evaluate fine samples behind the
+                    depth at which the COARSE transmittance has fallen below eps and compacts the rest by wave ballot
+                    (coarse pass, pdf and sample indices untouched; |d rgb| <= ~eps; ops.render_fwd(termination_eps=...));
   strict_near_far   True (default, the reference's behaviour): the staged path raises when no ray of the batch meets the
                     scene cube (lib/nerf_utils.py:258 fails on min() of an empty selection) - one host synchronisation
                     per call; a training loop that cannot see such a batch may clear it;
   row_window        None, or (row_offset, rows): render only these image rows (fused inference path; one image sharded
-                    over the ranks of a node, parallel.shard_rows); the outputs then have `rows` rows.
+                    over the ranks of a node, parallel.shard_rows); the outputs then have `rows` rows;
+  row_window_sync   False, or True / a process group: the ranks of the group render bands of the SAME image, and the
+                    batch-wide miss-fill of lib/nerf_utils.py:258-259 is reduced over them between the ray set-up and the
+                    render kernel (parallel.allreduce_ray_setup), so that every band is bit-identical to the same rows
+                    of the full render.  Without it the fill is the band's own: identical only where no marched ray
+                    misses the exact cube (the default cameras) - stated in include/nfi_hip.h.
 """
 import types
 
@@ -39,7 +47,7 @@ from .field_backward import field_query_bwd
 
 args = None
 dataset_config = None
-_DEFAULTS = dict(fast_termination=0.0, strict_near_far=True, row_window=None)
+_DEFAULTS = dict(termination_eps=0.0, strict_near_far=True, row_window=None, row_window_sync=False)
 options = types.SimpleNamespace(**_DEFAULTS)
 
 
@@ -170,9 +178,20 @@ def _render(cfg, dcfg, opts, target_model, height, width, tform_cam2world, focal
             return torch.rand([B * rows * width, S], dtype=torch.float32, device=dev)
         return None            # the kernels take linspace(0, 1, S) themselves (nerf_utils.py:196-200)
 
-    if fused is not None and plain and not cam_grad and not fused.requires_grad and S <= 128:
+    # semantics / coords are composited by the fused kernel itself; normals, the view-direction decoder and the 'bbox'
+    # overlay (which edits sigma, generator.py:645-659) keep the staged path
+    fused_maps = plain or (not compute_normals and ray_features is None and not getattr(fused, 'bbox_overlay', False))
+    if fused is not None and fused_maps and not cam_grad and not fused.requires_grad and S <= 128:
         # ---------------- fused inference path (the kernel generates the rays itself) ----------------
         window = None if opts.row_window is None else (int(opts.row_window[0]), height)
+        extras = not plain
+        ws = None
+        if window is not None and opts.row_window_sync:
+            from . import parallel
+            ws = ops.render_setup(tform_cam2world.detach(), None if focal_length is None else focal_length.detach(), rows,
+                                  width, scene_range, bbox=None if bbox is None else bbox.detach(),
+                                  center=None if center is None else center.detach(), row_window=window)
+            parallel.allreduce_ray_setup(ws, None if opts.row_window_sync is True else opts.row_window_sync)
         out = ops.render_fwd(
             tform_cam2world.detach(), None if focal_length is None else focal_length.detach(), rows, width, S,
             fused.texels, fused.decoder_image, scene_range, fused.n_attention,
@@ -181,8 +200,12 @@ def _render(cfg, dcfg, opts, target_model, height, width, tform_cam2world, focal
             bbox=None if bbox is None else bbox.detach(), center=None if center is None else center.detach(),
             noise_coarse=noise_c, noise_fine=inverse_cdf_draws(), fine_sampling=bool(cfg.fine_sampling),
             white_background=bool(white), skip_missed_rays=True, ray_features=ray_features,
-            fast_termination=opts.fast_termination, row_window=window)
-        return out['rgb'], out['depth'], out['mask'], None, None, model_outputs
+            termination_eps=0.0 if extras else opts.termination_eps, row_window=window,
+            want_semantics=compute_semantics and not compute_coords, want_coords=compute_coords,
+            workspace=ws, rays_ready=ws is not None)
+        # run.py:337-338: coords take the semantics slot of render_volume_density when both are asked for
+        extra_map = out['coords'] if compute_coords else (out['semantics'] if compute_semantics else None)
+        return out['rgb'], out['depth'], out['mask'], None, extra_map, model_outputs
     if opts.row_window is not None:
         raise NotImplementedError('row_window is an option of the fused inference path (no gradient, no extra maps)')
 

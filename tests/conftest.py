@@ -31,7 +31,12 @@ def load_golden(name, device='cpu'):
 
 
 @pytest.fixture(scope='session')
-def gpu_device():
+def gpu_device(request):
     if not torch.cuda.is_available():
+        # the harness fails loudly.  A run that ASKS for the GPU tests (-m gpu) on a box without a GPU is
+        # an error, not a pass with skips; only a run that merely collects them (no -m expression) skips.
+        expr = request.config.getoption('-m') or ''
+        if 'gpu' in expr and 'not gpu' not in expr:
+            pytest.fail('GPU tests requested (-m gpu) but no GPU is visible (torch.cuda.is_available() is False)', pytrace=False)
         pytest.skip('no GPU visible')
     return torch.device('cuda:0')

@@ -32,7 +32,7 @@ def hip_field_setup(meta, t, dev, texel_dtype=ops.TEXEL_F32):
     return texels, image
 
 
-def hip_render(meta, t, dev, taps=(), skip_missed_rays=False, texel_dtype=ops.TEXEL_F32):
+def hip_render(meta, t, dev, taps=(), skip_missed_rays=False, texel_dtype=ops.TEXEL_F32, **kw):
     texels, image = hip_field_setup(meta, t, dev, texel_dtype)
     g = lambda k: t[k].to(dev) if k in t else None
     return ops.render_fwd(
@@ -40,7 +40,7 @@ def hip_render(meta, t, dev, taps=(), skip_missed_rays=False, texel_dtype=ops.TE
         attention_values=g('attention_values'), use_sdf=meta['sdf'], beta=g('beta'), alpha=g('alpha'),
         bbox=g('bbox'), center=g('center'), noise_coarse=g('noise_coarse'), noise_fine=g('noise_fine'), fine_sampling=meta['fine'],
         white_background=meta['white'], taps=taps, skip_missed_rays=skip_missed_rays,
-        ray_features=ops.pad_ray_features(t['viewdir_x'].to(dev)) if 'viewdir_x' in t else None)
+        ray_features=ops.pad_ray_features(t['viewdir_x'].to(dev)) if 'viewdir_x' in t else None, **kw)
 
 
 def err(a, b):

@@ -55,8 +55,8 @@ def test_library_contains_gfx950_code_objects_only(lib):
 def test_struct_layout_matches_header():
     # spot checks: field order and the natural-alignment size ctypes derives from the parsed header
     f = [n for n, _ in _lib.STRUCT_FIELDS['nfi_render_args']]
-    assert f[:4] == ['n_scenes', 'height', 'width', 'n_samples'] and f[-11:] == ['profile_cycles', 'ray_features', 'fast_termination', 'texel_layout', 'clock_probe', 'row_offset', 'full_height',
-                                                                                          'stash_t', 'stash_sigma', 'stash_rgb', 'rays_ready']
+    assert f[:4] == ['n_scenes', 'height', 'width', 'n_samples'] and f[-12:] == ['profile_cycles', 'ray_features', 'termination_eps', 'texel_layout', 'clock_probe', 'row_offset', 'full_height',
+                                                                                          'stash_t', 'stash_sigma', 'stash_rgb', 'rays_ready', 'coords']
     assert ctypes.sizeof(_lib.STRUCTS['nfi_sample_pdf_args']) == 8 + 4 + 4 + 3 * 8 + 8 + 3 * 8
     for name, st in _lib.STRUCTS.items():
         assert ctypes.sizeof(st) % 8 == 0 or ctypes.sizeof(st) % 4 == 0, name
@@ -88,25 +88,30 @@ def test_product_path_has_no_cpu_fallback():
 
 
 def test_bench_roofline_is_reproducible_from_the_committed_profile():
-    """bench.py's roofline object (no GPU needed for the arithmetic): issue cycles per marched ray and the shader clock
-    come from the committed rocprofv3 PMC profile it names, kernel time and ray count are the live inputs; the
-    fraction is a fraction (round 1 printed 1.97 against HBM), the byte-side levels each have their own peak."""
+    """bench.py's roofline object (no GPU needed for the arithmetic): `frac` is SURVEY.md 8(d)'s own figure - algorithmic
+    decoder FLOPs per launch / kernel time against the fp32 matrix / vector peak - from the live kernel time and ray count
+    alone; the vector-ALU pipe fraction (the pipe that binds) and the byte-side levels come from the committed rocprofv3
+    PMC profile it names, each against its own peak; the ANY-issue proxy is a side field, never the fraction."""
     import json
     import bench
-    prof = json.load(open(os.path.join(ROOT, 'profiles', 'r3', 'pmc_render_fwd.json')))
+    src, prof = bench.load_pmc_profile()
+    assert src in bench.PMC_PROFILES and prof == json.load(open(os.path.join(ROOT, src)))
     kernel_ms, marched = prof['kernel_ns_in_clock_pass'] * 1e-6, prof['rays_marched_per_launch']
     r = bench.roofline(kernel_ms, marched, 8)
-    assert r['source'] == 'profiles/r3/pmc_render_fwd.json' and r['bound'] == 'valu-issue'
-    assert abs(r['frac'] - r['achieved'] / r['peak']) < 1e-12 and 0.3 < r['frac'] <= 1.0
-    # at the profile's own kernel time the fraction is the profile's issue fraction
-    assert abs(r['frac'] - prof['issue_frac']) < 0.01 * prof['issue_frac']
+    assert r['source'] == src and r['bound'] == 'mfma' and r['unit'] == 'TFLOP/s' and r['peak'] == 157.3
+    assert abs(r['achieved'] - 704512 * marched / (kernel_ms * 1e-3) / 1e12) < 1e-9
+    assert abs(r['frac'] - r['achieved'] / r['peak']) < 1e-12 and r['frac'] == r['frac_flops'] and 0.2 < r['frac'] < 1.0
     assert r['traffic'] == prof['fabric_bytes_per_launch']
-    # the vector ALU alone (the pipe that binds) and the occupancy the profile ran at
-    assert abs(r['valu_pipe']['frac'] - prof['valu_frac']) < 0.01 * prof['valu_frac'] and 0.4 < r['valu_pipe']['frac'] < r['frac']
+    # the vector ALU alone (the pipe that binds) at the profile's own kernel time is the profile's VALU fraction
+    assert abs(r['valu_pipe']['frac'] - prof['valu_frac']) < 0.01 * prof['valu_frac'] and 0.4 < r['valu_pipe']['frac'] < 1.0
+    assert abs(r['any_issue_proxy']['frac'] - prof['issue_frac']) < 0.01 * prof['issue_frac']
+    assert r['valu_pipe']['frac'] < r['any_issue_proxy']['frac']
     assert 1.5 < r['waves_per_simd'] <= 2.0
-    # priced at a shader clock measured in the timed launches, the fraction scales with the clock ratio
+    # priced at a shader clock measured in the timed launches, the pipe fraction scales with the clock ratio; the FLOP
+    # fraction does not depend on the clock
     live = bench.roofline(kernel_ms, marched, 8, live_clock_hz=2.4e9)
-    assert abs(live['frac'] - r['frac'] * prof['shader_clock_hz'] / 2.4e9) < 1e-9 and 'live' in live['shader_clock_source']
+    assert abs(live['valu_pipe']['frac'] - r['valu_pipe']['frac'] * prof['shader_clock_hz'] / 2.4e9) < 1e-9
+    assert 'live' in live['shader_clock_source'] and live['frac'] == r['frac']
     for level in ('hbm_compulsory', 'l2_requests', 'fabric'):
         assert 0.0 < r['levels'][level]['frac'] < 1.0, level
     assert r['levels']['gather_stream_algorithmic']['x_hbm_peak'] > 1.0      # cache-served: why HBM is not the bound

@@ -107,18 +107,53 @@ def test_render_dropin_fused(setup, fine, randomize, white):
     close(rgb, o['rgb'], 1e-4, 'rgb'); close(depth, o['depth'], 1e-4, 'depth'); close(mask, o['mask'], 1e-4, 'mask')
 
 
-def test_render_dropin_staged_semantics(setup):
-    """compute_semantics forces the staged path (one launch per stage through nerf_utils)."""
+class OneRenderLaunch:
+    """The extra maps must come out of ONE fused render launch: counts ops.render_fwd calls and makes the stage ops of
+    the staged path (field query, resampling, compositing) fail."""
+
+    def __enter__(self):
+        from nerf_from_image_amd import ops
+        self.ops, self.calls = ops, 0
+        self.saved = {k: getattr(ops, k) for k in ('render_fwd', 'field_query', 'composite', 'resample')}
+
+        def counted(*a, **k):
+            self.calls += 1
+            return self.saved['render_fwd'](*a, **k)
+
+        def forbidden(*a, **k):
+            raise AssertionError('a stage kernel of the staged path was launched')
+        ops.render_fwd = counted
+        ops.field_query = ops.composite = ops.resample = forbidden
+        return self
+
+    def __exit__(self, *a):
+        for k, v in self.saved.items():
+            setattr(self.ops, k, v)
+
+
+def test_render_dropin_fused_semantics(setup):
+    """compute_semantics without a gradient (every inversion eval batch, run.py:2036-2051): one fused launch, the
+    semantic map against the oracle, rgb / depth / mask identical to the call without it."""
     model, cam, focal, z = setup
     cfg = types.SimpleNamespace(use_viewdir=False, use_sdf=True, attention_values=10, fine_sampling=True)
     dcfg = {'scene_range': 0.55, 'white_background': True}
     render = nfi_render.make_render(cfg, dcfg)
     H, W, S = 20, 28, 32
-    with torch.no_grad(), RandTap() as tap:
+    with torch.no_grad(), RandTap() as tap, OneRenderLaunch() as one:
         rgb, depth, mask, normals, sem, _ = render(model, H, W, cam, focal, None, None, z, S, compute_semantics=True)
+    assert one.calls == 1 and normals is None and sem.shape == (2, H, W, 10)
     o = oracle_for(model, z, cam, focal, H, W, S, cfg, dcfg, tap.draws, want_semantics=True)
     close(rgb, o['rgb'], 1e-4, 'rgb'); close(mask, o['mask'], 1e-4, 'mask'); close(depth, o['depth'], 1e-4, 'depth')
-    close(sem, o['semantics'], 1e-4, 'semantic map')
+    close(sem, o['semantics'], 1e-5, 'semantic map')
+    draws = iter(tap.draws)
+    real_rand = torch.rand
+    torch.rand = lambda *a, **k: next(draws).to(cam.device)
+    try:
+        with torch.no_grad():
+            rgb0, depth0, mask0, _, none, _ = render(model, H, W, cam, focal, None, None, z, S)
+    finally:
+        torch.rand = real_rand
+    assert none is None and torch.equal(rgb0, rgb) and torch.equal(depth0, depth) and torch.equal(mask0, mask)
 
 
 def test_render_dropin_coords_and_force_no_cam_grad(setup):
@@ -129,9 +164,9 @@ def test_render_dropin_coords_and_force_no_cam_grad(setup):
     dcfg = {'scene_range': 0.55, 'white_background': False}
     render = nfi_render.make_render(cfg, dcfg)
     H, W, S = 12, 20, 32
-    with torch.no_grad(), RandTap() as tap:
+    with torch.no_grad(), RandTap() as tap, OneRenderLaunch() as one:
         rgb, depth, mask, normals, coords_map, _ = render(model, H, W, cam, focal, None, None, z, S, compute_coords=True)
-    assert normals is None and coords_map.shape == (2, H, W, 3)
+    assert one.calls == 1 and normals is None and coords_map.shape == (2, H, W, 3)
     with torch.no_grad():
         planes, att = model.planes_and_values(z)
         dec = model.decoder.net
@@ -141,7 +176,7 @@ def test_render_dropin_coords_and_force_no_cam_grad(setup):
                        noise_fine=tap.draws[1], use_sdf=True, beta=cpu(model.beta), alpha=cpu(model.alpha),
                        attention_values=cpu(att), want_coords=True)
     close(rgb, o['rgb'], 1e-4, 'rgb'); close(mask, o['mask'], 1e-4, 'mask')
-    close(coords_map, o['semantics'], 1e-4, 'composited coordinates')
+    close(coords_map, o['semantics'], 1e-5, 'composited coordinates')
     # gradients: with force_no_cam_grad the camera and focal length get none, the latent does
     cam_g, focal_g, z_g = cam.clone().requires_grad_(), focal.clone().requires_grad_(), z.clone().requires_grad_()
     draws = iter(tap.draws)

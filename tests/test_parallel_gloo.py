@@ -227,8 +227,30 @@ def _accumulate_worker(rank, world, port, q):
             return img[:, a:b], img[:, a:b, :, 0]
         full, first = parallel.render_image_rows(fake_rows, H)
         assert seen == [(r0, r1)] and torch.equal(full, img) and torch.equal(first, img[..., 0])
-        # fewer strips than ranks: one rank gets the strip, the other an empty band
+        # fewer strips than ranks: one rank gets the strip, the other an empty band - which must not reach the renderer
+        # (the kernels refuse height 0) and must still take part in the gather instead of leaving the others hanging in it
         assert parallel.shard_rows(8, rank=0, world_size=2) == (0, 0) and parallel.shard_rows(8, rank=1, world_size=2) == (0, 8)
+        small = torch.arange(2 * 8 * W * 3, dtype=torch.float32).view(2, 8, W, 3)
+        calls = []
+
+        def strict_rows(a, b):
+            assert b > a, 'render_rows called with an empty band'
+            calls.append((a, b))
+            return small[:, a:b], None, small[:, a:b, :, 0].to(torch.int32)
+        full, none, first = parallel.render_image_rows(strict_rows, 8)
+        assert calls == ([] if rank == 0 else [(0, 8)]) and none is None
+        assert torch.equal(full, small) and torch.equal(first, small[..., 0].to(torch.int32))
+        one = parallel.render_image_rows(lambda a, b: strict_rows(a, b)[0], 8)
+        assert torch.is_tensor(one) and torch.equal(one, small)
+        # the miss-fill cells of a row-sharded render: max of the two order-preserving keys (unsigned), sum of the count
+        ws = torch.zeros(64, dtype=torch.uint8)
+        cells = ws[:12].view(torch.int32)
+        mine3 = [0x7F000000 + 5, 0xC0000001, 7] if rank == 0 else [0x80000002, 0x40000000, 11]
+        cells.copy_(torch.tensor([v - 2 ** 32 if v >= 2 ** 31 else v for v in mine3], dtype=torch.int32))
+        parallel.allreduce_ray_setup(ws)
+        got = [int(v) & 0xFFFFFFFF for v in ws[:12].view(torch.int32).tolist()]
+        assert got == [0x80000002, 0xC0000001, 18], [hex(v) for v in got]
+        assert not ws[12:].any()
         # one-shot form keeps a staging buffer per gradient size (G and D steps alternate)
         a, b = torch.nn.Parameter(torch.ones(5)), torch.nn.Parameter(torch.ones(9))
         for _ in range(2):

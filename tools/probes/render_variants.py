@@ -1,4 +1,8 @@
-"""Variant builds of the fused render kernels (build-time knobs of nfi_device.hpp) for A/B timing on the GPU box.
+"""Variant builds of the fused render kernels for A/B timing on the GPU box - the NEGATIVE RESULTS of round 3 (DESIGN.md
+section 7).  The build-time knobs these variants switch (NFI_PLANEWISE, NFI_TILE_PAIR, NFI_SCALAR_RAY, NFI_LEAN_RAY,
+NFI_SPLIT_MIX, NFI_MERGE_HIST, the tuning bits 5-8 of the work queues) were removed from the product sources in round 4;
+they live in the tree of commit FROZEN below, which `build` extracts with `git show` (needs the repository's history,
+i.e. this container, not the GPU box) and compiles with the current build recipe.  `run` then times the libraries it finds.
 
     python tools/probes/render_variants.py build                     # here: build/variants/libnfi_render_<name>.so
     python tools/probes/render_variants.py run                       # on the GPU box: ms per launch of every variant
@@ -16,6 +20,7 @@ import os
 import subprocess
 import sys
 
+FROZEN = '4d6d769'             # last commit of round 3: csrc/ with the experiment knobs
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 OUT = os.path.join(ROOT, 'build', 'variants')
@@ -40,9 +45,19 @@ def build(names):
     import __graft_entry__ as entry
     from concurrent.futures import ThreadPoolExecutor
     os.makedirs(OUT, exist_ok=True)
-    bwd_obj = os.path.join(ROOT, 'build', 'nfi_backward_field.o')
-    assert os.path.exists(bwd_obj), 'run python __graft_entry__.py first'
-    src = os.path.join(entry.CSRC, 'nfi_kernels.hip')
+    # the frozen sources: csrc/ and the header as they were at FROZEN
+    frozen = os.path.join(OUT, 'src_' + FROZEN)
+    listing = subprocess.check_output(['git', 'ls-tree', '-r', '--name-only', FROZEN, 'nerf_from_image_amd/csrc', 'include'],
+                                      cwd=ROOT, text=True).split()
+    for rel in listing:
+        dst = os.path.join(frozen, rel)
+        os.makedirs(os.path.dirname(dst), exist_ok=True)
+        with open(dst, 'wb') as f:
+            f.write(subprocess.check_output(['git', 'show', '%s:%s' % (FROZEN, rel)], cwd=ROOT))
+    csrc = os.path.join(frozen, 'nerf_from_image_amd', 'csrc')
+    src = os.path.join(csrc, 'nfi_kernels.hip')
+    bwd_obj = os.path.join(OUT, 'nfi_backward_field_%s.o' % FROZEN)
+    entry.compile_unit(os.path.join(csrc, 'nfi_backward_field.hip'), ['-fno-slp-vectorize'], bwd_obj)
 
     def one(name):
         obj = os.path.join(OUT, 'render_%s.o' % name)
