@@ -430,7 +430,8 @@ typedef struct nfi_render_args {
    * split-fp16 (hi+lo, 22 significand bits) MFMA; both meet the 1e-4 parity budget.  bit 4: ONE device-wide work
    * counter instead of the per-XCD queues over square pixel blocks (results identical; the per-XCD queues take the
    * largest of 32 / 16 / 8 pixels that divides both image sides, two positions per atomic, and fall back to the single
-   * counter when not even 8 does). */
+   * counter when not even 8 does).  bit 5: the 128 + 128 kernel with fp16 texels at two workgroups per CU (256 registers,
+   * no scratch) instead of three (168 registers) - a measurement knob, results identical. */
   int tuning;
   /* optional uint64[12] device array: per-phase shader-cycle sums over all waves (profiling build of
    * the kernel; NULL = off): field tile {issue, wait+interp, mlp, count}, ray set-up, coarse field,
@@ -464,10 +465,11 @@ typedef struct nfi_render_args {
    * parallel.allreduce_ray_setup.  Outputs, noise and taps are sized for the window.  One image sharded over the ranks of a node: SURVEY.md 8(e),
    * run.py:598-605 (res_multiplier renders). */
   int row_offset; int full_height;
-  /* training stash (all three or none; fine_sampling only): the per-sample state the backward needs, ray-major with
-   * the coarse samples in [0,S) and the fine samples in [S,2S) of every row - stash_t [N,2S], stash_sigma [N,2S],
-   * stash_rgb [N,2S,3], in SOURCE order (not merged).  nfi_composite_bwd (list_row_stride = 2S) and
-   * nfi_field_query_bwd over the 2S points of every ray then replace autograd of run.py:193-348.  Unlike the debug
+  /* training stash (all three or none): the per-sample state the backward needs, ray-major with the coarse samples in
+   * [0,S) and the fine samples in [S,2S) of every row - stash_t [N,2S], stash_sigma [N,2S], stash_rgb [N,2S,3], in
+   * SOURCE order (not merged); without fine_sampling the rows hold the S samples of the single pass ([N,S], [N,S],
+   * [N,S,3]).  nfi_composite_bwd (list_row_stride = 2S, or one list of S) and nfi_field_query_bwd over the points of
+   * every ray then replace autograd of run.py:193-348.  Unlike the debug
    * taps the stash keeps the missed-ray skip: rays that are skipped get an all-zero row.  Mutually exclusive with the
    * t_coarse ... rgb_fine taps. */
   float* stash_t; float* stash_sigma; float* stash_rgb;

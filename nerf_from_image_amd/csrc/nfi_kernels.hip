@@ -1728,12 +1728,13 @@ __global__ __launch_bounds__(256, OCC) void render_fwd_kernel(RenderKernelParams
 #define NFI_SINGLE_MODE 0     // kRenderPlain ... kRenderExtra
 #endif
 template __global__ void render_fwd_kernel<NFI_SINGLE_KERNEL, true, NFI_RENDER_OCC, NFI_SINGLE_MODE, 1>(RenderKernelParams);
-#else
+#endif
+#if !defined(NFI_SINGLE_KERNEL) || defined(NFI_SINGLE_WIDE)
 // The same pipeline for 64 < S <= 128 samples per pass (BASELINE cfg5, ray_multiplier=2): every lane
 // owns two coarse and two fine samples (element e = slot*64 + lane), the field is marched 64 points
 // at a time, and the merge ranks all 2S keys against each other.
-template <int TEX, bool ATT, int MODE, int PREC, bool VD = false>
-__global__ __launch_bounds__(256, NFI_RENDER_OCC) void render_fwd_wide_kernel(RenderKernelParams k) {
+template <int TEX, bool ATT, int MODE, int PREC, bool VD = false, int OCC = NFI_RENDER_OCC>
+__global__ __launch_bounds__(256, OCC) void render_fwd_wide_kernel(RenderKernelParams k) {
   constexpr bool TAPS = MODE == kRenderTaps, TERM = MODE == kRenderTerm, EXTRA = MODE == kRenderExtra;
   constexpr int SEMP = (EXTRA && ATT) ? kSemPitchWide : 0;
   constexpr int kImg = VD ? kVdImageFloats : kLdsImageFloats;
@@ -1991,6 +1992,11 @@ __global__ __launch_bounds__(256, NFI_RENDER_OCC) void render_fwd_wide_kernel(Re
   clock.stop(k);
 }
 
+#endif   // wide kernel
+#ifdef NFI_SINGLE_WIDE
+template __global__ void render_fwd_wide_kernel<NFI_SINGLE_KERNEL, true, NFI_SINGLE_MODE, 1, false, NFI_RENDER_OCC>(RenderKernelParams);
+#endif
+#ifndef NFI_SINGLE_KERNEL
 extern "C" size_t nfi_render_workspace_bytes(int64_t n_rays) {
   // ro, rd, near_raw, far_raw (fp32) + hit (u8, padded) + reduce[4]
   size_t n = (size_t)n_rays;
@@ -2066,8 +2072,7 @@ extern "C" int nfi_render_fwd(const nfi_render_args* a, nfi_stream_t stream) {
   }
 
   const bool stash = a->stash_t || a->stash_sigma || a->stash_rgb;
-  REQUIRE(!stash || (a->stash_t && a->stash_sigma && a->stash_rgb && a->fine_sampling),
-          "render: the training stash needs stash_t, stash_sigma, stash_rgb and fine sampling");
+  REQUIRE(!stash || (a->stash_t && a->stash_sigma && a->stash_rgb), "render: the training stash needs stash_t, stash_sigma and stash_rgb");
   REQUIRE(!stash || !(a->t_coarse || a->sigma_coarse || a->rgb_coarse || a->t_fine || a->sigma_fine || a->rgb_fine),
           "render: the training stash and the per-sample debug taps are mutually exclusive");
   const bool debug_tap = a->t_coarse || a->sigma_coarse || a->rgb_coarse || a->t_fine || a->sigma_fine || a->rgb_fine ||
@@ -2087,11 +2092,14 @@ extern "C" int nfi_render_fwd(const nfi_render_args* a, nfi_stream_t stream) {
   k.t_fine = a->t_fine; k.sigma_fine = a->sigma_fine; k.rgb_fine = a->rgb_fine;
   k.tap_stride = a->n_samples;
   if (stash) {
-    // the stash rows hold the coarse samples in [0,S) and the fine samples in [S,2S)
-    k.tap_stride = 2 * a->n_samples; k.stash = 1;
-    k.t_coarse = a->stash_t; k.t_fine = a->stash_t + a->n_samples;
-    k.sigma_coarse = a->stash_sigma; k.sigma_fine = a->stash_sigma + a->n_samples;
-    k.rgb_coarse = a->stash_rgb; k.rgb_fine = a->stash_rgb + 3 * (size_t)a->n_samples;
+    // the stash rows hold the coarse samples in [0,S) and - with fine sampling - the fine samples in [S,2S)
+    k.tap_stride = (a->fine_sampling ? 2 : 1) * a->n_samples; k.stash = 1;
+    k.t_coarse = a->stash_t; k.sigma_coarse = a->stash_sigma; k.rgb_coarse = a->stash_rgb;
+    if (a->fine_sampling) {
+      k.t_fine = a->stash_t + a->n_samples;
+      k.sigma_fine = a->stash_sigma + a->n_samples;
+      k.rgb_fine = a->stash_rgb + 3 * (size_t)a->n_samples;
+    }
   }
   k.t_sorted = a->t_sorted; k.weights = a->weights; k.perm = a->perm;
   k.skip_missed = (a->skip_missed_rays && !debug_tap) ? 1 : 0;
@@ -2147,6 +2155,9 @@ extern "C" int nfi_render_fwd(const nfi_render_args* a, nfi_stream_t stream) {
   bool att = a->n_attention > 0;
   // kRenderExtra with semantics: the per-wave tables [A][pitch] in dynamic LDS
   const bool wide = a->n_samples > 64;
+  // fp16 texels, 128 + 128: three workgroups per CU (168 registers, ~40 scratch reloads per ray outside the field tiles);
+  // tuning bit 5 keeps two (256 registers, no scratch) for the A/B measurement
+  const bool wide_occ2 = ((a->tuning >> 5) & 1) != 0;
   const size_t sem_lds = a->semantics ? (size_t)4 * a->n_attention * (wide ? kSemPitchWide : kSemPitch) * sizeof(float) : 0;
   constexpr size_t kSemLdsMax = (size_t)4 * NFI_MAX_ATTENTION * kSemPitch * sizeof(float);
   constexpr size_t kSemLdsMaxWide = (size_t)4 * NFI_MAX_ATTENTION * kSemPitchWide * sizeof(float);
@@ -2173,6 +2184,7 @@ extern "C" int nfi_render_fwd(const nfi_render_args* a, nfi_stream_t stream) {
     else if (any_tap && strict) hipLaunchKernelGGL((render_fwd_wide_kernel<TEX, ATT, kRenderTaps, 0>), grid, dim3(256), 0, s, k); \
     else if (any_tap) hipLaunchKernelGGL((render_fwd_wide_kernel<TEX, ATT, kRenderTaps, 1>), grid, dim3(256), 0, s, k);        \
     else if (strict) hipLaunchKernelGGL((render_fwd_wide_kernel<TEX, ATT, kRenderPlain, 0>), grid, dim3(256), 0, s, k);        \
+    else if (TEX == 2 && !wide_occ2) hipLaunchKernelGGL((render_fwd_wide_kernel<2, ATT, kRenderPlain, 1, false, 3>), grid3, dim3(256), 0, s, k); \
     else hipLaunchKernelGGL((render_fwd_wide_kernel<TEX, ATT, kRenderPlain, 1>), grid, dim3(256), 0, s, k);                    \
   } while (0)
 #define NFI_LAUNCH_RENDER_VD(TEX, ATT)                                                                                        \

@@ -387,7 +387,8 @@ def render_fwd(cam2world, focal, height, width, num_samples, texels, decoder_ima
     (bit-identical to those rows of the full render; noise / outputs / taps are sized for the window).
     clock_probe: None or a uint64 / int64 [2] device tensor receiving {shader cycles, 100 MHz ticks} of the render kernel.
     stash: also return the training stash 'stash_t' [B,H,W,2S], 'stash_sigma' [B,H,W,2S], 'stash_rgb' [B,H,W,2S,3]
-    (coarse samples in [..., :S], fine in [..., S:], source order; skipped rays hold zeros) and 'ray_origins' /
+    (coarse samples in [..., :S], fine in [..., S:], source order; skipped rays hold zeros; without fine sampling the
+    rows hold the S samples of the single pass) and 'ray_origins' /
     'ray_directions' - what composite_bwd(list_row_stride=2S) + field_query_bwd need for the backward of the render.
     ray_features: padded [B,H,W,48] per-ray view-direction features (decoder_pack_viewdir image).
     termination_eps: 0 = off; eps in (0,1): fine samples behind the depth at which the COARSE transmittance has fallen
@@ -424,13 +425,11 @@ def render_fwd(cam2world, focal, height, width, num_samples, texels, decoder_ima
         shp, dt = shapes[name]
         tap_t[name] = torch.zeros(shp, dtype=dt, device=dev)
     if stash:
-        if not fine_sampling:
-            raise ValueError('render_fwd: the training stash exists for fine sampling only')
         for name in ('ray_origins', 'ray_directions'):
             tap_t.setdefault(name, torch.empty(shapes[name][0], dtype=torch.float32, device=dev))
-        tap_t['stash_t'] = torch.empty((B, height, width, 2 * S), dtype=torch.float32, device=dev)
-        tap_t['stash_sigma'] = torch.empty((B, height, width, 2 * S), dtype=torch.float32, device=dev)
-        tap_t['stash_rgb'] = torch.empty((B, height, width, 2 * S, 3), dtype=torch.float32, device=dev)
+        tap_t['stash_t'] = torch.empty((B, height, width, n2), dtype=torch.float32, device=dev)
+        tap_t['stash_sigma'] = torch.empty((B, height, width, n2), dtype=torch.float32, device=dev)
+        tap_t['stash_rgb'] = torch.empty((B, height, width, n2, 3), dtype=torch.float32, device=dev)
     if want_semantics:
         if n_attention <= 0:
             raise ValueError('render_fwd: semantics need attention values (n_attention > 0)')
@@ -522,14 +521,21 @@ def sdf_gradient_bwd(points, texels, w1, b1, w2, b2, scene_range, g_sdf, g_gradi
 # backward wrappers
 # --------------------------------------------------------------------------- #
 def composite_bwd_stash(ray_directions, stash_t, stash_sigma, stash_rgb, g_rgb_map, g_mask=None, white_background=True,
-                        want_rd=True):
-    """Compositing backward on the training stash of render_fwd (rows of 2S entries: coarse | fine).  Returns
-    dict(g_sigma [..., 2S], g_rgb [..., 2S, 3], g_ray_directions?) in the stash's layout."""
+                        want_rd=True, fine=True):
+    """Compositing backward on the training stash of render_fwd (rows of 2S entries: coarse | fine; fine=False: rows of
+    the S samples of a single pass).  Returns dict(g_sigma [..., 2S], g_rgb [..., 2S, 3], g_ray_directions?) in the
+    stash's layout."""
     rd = _f32c(ray_directions, 'ray_directions')
     t, sg, col = _f32c(stash_t, 'stash_t'), _f32c(stash_sigma, 'stash_sigma'), _f32c(stash_rgb, 'stash_rgb')
     S2 = t.shape[-1]
-    S = S2 // 2
     n = t.numel() // S2
+    if not fine:
+        g = composite_bwd(rd, t, sg, col, g_rgb_map, g_mask, white_background=white_background, want_rd=want_rd)
+        out = dict(g_sigma=g['g_sigma_a'], g_rgb=g['g_rgb_a'])
+        if want_rd:
+            out['g_ray_directions'] = g['g_ray_directions']
+        return out
+    S = S2 // 2
     out = dict(g_sigma=torch.empty_like(sg), g_rgb=torch.empty_like(col))
     if want_rd:
         out['g_ray_directions'] = torch.empty_like(rd)

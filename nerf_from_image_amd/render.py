@@ -8,14 +8,15 @@
 Three execution paths, all HIP through the C ABI:
   * fused          - one persistent launch for the whole pipeline (no gradient); the composited `semantics` and `coords`
                      maps (compute_semantics / compute_coords: run.py:1639-1646, 2036-2051) come out of the same launch;
-  * fused + stash  - the SAME launch when a gradient is needed (training / inversion, fine sampling on): the kernel also
+  * fused + stash  - the SAME launch when a gradient is needed (training / inversion; with or without fine sampling, plain
+                     or view-direction decoder): the kernel also
                      writes a per-sample stash (depths, sigma, rgb of the 2S samples of every ray, ray-major), and the
                      whole render is ONE autograd node whose backward is compositing backward on the stash -> one field
                      backward launch over the 2S points of every ray (+ its binned plane-gradient scatter) -> ray /
                      camera backward.  Replaces the ~20 launches of the staged graph;
   * staged         - one launch per stage through ``nerf_utils`` and the ``sampler`` closure: the normals map, extra maps
-                     with a gradient / the view-direction decoder / the 'bbox' overlay, the view-direction decoder with a
-                     gradient, or no fine sampling with a gradient.
+                     with a gradient / the view-direction decoder / the 'bbox' overlay, and a single pass of more than 128
+                     samples (run.py's inversion without --fine_sampling: 512).
 Randomness follows the reference, in its order: ``torch.rand`` of [B,H,W,S] for the stratified
 jitter (nerf_utils.py:115) BEFORE the model is called (its synthesis network draws noise of its own
 in training), then ``torch.rand`` of [B*H*W,S] for the inverse-CDF draws (nerf_utils.py:202), even
@@ -88,49 +89,60 @@ def _needs_grad(*tensors):
     return torch.is_grad_enabled() and any(t is not None and torch.is_tensor(t) and t.requires_grad for t in tensors)
 
 
-def _render_with_stash(fused, height, width, S, cam, focal, bbox, center, noise_c, noise_f, white, cam_grad):
+def _render_with_stash(fused, height, width, S, cam, focal, bbox, center, noise_c, noise_f, white, cam_grad, fine=True):
     """The fused render as ONE autograd node (see the module docstring).  Gradients follow the reference's graph:
     rgb_map / mask -> sigma, rgb of every sample and (through dists * ||rd||) the ray directions; depth_map and the
     depth samples carry none; the field -> planes, decoder, colour table, beta, alpha and - unless the camera is
-    detached - the query points -> rays -> tform_cam2world / focal_length."""
+    detached - the query points -> rays -> tform_cam2world / focal_length.  fine=False: one pass of S samples
+    (run.py without --fine_sampling).  With the view-direction decoder (fused.ray_features: --use_viewdir, carla) the
+    per-ray feature of the ViewDirectionMapper and its output layer are inputs of the node too: their gradients go
+    back into the PyTorch mapper and, through its view directions, into the camera."""
     texels, image = fused.texels, fused.decoder_image
     A, use_sdf, scene_range = fused.n_attention, fused.use_sdf, fused.scene_range
     w1, b1, w2, b2 = fused.decoder_params[:4]
+    vd = fused.ray_features is not None
     B = cam.shape[0]
+    n_list = (2 if fine else 1) * S
     keep = {}
 
-    def fwd(a_cam, a_focal, pl, a_w1, a_b1, a_w2, a_b2, att, be, al):
+    def fwd(a_cam, a_focal, pl, a_w1, a_b1, a_w2, a_b2, att, be, al, *vd_in):
         out = ops.render_fwd(a_cam, a_focal, height, width, S, texels, image, scene_range, A, att, use_sdf, be, al,
-                             bbox=bbox, center=center, noise_coarse=noise_c, noise_fine=noise_f, fine_sampling=True,
-                             white_background=bool(white), skip_missed_rays=True, stash=True)
+                             bbox=bbox, center=center, noise_coarse=noise_c, noise_fine=noise_f, fine_sampling=fine,
+                             white_background=bool(white), skip_missed_rays=True, stash=True,
+                             ray_features=fused.ray_features)
         keep.update({k: out[k] for k in ('stash_t', 'stash_sigma', 'stash_rgb', 'ray_origins', 'ray_directions')})
         return out['rgb'], out['depth'], out['mask']
 
     def bwd(inputs, out_meta, grads, needs):
-        a_cam, a_focal, pl, a_w1, a_b1, a_w2, a_b2, att, be, al = inputs
+        a_cam, a_focal, pl, a_w1, a_b1, a_w2, a_b2, att, be, al = inputs[:10]
         g_rgb = zeros_like_or(grads[0], out_meta[0])
         g_mask = None if grads[2] is None else grads[2].contiguous()
         st_t, rd = keep['stash_t'], keep['ray_directions']
         cb = ops.composite_bwd_stash(rd, st_t, keep['stash_sigma'], keep['stash_rgb'], g_rgb, g_mask,
-                                     white_background=bool(white), want_rd=cam_grad)
+                                     white_background=bool(white), want_rd=cam_grad, fine=fine)
         pts = ops.points_on_rays(keep['ray_origins'], rd, st_t).view(B, -1, 3)
+        viewdir = dict(ray_features=fused.ray_features, samples_per_ray=n_list, w3=inputs[11]) if vd else None
         g = field_query_bwd(pts, texels, image, a_w1, a_w2, scene_range, A, att, use_sdf, be, al,
                             cb['g_sigma'].view(B, -1), cb['g_rgb'].view(B, -1, 3), want_points=cam_grad,
-                            ray_order=(2 * S, width))
+                            viewdir=viewdir, ray_order=(n_list, width))
         g_cam = g_focal = None
         if cam_grad:
             g_ro, g_rd = ops.points_bwd(g['g_points'].view(*st_t.shape, 3), st_t)
             g_rd = g_rd + cb['g_ray_directions']
             g_cam, g_focal = ops.raygen_bwd(height, width, a_focal, a_cam, bbox, center, True, g_ro, g_rd)
         g_planes = ops.texel_grad_to_planes(g['g_texels']) if needs[2] else None
-        return (g_cam, g_focal, g_planes, g['g_w1'], g['g_b1'], g['g_w2'], g['g_b2'], g.get('g_attention_values'),
+        base = (g_cam, g_focal, g_planes, g['g_w1'], g['g_b1'], g['g_w2'], g['g_b2'], g.get('g_attention_values'),
                 g.get('g_beta'), g.get('g_alpha'))
+        if not vd:
+            return base
+        return base + (g['g_ray_features'].reshape(inputs[10].shape), g['g_w3'], g['g_b3'])
 
     cam_in = cam if cam_grad else cam.detach()
     focal_in = focal if (cam_grad or focal is None) else focal.detach()
+    extra_in = tuple(fused.decoder_params[4:7]) if vd else ()          # (ray_feature [B,H,W,1,32], w3, b3)
     res = differentiable('render', fwd, cam_in, focal_in, fused.planes, w1, b1, w2, b2,
                          fused.attention_values if A > 0 else None, fused.beta if use_sdf else None,
-                         fused.alpha if use_sdf else None, bwd=bwd, non_differentiable_outputs=(1,))
+                         fused.alpha if use_sdf else None, *extra_in, bwd=bwd, non_differentiable_outputs=(1,))
     return res
 
 
@@ -209,15 +221,18 @@ def _render(cfg, dcfg, opts, target_model, height, width, tform_cam2world, focal
     if opts.row_window is not None:
         raise NotImplementedError('row_window is an option of the fused inference path (no gradient, no extra maps)')
 
-    if fused is not None and plain and cfg.fine_sampling and S <= 128 and ray_features is None:
+    if fused is not None and plain and S <= 128 and (ray_features is None or fused.texels.dtype == torch.float32):
         # ---------------- fused render + stash as one differentiable node ----------------
+        # (with or without fine sampling, plain or view-direction decoder; the view-direction rays of run.py:216-222 were
+        #  computed above for the model - the kernel regenerates the same rays, and the camera gradient of the viewdirs
+        #  flows through the PyTorch mapper into that first ray op)
         det = (lambda t: None if t is None else t.detach())
         rgb_map, depth_map, mask = _render_with_stash(
             fused, height, width, S, tform_cam2world, focal_length, det(bbox), det(center), noise_c, inverse_cdf_draws(),
-            white, cam_grad)
+            white, cam_grad, fine=bool(cfg.fine_sampling))
         return rgb_map, depth_map, mask, None, None, model_outputs
 
-    # ---------------- staged path (extra maps, view-direction decoder, single pass with a gradient) ----------------
+    # ---------------- staged path (normals, extra maps with a gradient, one pass of more than 128 samples) ----------------
     ray_origins, ray_directions = rays if rays is not None else nerf_utils.get_ray_bundle_normalized(
         height, width, focal_length, tform_cam2world, bbox, center)
     with torch.no_grad():

@@ -24,7 +24,7 @@ def test_wrapped_forward_keeps_reference_outputs_and_captures_planes(monkeypatch
     seen = {}
 
     def fake_make_sampler(planes, decoder, scene_range, n_att, att, use_sdf, beta, alpha, texel_dtype=0,
-                          request_model_outputs=(), viewdir=None):
+                          request_model_outputs=(), viewdir=None, texel_cache=None):
         assert viewdir is None
         seen.update(planes=planes, att=att, decoder=decoder, beta=beta, alpha=alpha, scene_range=scene_range)
         return lambda x, req=['sigma', 'rgb']: {'sigma': None}
@@ -80,7 +80,7 @@ def test_wrapped_forward_hands_over_the_view_direction_feature(monkeypatch):
     seen = {}
 
     def fake_make_sampler(planes, decoder, scene_range, n_att, att, use_sdf, beta, alpha, texel_dtype=0,
-                          request_model_outputs=(), viewdir=None):
+                          request_model_outputs=(), viewdir=None, texel_cache=None):
         seen.update(planes=planes, att=att, viewdir=viewdir)
         return lambda x, req=['sigma', 'rgb']: {}
     monkeypatch.setattr(nfi_gen, 'make_sampler', fake_make_sampler)
@@ -183,7 +183,7 @@ def test_wrapped_forward_can_hand_the_regularisers_to_hip(monkeypatch):
     model = ref_gen.Generator(512, 0.55, attention_values=10, use_sdf=True, disable_stylegan_noise=True).train()
     seen = {}
 
-    def fake_regularisers(self, planes, request):
+    def fake_regularisers(self, planes, request, texel_cache=None):
         seen.update(planes=planes, request=list(request))
         return {r: torch.zeros(planes.shape[0]) for r in request if r.endswith('_loss')}
     monkeypatch.setattr(nfi_gen, 'regulariser_outputs', fake_regularisers)

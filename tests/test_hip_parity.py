@@ -281,7 +281,7 @@ def test_fused_render_extra_maps(case):
         close(r['coords'], (w.unsqueeze(-1) * pts).sum(-2), 1e-5, 'coords map')
         if meta.get('coords'):
             close(r['coords'], o['semantics'], 1e-5, 'coords map (oracle render)')
-            close(r['coords'], t['ref_semantics'], 1e-5, 'coords map vs committed reference output')
+            close(r['coords'], t['ref_coords_map'], 1e-5, 'coords map vs committed reference output')
     # evaluating every ray instead of skipping the missed ones changes nothing (their weights are exactly 0)
     r0 = hip_render(meta, t, dev, skip_missed_rays=False, want_semantics=want_sem, want_coords=True)
     r1 = hip_render(meta, t, dev, skip_missed_rays=True, want_semantics=want_sem, want_coords=True)

@@ -376,7 +376,7 @@ def _viewdir_oracle(model, z, cam, focal, H, W, S, draws, white, double=False):
 def test_render_with_view_directions(gpu_device):
     """args.use_viewdir (carla): render() computes the rays first, hands their directions to the model
     (run.py:216-222), and the per-ray mapper feature + its output layer run inside the HIP kernels; fused
-    inference path and staged differentiable path against the oracle."""
+    inference path and the differentiable path (fused render + stash as one node) against the oracle."""
     torch.manual_seed(77)
     model = StandInGenerator(0.55, attention_values=10, use_sdf=True, plane_res=48, use_viewdir=True).to(gpu_device).eval()
     nfi_gen.attach(model)
@@ -387,16 +387,17 @@ def test_render_with_view_directions(gpu_device):
     z = torch.randn(B, 512, generator=g).to(gpu_device)
     cfg = types.SimpleNamespace(use_viewdir=True, use_sdf=True, attention_values=10, fine_sampling=True)
     render = nfi_render.make_render(cfg, {'scene_range': 0.55, 'white_background': False})
-    # staged path with gradients to the mapper, its output layer and the camera.  (The comparison is against a
+    # gradients to the mapper, its output layer and the camera.  (The comparison is against a
     # float64 oracle: a sample within fp32 rounding of a texel boundary has a different bilinear slope there - about
     # one such sample per ~1e5 is expected - so the noise draws of this test are pinned by the seed above.)
     params = [model.viewdir_mapper.fc0.weight, model.viewdir_mapper.fc6.bias, model.viewdir_mapper.output.weight,
               model.viewdir_mapper.output.bias, model.decoder.net[2].weight]
     cam_g = cam.clone().requires_grad_()
     w_rgb = torch.randn(B, H, W, 3, generator=g).to(gpu_device)
-    with RandTap() as tap:
+    with RandTap() as tap, OneRenderLaunch() as one:       # the view-direction decoder with a gradient: the one-node path too
         rgb2, _, mask2, _, _, _ = render(model, H, W, cam_g, focal, None, None, z, S)
-    got = torch.autograd.grad((rgb2 * w_rgb).sum() + mask2.sum(), params + [cam_g])
+        got = torch.autograd.grad((rgb2 * w_rgb).sum() + mask2.sum(), params + [cam_g])
+    assert one.calls == 1
     import copy
     m64 = copy.deepcopy(model).cpu().double()
     cam64 = cam.detach().cpu().double().requires_grad_()

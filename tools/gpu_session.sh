@@ -25,7 +25,7 @@ for w in $WHAT; do
         bench.py --gpus 1 --mode train --steps 30 --warmup 5 --force-dist > $O/train.json 2> $O/train.err; echo "train rc=$?" >> $O/env.txt; tail -c 1500 $O/train.json;;
     pmc)
       timeout 1200 python tools/pmc_collect.py --kernel render_fwd_kernel --out $O/pmc_render_fwd.json --marched-from-bench -- \
-        python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras > $O/pmc.log 2>&1; echo "pmc rc=$?" >> $O/env.txt; tail -30 $O/pmc.log;;
+        python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras --no-variants > $O/pmc.log 2>&1; echo "pmc rc=$?" >> $O/env.txt; tail -30 $O/pmc.log;;
     pmc_bwd)
       # the field backward kernel inside the training step (4 images x 128x128 rays x 64 samples per launch: the coarse and the fine half are separate launches)
       timeout 1200 python tools/pmc_collect.py --kernel field_query_bwd_kernel --out $O/pmc_backward.json --units 4194304 -- \
@@ -59,12 +59,14 @@ for f in glob.glob("$O/prof_train/**/*kernel_stats.csv", recursive=True):
 PY
       ;;
     prof_bench)
-      (cd /tmp && export TMPDIR=/tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_bench -o b -- python $R/bench.py --steps 100 --warmup 20 --no-extras --no-cpu-baseline > $O/prof_bench.log 2>&1); tail -c 300 $O/prof_bench.log
+      (cd /tmp && export TMPDIR=/tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_bench -o b -- python $R/bench.py --steps 100 --warmup 20 --no-extras --no-cpu-baseline --no-variants > $O/prof_bench.log 2>&1); tail -c 300 $O/prof_bench.log
       python tools/kstats.py $O/prof_bench 8;;
     regulariser)
       timeout 300 python tools/bench_regulariser.py > $O/bench_regulariser.log 2>&1; tail -2 $O/bench_regulariser.log;;
     train_bwd)
       timeout 300 python tools/bench_train_backward.py 30 > $O/bench_train_backward.log 2>&1; tail -2 $O/bench_train_backward.log;;
+    wide_occ)
+      timeout 300 python tools/probes/wide_occ.py > $O/wide_occ.log 2>&1; cat $O/wide_occ.log;;
     stress)
       timeout 900 python tools/repro_stress.py > $O/repro_stress.log 2>&1; tail -12 $O/repro_stress.log;;
   esac
