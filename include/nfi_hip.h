@@ -430,8 +430,7 @@ typedef struct nfi_render_args {
    * split-fp16 (hi+lo, 22 significand bits) MFMA; both meet the 1e-4 parity budget.  bit 4: ONE device-wide work
    * counter instead of the per-XCD queues over square pixel blocks (results identical; the per-XCD queues take the
    * largest of 32 / 16 / 8 pixels that divides both image sides, two positions per atomic, and fall back to the single
-   * counter when not even 8 does).  bit 5: the 128 + 128 kernel with fp16 texels at two workgroups per CU (256 registers,
-   * no scratch) instead of three (168 registers) - a measurement knob, results identical. */
+   * counter when not even 8 does). */
   int tuning;
   /* optional uint64[12] device array: per-phase shader-cycle sums over all waves (profiling build of
    * the kernel; NULL = off): field tile {issue, wait+interp, mlp, count}, ray set-up, coarse field,
@@ -483,6 +482,11 @@ typedef struct nfi_render_args {
    * the SAME render launch (rgb / depth / mask bit-identical to a call without it); neither is available together with
    * stage taps, the cycle profile, the view-direction decoder or the exact-fp32 MLP. */
   float* coords;
+  /* [N,3] or NULL: the composited normal map, sum_k w_k normalize(d sdf / d x)_k over the merged samples, + (1 - mask)
+   * on a white background (compute_normals: run.py:228-230, 241-245, 296-300; lib/nerf_utils.py:149-151, 159; the
+   * sampler's 'normals' output, models/generator.py:599-618, here the analytic derivative of the decoder's distance
+   * instead of autograd).  use_sdf only; fp32 or fp16 texels; same launch, same restrictions as `coords`. */
+  float* normals;
 } nfi_render_args;
 size_t nfi_render_workspace_bytes(int64_t n_rays);
 int nfi_render_fwd(const nfi_render_args* a, nfi_stream_t stream);

@@ -375,7 +375,28 @@ struct FieldParams {
   float neg_log2e_over_beta;      // -log2(e)/beta: exp(-|d|/beta) = exp2(|d| * this)
   const float* lds;              // LDS: decoder operand image (shared by the block)
   const float* vf;               // LDS: this scene's attention values in accumulator layout [16 rows][4]
+  // normal maps (field_wave<..., NRM>): W1' transposed as the A operand of the contraction over the hidden units,
+  // [2 channel tiles][4 n-tiles][64 lanes][4 regs], and row 0 of W2' in accumulator layout [4 groups][4 n-tiles][4 regs]
+  const float* w1t;
+  const float* w2r0;
 };
+constexpr int kW1TFloats = 2 * 4 * 64 * 4, kNrmLdsFloats = kW1TFloats + 64;
+
+// The two tables above from the fp32 section of the decoder operand image (global), by the threads of a block:
+//   W1F[s][(g', m')][nt] = W1'[unit 16 nt + m'][channel c(s, g')], c(s, g') = s < 4 ? 4 g' + s : 16 + 4 g' + (s - 4)
+//   -> w1t[(ct, nt)][(g, m)][r] = W1'[unit 16 nt + 4 g + r][channel 16 ct + m] = W1F[4 ct + (m & 3)][(m >> 2, 4 g + r)][nt]
+//   W2F[nt][(g, m)][r] = W2'[row m][unit 16 nt + 4 g + r]  ->  w2r0[g][nt][r] = W2F[nt][(g, 0)][r]
+__device__ __forceinline__ void stage_normal_operands(float* dst, const float* image) {
+  for (int i = threadIdx.x; i < kW1TFloats; i += blockDim.x) {
+    const int r = i & 3, ln = (i >> 2) & 63, nt = (i >> 8) & 3, ct = i >> 10;
+    const int g = ln >> 4, m = ln & 15;
+    dst[i] = image[kW1F + (((4 * ct + (m & 3)) * 64 + (16 * (m >> 2) + 4 * g + r)) << 2) + nt];
+  }
+  for (int i = threadIdx.x; i < 64; i += blockDim.x) {
+    const int r = i & 3, nt = (i >> 2) & 3, g = i >> 4;
+    dst[kW1TFloats + i] = image[kW2F + ((nt * 64 + 16 * g) << 2) + r];
+  }
+}
 
 // per-point gather set-up in sample layout: unnormalised, border-clamped plane coordinates.
 // grid_sample(align_corners=True): u = ((p+1)/2)*(R-1); border: clamp to [0,R-1].  The left
@@ -775,9 +796,12 @@ __device__ __forceinline__ uint32_t ratio_f16x2(int es, float inv_pt) {
 //         fp32's 2^-24, an order of magnitude below the 1e-4 parity budget, at 1/5 of the matrix-pipe time.
 //         On gfx950 the f32-input MFMA runs at the f32 VECTOR rate and does not overlap with VALU work of
 //         other waves (tools/probes/mfma_valu_overlap.hip), so this time comes straight off the kernel.
-template <bool ATT, int N, int PREC, int SEMP = 0>
+// NRM: gh[n][nt] receives d(distance) / d(h2) of the lane's hidden units = sigmoid(h) * W2'[0][unit] (accumulator layout),
+// the operand of the normal map's contraction with W1' (field_wave).
+template <bool ATT, int N, int PREC, int SEMP = 0, bool NRM = false>
 __device__ __forceinline__ void tile_mlp(const FieldParams& P, int lane, const float (&feat)[N][8],
-                                         const float (&outside)[N], float* const (&sem)[N], TileOut (&res)[N]) {
+                                         const float (&outside)[N], float* const (&sem)[N], TileOut (&res)[N],
+                                         f32x4 (&gh)[N][4]) {
   const int g = lane >> 4;
   const f32x4* ldsv = reinterpret_cast<const f32x4*>(P.lds);
   f32x4 o[N];
@@ -811,6 +835,10 @@ __device__ __forceinline__ void tile_mlp(const FieldParams& P, int lane, const f
           float e = __builtin_amdgcn_exp2f(h);
           float sp = __builtin_amdgcn_logf(1.0f + e);
           acc1[n][nt][r] = __builtin_amdgcn_fmed3f(sp, h, 128.0f);
+          if constexpr (NRM) {
+            const float sg = (h > kSoftplusThr2) ? 1.0f : e * __builtin_amdgcn_rcpf(1.0f + e);     // d softplus2 / d h2
+            gh[n][nt][r] = sg * reinterpret_cast<const f32x4*>(P.w2r0)[g * 4 + nt][r];
+          }
         }
     const f32x4 b2 = ldsv[(kB2F >> 2) + g];
 #pragma unroll
@@ -864,6 +892,10 @@ __device__ __forceinline__ void tile_mlp(const FieldParams& P, int lane, const f
           float e = __builtin_amdgcn_exp2f(h);
           float sp = __builtin_amdgcn_logf(1.0f + e);
           acc1[n][nt][r] = (h > kSoftplusThr2) ? h : sp;
+          if constexpr (NRM) {
+            const float sg = (h > kSoftplusThr2) ? 1.0f : e * __builtin_amdgcn_rcpf(1.0f + e);
+            gh[n][nt][r] = sg * reinterpret_cast<const f32x4*>(P.w2r0)[g * 4 + nt][r];
+          }
         }
     // ---- layer 2: O^T[16 x 16] = W2'[16 x 64] * SP^T[64 x 16]; two accumulators per tile ----
     f32x4 o0[N], o1[N];
@@ -886,6 +918,12 @@ __device__ __forceinline__ void tile_mlp(const FieldParams& P, int lane, const f
   }
 
   tile_epilogue<ATT, N, SEMP>(P, lane, o, outside, sem, res);
+}
+template <bool ATT, int N, int PREC, int SEMP = 0>
+__device__ __forceinline__ void tile_mlp(const FieldParams& P, int lane, const float (&feat)[N][8],
+                                         const float (&outside)[N], float* const (&sem)[N], TileOut (&res)[N]) {
+  f32x4 unused[N][4];
+  tile_mlp<ATT, N, PREC, SEMP, false>(P, lane, feat, outside, sem, res, unused);
 }
 
 // View-direction variant of the decoder (exact fp32 MFMA): layer 1 as above, layer 2 with 33 outputs
@@ -977,6 +1015,7 @@ __device__ __forceinline__ void tile_mlp_vd(const FieldParams& P, int lane, cons
 
 struct SampleOut {
   float sdf, sigma, r, g, b;
+  float nx, ny, nz;     // field_wave<..., NRM>: normalize(d sdf / d x) of the sample (models/generator.py:609-618)
 };
 
 // Field query for the (up to) 64 points a wave holds one per lane.  px,py,pz: WORLD coordinates;
@@ -990,7 +1029,12 @@ struct SampleOut {
 // prof: null, or 4 cycle accumulators {tile set-up + load issue, load wait + interpolation,
 // transpose + MLP + epilogue, tiles} filled with s_memtime deltas (profiling builds only)
 // VD: view-direction decoder; xray = padded per-ray features [rays][kRayFeatPad], ray_idx = this lane's ray.
-template <int TEX, bool ATT, bool SKIP, int PREC = 0, bool VD = false, int SEMP = 0>
+// NRM (fused renderer, compute_normals): the sample's unit normal normalize(d sdf / d x) - the decoder's distance
+// differentiated analytically: G = W1'^T (sigmoid(h) * W2'[0]) on 32 fp32 MFMAs per tile, then its inner product with the
+// bilinear footprint's corner differences from a second (cache-hot) gather, one plane at a time; the positive factors
+// common to the three axes ((R - 1) / 2 / scene_range, the plane mean's 1/3, the base-2 scalings) drop out of the
+// normalisation.  Border-clamped coordinates carry no gradient, like grid_sample's.
+template <int TEX, bool ATT, bool SKIP, int PREC = 0, bool VD = false, int SEMP = 0, bool NRM = false>
 __device__ __forceinline__ SampleOut field_wave(const FieldParams& P, float scene_range, int lane, float px, float py,
                                                 float pz, bool valid, float* sem_base, bool* outside_flag,
                                                 float* stage, unsigned long long* prof = nullptr,
@@ -1006,8 +1050,12 @@ __device__ __forceinline__ SampleOut field_wave(const FieldParams& P, float scen
   plane_coord(qz, P.res_m1, P.res, z0, fz);
   if (!valid) { x0 = y0 = z0 = 0; fx = fy = fz = 0.0f; }  // keep NaN/garbage out of the address math
   const int xi = (int)((uint32_t)x0 | ((uint32_t)y0 << 10) | ((uint32_t)z0 << 20));
-  // bit 0: outside, bit 1: valid
-  const int flags = (out ? 1 : 0) | (valid ? 2 : 0);
+  // bit 0: outside, bit 1: valid, bits 2-4 (NRM): the axis' unnormalised coordinate lies strictly inside (0, R-1)
+  int flags = (out ? 1 : 0) | (valid ? 2 : 0);
+  if constexpr (NRM) {
+    auto inside = [&](float q) { float u = ((q + 1.0f) / 2.0f) * P.res_m1; return (u > 0.0f && u < P.res_m1) ? 1 : 0; };
+    flags |= (inside(qx) << 2) | (inside(qy) << 3) | (inside(qz) << 4);
+  }
   const uint64_t live = SKIP ? __ballot(valid && !out) : __ballot(valid);
   uint32_t tm = 0;   // wave-uniform 4-bit mask of tiles with work
 #pragma unroll
@@ -1015,6 +1063,7 @@ __device__ __forceinline__ SampleOut field_wave(const FieldParams& P, float scen
 
   SampleOut so;
   so.sdf = 0.0f; so.sigma = 0.0f; so.r = 0.0f; so.g = 0.0f; so.b = 0.0f;
+  so.nx = 0.0f; so.ny = 0.0f; so.nz = 0.0f;
   if (tm == 0) return so;
   const int j = lane & 15, g = lane >> 4;
 
@@ -1088,6 +1137,85 @@ __device__ __forceinline__ SampleOut field_wave(const FieldParams& P, float scen
         xr[1][t] = *reinterpret_cast<const f32x4*>(xray + (size_t)rb * kRayFeatPad + 16 * t + 4 * g);
       }
       tile_mlp_vd<ATT, 2>(P, lane, feat, xr, outs, sems, to);
+    } else if constexpr (NRM) {
+      f32x4 gh[2][4];
+      tile_mlp<ATT, 2, PREC, SEMP, true>(P, lane, feat, outs, sems, to, gh);
+      // ---- normals of the pair's points, one tile at a time ----
+#pragma unroll 1
+      for (int n = 0; n < 2; ++n) {
+        if (n == 1 && !pair) break;
+        const int t = n ? tb : ta;
+        // G^T[32 channels x 16 points] = W1'^T[32 x 64] * GH[64 x 16]: rows 16 ct + 4 g + r, the channel ownership of `feat`
+        f32x4 G[2] = {f32x4{0.0f, 0.0f, 0.0f, 0.0f}, f32x4{0.0f, 0.0f, 0.0f, 0.0f}};
+        const f32x4* w1t = reinterpret_cast<const f32x4*>(P.w1t);
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+          for (int ct = 0; ct < 2; ++ct) {
+            const f32x4 w = w1t[(ct * 4 + nt) * 64 + lane];
+            const f32x4 b = n ? gh[1][nt] : gh[0][nt];
+            G[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(w.x, b.x, G[ct], 0, 0, 0);
+            G[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(w.y, b.y, G[ct], 0, 0, 0);
+            G[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(w.z, b.z, G[ct], 0, 0, 0);
+            G[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(w.w, b.w, G[ct], 0, 0, 0);
+          }
+        // M -> L layout through the stage tile (the mirror image of gather_tile's transpose)
+        f32x4* wr = reinterpret_cast<f32x4*>(stage + j * 36 + g * 4);
+        wr[0] = G[0]; wr[4] = G[1];
+        wave_lds_fence();
+        float gfL[8];
+        {
+          const f32x4* rd = reinterpret_cast<const f32x4*>(stage + lp * 36 + lq * 4);
+          const f32x4 lo = rd[0], hi = rd[4];
+          gfL[0] = lo.x; gfL[1] = lo.y; gfL[2] = lo.z; gfL[3] = lo.w;
+          gfL[4] = hi.x; gfL[5] = hi.y; gfL[6] = hi.z; gfL[7] = hi.w;
+        }
+        wave_lds_fence();
+        const int srcL = 16 * t + lp;
+        const float cfx = __shfl(fx, srcL, 64), cfy = __shfl(fy, srcL, 64), cfz = __shfl(fz, srcL, 64);
+        const uint32_t cxi = (uint32_t)__shfl(xi, srcL, 64);
+        const int flL = __shfl(flags, srcL, 64);
+        float gcoord[3] = {0.0f, 0.0f, 0.0f};
+        const uint32_t x0 = cxi & 1023u, y0 = (cxi >> 10) & 1023u, z0 = (cxi >> 20) & 1023u;
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) {
+          const uint32_t a0 = (pl == 2) ? y0 : x0, b0 = (pl == 0) ? y0 : z0;
+          const uint32_t voff = (uint32_t)pl * P.plane_bytes + __umul24(b0 * (uint32_t)P.res + a0, P.pix_bytes) + (uint32_t)lq * 16u;
+          float tv[4][8];
+          load_texel8<TEX>(P, voff, 0, 0, tv[0]);
+          load_texel8<TEX>(P, voff, P.pix_bytes, 0, tv[1]);
+          load_texel8<TEX>(P, voff, P.row_bytes, 0, tv[2]);
+          load_texel8<TEX>(P, voff, P.row_pix_bytes, 0, tv[3]);
+          const float fa = (pl == 2) ? cfy : cfx, fb = (pl == 0) ? cfy : cfz;
+          const float ga = 1.0f - fa, gb = 1.0f - fb;
+          float dcorner[4];
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            float acc = 0.0f;
+#pragma unroll
+            for (int s8 = 0; s8 < 8; ++s8) acc = fmaf(gfL[s8], tv[c][s8], acc);
+            acc += dpp_f32<kDppQuadXor1>(0.0f, acc);          // sum over the 4 lanes (channel chunks) of the point
+            acc += dpp_f32<kDppQuadXor2>(0.0f, acc);
+            dcorner[c] = acc;
+          }
+          const float g_fa = gb * (dcorner[1] - dcorner[0]) + fb * (dcorner[3] - dcorner[2]);
+          const float g_fb = ga * (dcorner[2] - dcorner[0]) + fa * (dcorner[3] - dcorner[1]);
+          gcoord[(pl == 2) ? 1 : 0] += g_fa;                    // plane 0: (x,y)  plane 1: (x,z)  plane 2: (y,z)
+          gcoord[(pl == 0) ? 1 : 2] += g_fb;
+          __builtin_amdgcn_sched_barrier(0);                    // one plane's 32 texel registers at a time
+        }
+        float gx = ((flL >> 2) & 1) ? gcoord[0] : 0.0f, gy = ((flL >> 3) & 1) ? gcoord[1] : 0.0f,
+              gz = ((flL >> 4) & 1) ? gcoord[2] : 0.0f;
+        // F.normalize(x_grad, dim=-1): the common factor (R - 1) / 2 / scene_range is applied first so that the eps clamp
+        // sees the reference's magnitude
+        const float sc = (P.res_m1 * 0.5f) / scene_range;
+        gx *= sc; gy *= sc; gz *= sc;
+        const float nrm = fmaxf(norm3(gx, gy, gz), 1e-12f);
+        gx /= nrm; gy /= nrm; gz /= nrm;
+        // the point's lanes 4 p .. 4 p + 3 all hold the result; sample lane 16 t + p takes it from lane 4 p
+        const float sx = __shfl(gx, 4 * j, 64), sy = __shfl(gy, 4 * j, 64), sz = __shfl(gz, 4 * j, 64);
+        if (g == t) { so.nx = sx; so.ny = sy; so.nz = sz; }
+      }
     } else {
       tile_mlp<ATT, 2, PREC, SEMP>(P, lane, feat, outs, sems, to);
     }

@@ -1345,6 +1345,7 @@ struct RenderKernelParams {
   float term_eps;      // kRenderTerm kernels: coarse transmittance below which fine samples are no longer evaluated
   float* semantics;    // kRenderExtra kernels: composited softmax probabilities [N][A], or null
   float* coords;       // kRenderExtra kernels: composited query points [N][3], or null
+  float* normals;      // kRenderNormals kernels: composited unit normals [N][3]
   unsigned long long* clock_probe;   // null, or {shader cycles, 100 MHz ticks} lived by workgroup 0 / wave 0
   FastDiv div_hw, div_bps, div_bw;   // division by rays per image, blocks per scene, blocks per image row (nfi_device.hpp)
   int tap_stride;      // entries per ray in the per-sample tap arrays: S, or 2S for the training stash (fine half at +S)
@@ -1444,9 +1445,14 @@ struct RayQueue {
 //                 (softmax probabilities, parked per sample in a per-wave LDS table [A][pitch] by the field epilogue and
 //                 composited with the merged weights brought back to source order) and `coords` (the query point
 //                 o + d t of every merged sample)
-constexpr int kRenderPlain = 0, kRenderTaps = 1, kRenderProf = 2, kRenderTerm = 3, kRenderExtra = 4;
+//   kRenderNormals  kRenderExtra + the composited `normals` map (SDF only; lib/nerf_utils.py:149-151, 159): every sample's
+//                 normalize(d sdf / d x) from the analytic derivative of the decoder (field_wave<..., NRM>), composited
+//                 with the merged weights in source order like the semantics
+constexpr int kRenderPlain = 0, kRenderTaps = 1, kRenderProf = 2, kRenderTerm = 3, kRenderExtra = 4, kRenderNormals = 5;
 constexpr int kSemPitch = 2 * 64 + 4, kSemPitchWide = 2 * 128 + 4;   // pitch = 4 (mod 64): conflict-free stores from the MFMA layout
-extern __shared__ __attribute__((aligned(16))) float nfi_dyn_lds[];   // kRenderExtra: 4 waves x A x pitch floats
+// dynamic LDS of the kRenderExtra / kRenderNormals kernels: [normal operands: kNrmLdsFloats, kRenderNormals only]
+// [semantics tables: 4 waves x A x pitch floats, when asked for]
+extern __shared__ __attribute__((aligned(16))) float nfi_dyn_lds[];
 
 typedef __attribute__((address_space(3))) float lds_float;
 
@@ -1470,12 +1476,14 @@ __device__ __forceinline__ void composite_coords(const Slab& slab, const float (
 
 template <int TEX, bool ATT, int OCC, int MODE, int PREC, bool VD = false>
 __global__ __launch_bounds__(256, OCC) void render_fwd_kernel(RenderKernelParams k) {
-  constexpr bool TAPS = MODE == kRenderTaps, PROF = MODE == kRenderProf, TERM = MODE == kRenderTerm, EXTRA = MODE == kRenderExtra;
+  constexpr bool TAPS = MODE == kRenderTaps, PROF = MODE == kRenderProf, TERM = MODE == kRenderTerm;
+  constexpr bool EXTRA = MODE == kRenderExtra || MODE == kRenderNormals, NRM = MODE == kRenderNormals;
   constexpr int SEMP = (EXTRA && ATT) ? kSemPitch : 0;
   constexpr int kImg = VD ? kVdImageFloats : kLdsImageFloats;
   __shared__ __attribute__((aligned(16))) float lds[kImg];
   __shared__ __attribute__((aligned(16))) float vfs[4][64];
   __shared__ WaveSlab slabs[4];
+  if constexpr (NRM) stage_normal_operands(nfi_dyn_lds, k.image);
   ClockProbe clock;
   clock.start(k);
   if (PREC == 1) {
@@ -1510,6 +1518,7 @@ __global__ __launch_bounds__(256, OCC) void render_fwd_kernel(RenderKernelParams
 
   FieldParams P = make_field_params(k.texels, k.res, TEX, k.A, k.use_sdf, k.beta, k.alpha, lds, kImg, k.layout);
   P.vf = vf;
+  P.w1t = nfi_dyn_lds; P.w2r0 = nfi_dyn_lds + kW1TFloats;       // (kRenderNormals only)
   int cur_scene = -1;
 
   // kRenderExtra: this wave's semantics table [A][kSemPitch]: column = sample (coarse [0,64), fine [64,128)).  Zeroed once:
@@ -1518,7 +1527,7 @@ __global__ __launch_bounds__(256, OCC) void render_fwd_kernel(RenderKernelParams
   float* semT = nullptr;
   if constexpr (SEMP > 0) {
     if (k.semantics) {
-      semT = nfi_dyn_lds + wave * (k.A * kSemPitch);
+      semT = nfi_dyn_lds + (NRM ? kNrmLdsFloats : 0) + wave * (k.A * kSemPitch);
       for (int i = lane; i < k.A * kSemPitch; i += 64) ((lds_float*)semT)[i] = 0.0f;
       wave_lds_fence();
     }
@@ -1558,6 +1567,7 @@ __global__ __launch_bounds__(256, OCC) void render_fwd_kernel(RenderKernelParams
       if constexpr (EXTRA) {
         if (k.coords && lane < 3) k.coords[(size_t)ray * 3 + lane] = 0.0f;
         if (k.semantics && lane < k.A) k.semantics[(size_t)ray * k.A + lane] = 0.0f;
+        if (NRM && lane < 3) k.normals[(size_t)ray * 3 + lane] = bg;      // sum w n + (1 - mask) on a white background
       }
       if constexpr (TAPS) {
         if (k.stash && valid) {
@@ -1597,12 +1607,14 @@ __global__ __launch_bounds__(256, OCC) void render_fwd_kernel(RenderKernelParams
       float tc = 0.0f;
       if (valid) tc = stratified_depth(near, far, lane, S, in.noise, k.noise_c != nullptr);
       MergeIn c;
+      float ncx = 0.0f, ncy = 0.0f, ncz = 0.0f, nfx = 0.0f, nfy = 0.0f, nfz = 0.0f;     // NRM: the samples' unit normals
       unsigned long long t1 = PROF ? __builtin_readcyclecounter() : 0;
       {
-        SampleOut q = field_wave<TEX, ATT, true, PREC, VD, SEMP>(P, k.scene_range, lane, ox + dx * tc, oy + dy * tc, oz + dz * tc,
-                                                                 valid, semT, nullptr, &slab.srt[0][0], PROF ? pc : nullptr,
-                                                                 k.xray, (int)ray);
+        SampleOut q = field_wave<TEX, ATT, true, PREC, VD, SEMP, NRM>(P, k.scene_range, lane, ox + dx * tc, oy + dy * tc, oz + dz * tc,
+                                                                      valid, semT, nullptr, &slab.srt[0][0], PROF ? pc : nullptr,
+                                                                      k.xray, (int)ray);
         c.t = tc; c.sigma = q.sigma; c.r = q.r; c.g = q.g; c.b = q.b;
+        if constexpr (NRM) { ncx = q.nx; ncy = q.ny; ncz = q.nz; }
       }
       int n = S;
       int rank_c = lane, rank_f = 0;
@@ -1634,10 +1646,11 @@ __global__ __launch_bounds__(256, OCC) void render_fwd_kernel(RenderKernelParams
                                                              nullptr, nullptr, &slab.srt[0][0], nullptr, k.xray, (int)ray);
           f.t = tf; f.sigma = vl ? q.sigma : 0.0f; f.r = vl ? q.r : 0.0f; f.g = vl ? q.g : 0.0f; f.b = vl ? q.b : 0.0f;
         } else {
-          SampleOut q = field_wave<TEX, ATT, true, PREC, VD, SEMP>(P, k.scene_range, lane, ox + dx * tf, oy + dy * tf, oz + dz * tf,
-                                                                   valid, semT ? semT + 64 : nullptr, nullptr, &slab.srt[0][0],
-                                                                   PROF ? pc : nullptr, k.xray, (int)ray);
+          SampleOut q = field_wave<TEX, ATT, true, PREC, VD, SEMP, NRM>(P, k.scene_range, lane, ox + dx * tf, oy + dy * tf, oz + dz * tf,
+                                                                        valid, semT ? semT + 64 : nullptr, nullptr, &slab.srt[0][0],
+                                                                        PROF ? pc : nullptr, k.xray, (int)ray);
           f.t = tf; f.sigma = q.sigma; f.r = q.r; f.g = q.g; f.b = q.b;
+          if constexpr (NRM) { nfx = q.nx; nfy = q.ny; nfz = q.nz; }
         }
         if constexpr (TAPS) {
           if (valid) {
@@ -1662,14 +1675,24 @@ __global__ __launch_bounds__(256, OCC) void render_fwd_kernel(RenderKernelParams
       }
       if constexpr (EXTRA) {
         if (k.coords) composite_coords<2>(slab, w, n, lane, ox, oy, oz, dx, dy, dz, k.coords + (size_t)ray * 3);
+        float wc = 0.0f, wf = 0.0f;
+        if ((SEMP > 0 && semT) || NRM) {
+          // the merged weights back in source order (lane = sample): the cdf row is free after the merge
+          wave_lds_fence();
+          slab.cdf[lane] = w[0]; slab.cdf[64 + lane] = w[1];
+          wave_lds_fence();
+          wc = valid ? slab.cdf[rank_c] : 0.0f;
+          wf = (valid && k.fine) ? slab.cdf[rank_f] : 0.0f;
+        }
+        if constexpr (NRM) {
+          // normal_map = sum_k w_k n_k (+ 1 - mask on a white background), lib/nerf_utils.py:149-151, 159
+          const float bgn = k.white ? 1.0f - o.mask : 0.0f;
+          const float mx = wave_sum(wc * ncx + wf * nfx) + bgn, my = wave_sum(wc * ncy + wf * nfy) + bgn,
+                      mz = wave_sum(wc * ncz + wf * nfz) + bgn;
+          if (lane == 0) { float* q = k.normals + (size_t)ray * 3; q[0] = mx; q[1] = my; q[2] = mz; }
+        }
         if constexpr (SEMP > 0) {
           if (semT) {
-            // the merged weights back in source order (lane = sample): the cdf row is free after the merge
-            wave_lds_fence();
-            slab.cdf[lane] = w[0]; slab.cdf[64 + lane] = w[1];
-            wave_lds_fence();
-            const float wc = valid ? slab.cdf[rank_c] : 0.0f;
-            const float wf = (valid && k.fine) ? slab.cdf[rank_f] : 0.0f;
             const lds_float* sl = (const lds_float*)semT;
             float mine = 0.0f;
             for (int a = 0; a < k.A; ++a) {
@@ -1735,12 +1758,14 @@ template __global__ void render_fwd_kernel<NFI_SINGLE_KERNEL, true, NFI_RENDER_O
 // at a time, and the merge ranks all 2S keys against each other.
 template <int TEX, bool ATT, int MODE, int PREC, bool VD = false, int OCC = NFI_RENDER_OCC>
 __global__ __launch_bounds__(256, OCC) void render_fwd_wide_kernel(RenderKernelParams k) {
-  constexpr bool TAPS = MODE == kRenderTaps, TERM = MODE == kRenderTerm, EXTRA = MODE == kRenderExtra;
+  constexpr bool TAPS = MODE == kRenderTaps, TERM = MODE == kRenderTerm;
+  constexpr bool EXTRA = MODE == kRenderExtra || MODE == kRenderNormals, NRM = MODE == kRenderNormals;
   constexpr int SEMP = (EXTRA && ATT) ? kSemPitchWide : 0;
   constexpr int kImg = VD ? kVdImageFloats : kLdsImageFloats;
   __shared__ __attribute__((aligned(16))) float lds[kImg];
   __shared__ __attribute__((aligned(16))) float vfs[4][64];
   __shared__ WaveSlabWide slabs[4];
+  if constexpr (NRM) stage_normal_operands(nfi_dyn_lds, k.image);
   ClockProbe clock;
   clock.start(k);
   if (PREC == 1) {
@@ -1769,12 +1794,13 @@ __global__ __launch_bounds__(256, OCC) void render_fwd_wide_kernel(RenderKernelP
   };
   FieldParams P = make_field_params(k.texels, k.res, TEX, k.A, k.use_sdf, k.beta, k.alpha, lds, kImg, k.layout);
   P.vf = vf;
+  P.w1t = nfi_dyn_lds; P.w2r0 = nfi_dyn_lds + kW1TFloats;       // (kRenderNormals only)
   int cur_scene = -1;
   // kRenderExtra: this wave's semantics table [A][kSemPitchWide], column = sample: coarse [0,128), fine [128,256)
   float* semT = nullptr;
   if constexpr (SEMP > 0) {
     if (k.semantics) {
-      semT = nfi_dyn_lds + wave * (k.A * kSemPitchWide);
+      semT = nfi_dyn_lds + (NRM ? kNrmLdsFloats : 0) + wave * (k.A * kSemPitchWide);
       for (int i = lane; i < k.A * kSemPitchWide; i += 64) ((lds_float*)semT)[i] = 0.0f;
       wave_lds_fence();
     }
@@ -1793,6 +1819,7 @@ __global__ __launch_bounds__(256, OCC) void render_fwd_wide_kernel(RenderKernelP
       if constexpr (EXTRA) {
         if (k.coords && lane < 3) k.coords[(size_t)ray * 3 + lane] = 0.0f;
         if (k.semantics && lane < k.A) k.semantics[(size_t)ray * k.A + lane] = 0.0f;
+        if (NRM && lane < 3) k.normals[(size_t)ray * 3 + lane] = bg;
       }
       if constexpr (TAPS) {
         if (k.stash) {
@@ -1845,12 +1872,16 @@ __global__ __launch_bounds__(256, OCC) void render_fwd_wide_kernel(RenderKernelP
         const float nz = (k.noise_c && val[j]) ? k.noise_c[rs + e] : 0.0f;
         tc[j] = val[j] ? stratified_depth(near, far, e, S, nz, k.noise_c != nullptr) : 0.0f;
       }
+      float nrm[4][3];                  // NRM: unit normals of the coarse (slots 0, 1) and fine (2, 3) samples
+#pragma unroll
+      for (int j = 0; j < 4; ++j) nrm[j][0] = nrm[j][1] = nrm[j][2] = 0.0f;
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
-        SampleOut q = field_wave<TEX, ATT, true, PREC, VD, SEMP>(P, k.scene_range, lane, ox + dx * tc[j], oy + dy * tc[j],
-                                                                 oz + dz * tc[j], val[j], semT ? semT + j * 64 : nullptr, nullptr,
-                                                                 stage, nullptr, k.xray, (int)ray);
+        SampleOut q = field_wave<TEX, ATT, true, PREC, VD, SEMP, NRM>(P, k.scene_range, lane, ox + dx * tc[j], oy + dy * tc[j],
+                                                                      oz + dz * tc[j], val[j], semT ? semT + j * 64 : nullptr, nullptr,
+                                                                      stage, nullptr, k.xray, (int)ray);
         sc[j] = q.sigma; rc[j] = q.r; gc[j] = q.g; bc[j] = q.b;
+        if constexpr (NRM) { nrm[j][0] = q.nx; nrm[j][1] = q.ny; nrm[j][2] = q.nz; }
       }
       int n = S;
       float dep[4], sig[4], cr[4], cg[4], cb[4];
@@ -1898,10 +1929,11 @@ __global__ __launch_bounds__(256, OCC) void render_fwd_wide_kernel(RenderKernelP
         }
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-          SampleOut q = field_wave<TEX, ATT, true, PREC, VD, SEMP>(P, k.scene_range, lane, ox + dx * tf[j], oy + dy * tf[j],
-                                                                   oz + dz * tf[j], vfine[j], semT ? semT + 128 + j * 64 : nullptr,
-                                                                   nullptr, stage, nullptr, k.xray, (int)ray);
+          SampleOut q = field_wave<TEX, ATT, true, PREC, VD, SEMP, NRM>(P, k.scene_range, lane, ox + dx * tf[j], oy + dy * tf[j],
+                                                                        oz + dz * tf[j], vfine[j], semT ? semT + 128 + j * 64 : nullptr,
+                                                                        nullptr, stage, nullptr, k.xray, (int)ray);
           if (TERM && !vfine[j]) { q.sigma = 0.0f; q.r = 0.0f; q.g = 0.0f; q.b = 0.0f; }
+          if constexpr (NRM) { nrm[2 + j][0] = q.nx; nrm[2 + j][1] = q.ny; nrm[2 + j][2] = q.nz; }
           dep[2 + j] = tf[j]; sig[2 + j] = q.sigma; cr[2 + j] = q.r; cg[2 + j] = q.g; cb[2 + j] = q.b;
           eidx[2 + j] = val[j] ? S + j * 64 + lane : 0x7fffffff;
           if constexpr (TAPS) {
@@ -1934,19 +1966,29 @@ __global__ __launch_bounds__(256, OCC) void render_fwd_wide_kernel(RenderKernelP
       }
       if constexpr (EXTRA) {
         if (k.coords) composite_coords<4>(slab, w, n, lane, ox, oy, oz, dx, dy, dz, k.coords + (size_t)ray * 3);
+        float ws[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+        if ((SEMP > 0 && semT) || NRM) {
+          // the merged weights back in source order (the cdf row is free after the merge)
+          wave_lds_fence();
+#pragma unroll
+          for (int j = 0; j < 4; ++j) slab.cdf[j * 64 + lane] = w[j];
+          wave_lds_fence();
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            ws[j] = val[j] ? slab.cdf[rank[j]] : 0.0f;
+            ws[2 + j] = (val[j] && k.fine) ? slab.cdf[rank[2 + j]] : 0.0f;
+          }
+        }
+        if constexpr (NRM) {
+          const float bgn = k.white ? 1.0f - o.mask : 0.0f;
+          float m3[3];
+#pragma unroll
+          for (int c = 0; c < 3; ++c)
+            m3[c] = wave_sum((ws[0] * nrm[0][c] + ws[1] * nrm[1][c]) + (ws[2] * nrm[2][c] + ws[3] * nrm[3][c])) + bgn;
+          if (lane == 0) { float* q = k.normals + (size_t)ray * 3; q[0] = m3[0]; q[1] = m3[1]; q[2] = m3[2]; }
+        }
         if constexpr (SEMP > 0) {
           if (semT) {
-            // the merged weights back in source order (the cdf row is free after the merge)
-            wave_lds_fence();
-#pragma unroll
-            for (int j = 0; j < 4; ++j) slab.cdf[j * 64 + lane] = w[j];
-            wave_lds_fence();
-            float ws[4];
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-              ws[j] = val[j] ? slab.cdf[rank[j]] : 0.0f;
-              ws[2 + j] = (val[j] && k.fine) ? slab.cdf[rank[2 + j]] : 0.0f;
-            }
             const lds_float* sl = (const lds_float*)semT;
             float mine = 0.0f;
             for (int a = 0; a < k.A; ++a) {
@@ -2132,15 +2174,17 @@ extern "C" int nfi_render_fwd(const nfi_render_args* a, nfi_stream_t stream) {
   k.clock_probe = reinterpret_cast<unsigned long long*>(a->clock_probe);
   const bool strict = ((a->tuning >> 3) & 1) != 0;   // exact-fp32 MLP instead of the split-fp16 one
   const bool term = a->termination_eps > 0.0f;
-  const bool extra = a->semantics || a->coords;
+  const bool extra = a->semantics || a->coords || a->normals;
+  REQUIRE(!a->normals || a->use_sdf, "render: the normals map needs the SDF decoder (use_sdf)");
+  REQUIRE(!a->normals || a->texel_dtype != NFI_TEXEL_BF16, "render: the normals map exists for fp32 and fp16 texels");
   REQUIRE(a->termination_eps >= 0.0f && a->termination_eps < 1.0f, "render: termination_eps must be in [0,1)");
   REQUIRE(!term || a->fine_sampling, "render: termination_eps acts on the fine pass (fine_sampling)");
   REQUIRE(!term || !(any_tap || extra || a->profile_cycles || a->ray_features || strict),
           "render: termination_eps cannot be combined with stage taps, extra maps, the cycle profile, the view-direction decoder or the exact-fp32 MLP");
   REQUIRE(!extra || !(any_tap || a->profile_cycles || a->ray_features || strict),
-          "render: semantics / coords maps cannot be combined with stage taps, the cycle profile, the view-direction decoder or the exact-fp32 MLP");
+          "render: semantics / coords / normals maps cannot be combined with stage taps, the cycle profile, the view-direction decoder or the exact-fp32 MLP");
   k.term_eps = a->termination_eps;
-  k.semantics = a->semantics; k.coords = a->coords;
+  k.semantics = a->semantics; k.coords = a->coords; k.normals = a->normals;
   REQUIRE(!(a->ray_features && a->profile_cycles), "render: no cycle profile with the view-direction decoder");
   // persistent 1-D grid: OCC blocks of 4 waves per CU, never more blocks than rays need
   // 2 blocks (8 waves) per CU: with the whole 256-VGPR budget the field tile keeps more loads and MFMA chains in
@@ -2155,16 +2199,22 @@ extern "C" int nfi_render_fwd(const nfi_render_args* a, nfi_stream_t stream) {
   bool att = a->n_attention > 0;
   // kRenderExtra with semantics: the per-wave tables [A][pitch] in dynamic LDS
   const bool wide = a->n_samples > 64;
-  // fp16 texels, 128 + 128: three workgroups per CU (168 registers, ~40 scratch reloads per ray outside the field tiles);
-  // tuning bit 5 keeps two (256 registers, no scratch) for the A/B measurement
-  const bool wide_occ2 = ((a->tuning >> 5) & 1) != 0;
-  const size_t sem_lds = a->semantics ? (size_t)4 * a->n_attention * (wide ? kSemPitchWide : kSemPitch) * sizeof(float) : 0;
-  constexpr size_t kSemLdsMax = (size_t)4 * NFI_MAX_ATTENTION * kSemPitch * sizeof(float);
-  constexpr size_t kSemLdsMaxWide = (size_t)4 * NFI_MAX_ATTENTION * kSemPitchWide * sizeof(float);
+  // (fp16 texels, 128 + 128, at THREE workgroups per CU - 168 registers, ~40 scratch reloads per ray outside the field
+  //  tiles - was measured in round 4 and is slower: 1.387 vs 1.300 ms chairs-like, 2.249 vs 2.156 ms every ray hits, images
+  //  identical (profiles/r4/wide_fp16_three_workgroups.log); unlike the 64 + 64 kernel, whose fp16 form gains 8 % from the
+  //  third workgroup, a 256-sample ray's texel footprint makes 50 % more rays in flight cost more in the L2 than they hide)
+  const size_t sem_lds = (a->semantics ? (size_t)4 * a->n_attention * (wide ? kSemPitchWide : kSemPitch) * sizeof(float) : 0) +
+                         (a->normals ? (size_t)kNrmLdsFloats * sizeof(float) : 0);
+  constexpr size_t kSemLdsMax = ((size_t)4 * NFI_MAX_ATTENTION * kSemPitch + kNrmLdsFloats) * sizeof(float);
+  constexpr size_t kSemLdsMaxWide = ((size_t)4 * NFI_MAX_ATTENTION * kSemPitchWide + kNrmLdsFloats) * sizeof(float);
   if (a->event_start) (void)hipEventRecord((hipEvent_t)a->event_start, s);
 #define NFI_LAUNCH_RENDER(TEX, ATT)                                                                                   \
   do {                                                                                                                \
-    if (extra) {                                                                                                      \
+    if (a->normals) {                                                                                                 \
+      constexpr int TN = TEX == 1 ? 0 : TEX;       /* (bf16 is refused above) */                                       \
+      NFI_ENSURE_DYNAMIC_LDS((render_fwd_kernel<TN, ATT, NFI_RENDER_OCC, kRenderNormals, 1>), kSemLdsMax, "render");   \
+      hipLaunchKernelGGL((render_fwd_kernel<TN, ATT, NFI_RENDER_OCC, kRenderNormals, 1>), grid, dim3(256), sem_lds, s, k); \
+    } else if (extra) {                                                                                               \
       NFI_ENSURE_DYNAMIC_LDS((render_fwd_kernel<TEX, ATT, NFI_RENDER_OCC, kRenderExtra, 1>), kSemLdsMax, "render");    \
       hipLaunchKernelGGL((render_fwd_kernel<TEX, ATT, NFI_RENDER_OCC, kRenderExtra, 1>), grid, dim3(256), sem_lds, s, k); \
     } else if (term) hipLaunchKernelGGL((render_fwd_kernel<TEX, ATT, NFI_RENDER_OCC, kRenderTerm, 1>), grid, dim3(256), 0, s, k); \
@@ -2177,14 +2227,17 @@ extern "C" int nfi_render_fwd(const nfi_render_args* a, nfi_stream_t stream) {
   } while (0)
 #define NFI_LAUNCH_RENDER_WIDE(TEX, ATT)                                                                             \
   do {                                                                                                                \
-    if (extra) {                                                                                                      \
+    if (a->normals) {                                                                                                 \
+      constexpr int TN = TEX == 1 ? 0 : TEX;                                                                          \
+      NFI_ENSURE_DYNAMIC_LDS((render_fwd_wide_kernel<TN, ATT, kRenderNormals, 1>), kSemLdsMaxWide, "render");          \
+      hipLaunchKernelGGL((render_fwd_wide_kernel<TN, ATT, kRenderNormals, 1>), grid, dim3(256), sem_lds, s, k);        \
+    } else if (extra) {                                                                                               \
       NFI_ENSURE_DYNAMIC_LDS((render_fwd_wide_kernel<TEX, ATT, kRenderExtra, 1>), kSemLdsMaxWide, "render");           \
       hipLaunchKernelGGL((render_fwd_wide_kernel<TEX, ATT, kRenderExtra, 1>), grid, dim3(256), sem_lds, s, k);         \
     } else if (term) hipLaunchKernelGGL((render_fwd_wide_kernel<TEX, ATT, kRenderTerm, 1>), grid, dim3(256), 0, s, k);   \
     else if (any_tap && strict) hipLaunchKernelGGL((render_fwd_wide_kernel<TEX, ATT, kRenderTaps, 0>), grid, dim3(256), 0, s, k); \
     else if (any_tap) hipLaunchKernelGGL((render_fwd_wide_kernel<TEX, ATT, kRenderTaps, 1>), grid, dim3(256), 0, s, k);        \
     else if (strict) hipLaunchKernelGGL((render_fwd_wide_kernel<TEX, ATT, kRenderPlain, 0>), grid, dim3(256), 0, s, k);        \
-    else if (TEX == 2 && !wide_occ2) hipLaunchKernelGGL((render_fwd_wide_kernel<2, ATT, kRenderPlain, 1, false, 3>), grid3, dim3(256), 0, s, k); \
     else hipLaunchKernelGGL((render_fwd_wide_kernel<TEX, ATT, kRenderPlain, 1>), grid, dim3(256), 0, s, k);                    \
   } while (0)
 #define NFI_LAUNCH_RENDER_VD(TEX, ATT)                                                                                        \

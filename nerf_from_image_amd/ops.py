@@ -381,7 +381,7 @@ def render_fwd(cam2world, focal, height, width, num_samples, texels, decoder_ima
                noise_coarse=None, noise_fine=None, fine_sampling=True, white_background=True, taps=(),
                skip_missed_rays=True, workspace=None, events=None, tuning=0, profile_cycles=None, ray_features=None,
                termination_eps=0.0, row_window=None, clock_probe=None, stash=False, rays_ready=False,
-               want_semantics=False, want_coords=False):
+               want_semantics=False, want_coords=False, want_normals=False, strict=False):
     """Fused forward render.  Returns dict(rgb [B,H,W,3], depth, mask [B,H,W], + requested taps).
     row_window: None, or (row_offset, full_height): `height` rows starting at row_offset of an image full_height rows tall
     (bit-identical to those rows of the full render; noise / outputs / taps are sized for the window).
@@ -394,8 +394,11 @@ def render_fwd(cam2world, focal, height, width, num_samples, texels, decoder_ima
     termination_eps: 0 = off; eps in (0,1): fine samples behind the depth at which the COARSE transmittance has fallen
     below eps are not evaluated and the rest is compacted by wave ballot (the coarse pass, the pdf and every sample index
     are untouched; |d rgb| <= ~eps, see include/nfi_hip.h).
+    strict: raise when no ray of the batch meets the scene cube, as the reference does (lib/nerf_utils.py:258 fails on
+    min() of an empty selection); reads the hit counter of the ray set-up back = one host synchronisation.
     want_semantics / want_coords: also return 'semantics' [B,H,W,A] (composited softmax probabilities, run.py:312-335)
-    / 'coords' [B,H,W,3] (composited query points, run.py:337-338) from the SAME launch."""
+    / 'coords' [B,H,W,3] (composited query points, run.py:337-338) / 'normals' [B,H,W,3] (composited unit normals of the
+    SDF, + 1 - mask on a white background, lib/nerf_utils.py:149-151, 159; fp32 / fp16 texels) from the SAME launch."""
     cam2world = _f32c(cam2world, 'tform_cam2world')
     B = cam2world.shape[0]
     dev = cam2world.device
@@ -436,6 +439,10 @@ def render_fwd(cam2world, focal, height, width, num_samples, texels, decoder_ima
         tap_t['semantics'] = torch.empty((B, height, width, n_attention), dtype=torch.float32, device=dev)
     if want_coords:
         tap_t['coords'] = torch.empty((B, height, width, 3), dtype=torch.float32, device=dev)
+    if want_normals:
+        if not use_sdf:
+            raise ValueError('render_fwd: the normals map needs the SDF decoder (use_sdf)')
+        tap_t['normals'] = torch.empty((B, height, width, 3), dtype=torch.float32, device=dev)
     ws_bytes = lib.nfi_render_workspace_bytes(n)
     if rays_ready:
         # the kernel would march whatever the workspace holds: refuse anything that is not nfi_render_setup's own result
@@ -475,6 +482,9 @@ def render_fwd(cam2world, focal, height, width, num_samples, texels, decoder_ima
             full_height=0 if row_window is None else int(row_window[1]), rays_ready=int(bool(rays_ready)), **tap_t)
     out.update(tap_t)
     out['_workspace'] = workspace
+    if strict and int(workspace[8:12].view(torch.int32).item()) == 0:      # the hit count of the ray set-up (csrc: reduce[2])
+        raise RuntimeError('compute_near_far_planes: no ray intersects the scene cube '
+                           '(the reference fails on min() of an empty selection here)')
     return out
 
 

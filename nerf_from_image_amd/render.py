@@ -6,17 +6,18 @@
     render = nfi_render.render                           # replaces run.py's own def
 
 Three execution paths, all HIP through the C ABI:
-  * fused          - one persistent launch for the whole pipeline (no gradient); the composited `semantics` and `coords`
-                     maps (compute_semantics / compute_coords: run.py:1639-1646, 2036-2051) come out of the same launch;
+  * fused          - one persistent launch for the whole pipeline (no gradient); the composited `semantics`, `coords` and
+                     `normals` maps (compute_semantics / compute_coords / compute_normals: run.py:1250-1264, 1444-1454,
+                     1639-1646, 2036-2051) come out of the same launch;
   * fused + stash  - the SAME launch when a gradient is needed (training / inversion; with or without fine sampling, plain
                      or view-direction decoder): the kernel also
                      writes a per-sample stash (depths, sigma, rgb of the 2S samples of every ray, ray-major), and the
                      whole render is ONE autograd node whose backward is compositing backward on the stash -> one field
                      backward launch over the 2S points of every ray (+ its binned plane-gradient scatter) -> ray /
                      camera backward.  Replaces the ~20 launches of the staged graph;
-  * staged         - one launch per stage through ``nerf_utils`` and the ``sampler`` closure: the normals map, extra maps
-                     with a gradient / the view-direction decoder / the 'bbox' overlay, and a single pass of more than 128
-                     samples (run.py's inversion without --fine_sampling: 512).
+  * staged         - one launch per stage through ``nerf_utils`` and the ``sampler`` closure: extra maps with a gradient /
+                     the view-direction decoder / the 'bbox' overlay / bf16 texels (normals), and a single pass of more
+                     than 128 samples (run.py's inversion without --fine_sampling: 512).
 Randomness follows the reference, in its order: ``torch.rand`` of [B,H,W,S] for the stratified
 jitter (nerf_utils.py:115) BEFORE the model is called (its synthesis network draws noise of its own
 in training), then ``torch.rand`` of [B*H*W,S] for the inverse-CDF draws (nerf_utils.py:202), even
@@ -27,9 +28,10 @@ process-wide - the reference calls render from one thread per GPU):
   termination_eps   0 = off (default).  eps in (0,1): the fused inference kernel does not evaluate fine samples behind the
                     depth at which the COARSE transmittance has fallen below eps and compacts the rest by wave ballot
                     (coarse pass, pdf and sample indices untouched; |d rgb| <= ~eps; ops.render_fwd(termination_eps=...));
-  strict_near_far   True (default, the reference's behaviour): the staged path raises when no ray of the batch meets the
-                    scene cube (lib/nerf_utils.py:258 fails on min() of an empty selection) - one host synchronisation
-                    per call; a training loop that cannot see such a batch may clear it;
+  strict_near_far   True (default, the reference's behaviour): every path raises when no ray of the batch meets the scene
+                    cube (lib/nerf_utils.py:258 fails on min() of an empty selection) - one host synchronisation per
+                    call (the hit counter of the ray set-up is read back); a loop that cannot see such a batch may clear
+                    it and then gets the background image instead;
   row_window        None, or (row_offset, rows): render only these image rows (fused inference path; one image sharded
                     over the ranks of a node, parallel.shard_rows); the outputs then have `rows` rows;
   row_window_sync   False, or True / a process group: the ranks of the group render bands of the SAME image, and the
@@ -89,7 +91,8 @@ def _needs_grad(*tensors):
     return torch.is_grad_enabled() and any(t is not None and torch.is_tensor(t) and t.requires_grad for t in tensors)
 
 
-def _render_with_stash(fused, height, width, S, cam, focal, bbox, center, noise_c, noise_f, white, cam_grad, fine=True):
+def _render_with_stash(fused, height, width, S, cam, focal, bbox, center, noise_c, noise_f, white, cam_grad, fine=True,
+                       strict=False):
     """The fused render as ONE autograd node (see the module docstring).  Gradients follow the reference's graph:
     rgb_map / mask -> sigma, rgb of every sample and (through dists * ||rd||) the ray directions; depth_map and the
     depth samples carry none; the field -> planes, decoder, colour table, beta, alpha and - unless the camera is
@@ -109,7 +112,7 @@ def _render_with_stash(fused, height, width, S, cam, focal, bbox, center, noise_
         out = ops.render_fwd(a_cam, a_focal, height, width, S, texels, image, scene_range, A, att, use_sdf, be, al,
                              bbox=bbox, center=center, noise_coarse=noise_c, noise_fine=noise_f, fine_sampling=fine,
                              white_background=bool(white), skip_missed_rays=True, stash=True,
-                             ray_features=fused.ray_features)
+                             ray_features=fused.ray_features, strict=strict)
         keep.update({k: out[k] for k in ('stash_t', 'stash_sigma', 'stash_rgb', 'ray_origins', 'ray_directions')})
         return out['rgb'], out['depth'], out['mask']
 
@@ -190,9 +193,13 @@ def _render(cfg, dcfg, opts, target_model, height, width, tform_cam2world, focal
             return torch.rand([B * rows * width, S], dtype=torch.float32, device=dev)
         return None            # the kernels take linspace(0, 1, S) themselves (nerf_utils.py:196-200)
 
-    # semantics / coords are composited by the fused kernel itself; normals, the view-direction decoder and the 'bbox'
-    # overlay (which edits sigma, generator.py:645-659) keep the staged path
-    fused_maps = plain or (not compute_normals and ray_features is None and not getattr(fused, 'bbox_overlay', False))
+    # semantics / coords / normals are composited by the fused kernel itself; the view-direction decoder, the 'bbox'
+    # overlay (which edits sigma, generator.py:645-659) and normals on bf16 texels keep the staged path
+    fused_maps = plain or (ray_features is None and not getattr(fused, 'bbox_overlay', False) and
+                           not (compute_normals and fused is not None and fused.texels.dtype == torch.bfloat16))
+    if compute_normals and fused is not None:
+        # the sampler's own condition (generator.py:599-602; torch.is_grad_enabled() is autograd's business there)
+        assert fused.use_sdf and not getattr(target_model, 'training', False)
     if fused is not None and fused_maps and not cam_grad and not fused.requires_grad and S <= 128:
         # ---------------- fused inference path (the kernel generates the rays itself) ----------------
         window = None if opts.row_window is None else (int(opts.row_window[0]), height)
@@ -214,10 +221,10 @@ def _render(cfg, dcfg, opts, target_model, height, width, tform_cam2world, focal
             white_background=bool(white), skip_missed_rays=True, ray_features=ray_features,
             termination_eps=0.0 if extras else opts.termination_eps, row_window=window,
             want_semantics=compute_semantics and not compute_coords, want_coords=compute_coords,
-            workspace=ws, rays_ready=ws is not None)
+            want_normals=compute_normals, workspace=ws, rays_ready=ws is not None, strict=bool(opts.strict_near_far))
         # run.py:337-338: coords take the semantics slot of render_volume_density when both are asked for
         extra_map = out['coords'] if compute_coords else (out['semantics'] if compute_semantics else None)
-        return out['rgb'], out['depth'], out['mask'], None, extra_map, model_outputs
+        return out['rgb'], out['depth'], out['mask'], out.get('normals'), extra_map, model_outputs
     if opts.row_window is not None:
         raise NotImplementedError('row_window is an option of the fused inference path (no gradient, no extra maps)')
 
@@ -229,10 +236,10 @@ def _render(cfg, dcfg, opts, target_model, height, width, tform_cam2world, focal
         det = (lambda t: None if t is None else t.detach())
         rgb_map, depth_map, mask = _render_with_stash(
             fused, height, width, S, tform_cam2world, focal_length, det(bbox), det(center), noise_c, inverse_cdf_draws(),
-            white, cam_grad, fine=bool(cfg.fine_sampling))
+            white, cam_grad, fine=bool(cfg.fine_sampling), strict=bool(opts.strict_near_far))
         return rgb_map, depth_map, mask, None, None, model_outputs
 
-    # ---------------- staged path (normals, extra maps with a gradient, one pass of more than 128 samples) ----------------
+    # ---------------- staged path (extra maps with a gradient, one pass of more than 128 samples) ----------------
     ray_origins, ray_directions = rays if rays is not None else nerf_utils.get_ray_bundle_normalized(
         height, width, focal_length, tform_cam2world, bbox, center)
     with torch.no_grad():

@@ -55,8 +55,8 @@ def test_library_contains_gfx950_code_objects_only(lib):
 def test_struct_layout_matches_header():
     # spot checks: field order and the natural-alignment size ctypes derives from the parsed header
     f = [n for n, _ in _lib.STRUCT_FIELDS['nfi_render_args']]
-    assert f[:4] == ['n_scenes', 'height', 'width', 'n_samples'] and f[-12:] == ['profile_cycles', 'ray_features', 'termination_eps', 'texel_layout', 'clock_probe', 'row_offset', 'full_height',
-                                                                                          'stash_t', 'stash_sigma', 'stash_rgb', 'rays_ready', 'coords']
+    assert f[:4] == ['n_scenes', 'height', 'width', 'n_samples'] and f[-13:] == ['profile_cycles', 'ray_features', 'termination_eps', 'texel_layout', 'clock_probe', 'row_offset', 'full_height',
+                                                                                          'stash_t', 'stash_sigma', 'stash_rgb', 'rays_ready', 'coords', 'normals']
     assert ctypes.sizeof(_lib.STRUCTS['nfi_sample_pdf_args']) == 8 + 4 + 4 + 3 * 8 + 8 + 3 * 8
     for name, st in _lib.STRUCTS.items():
         assert ctypes.sizeof(st) % 8 == 0 or ctypes.sizeof(st) % 4 == 0, name

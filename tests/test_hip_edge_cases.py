@@ -103,6 +103,28 @@ def test_rejected_inputs(gpu_device):
         ops.planes_to_texels(torch.randn(1, 3, 32, 1, 1, device=dev))     # plane_res < 2
 
 
+def test_no_ray_meets_the_cube(gpu_device):
+    """A batch whose rays all miss the scene cube: the reference fails (min() of an empty selection,
+    lib/nerf_utils.py:258).  ops.render_fwd(strict=True) - what the drop-in render() passes by default
+    (strict_near_far) - raises like it; without strict the fused kernel returns the background image."""
+    d, g = scene(1, 10, 16, 11)
+    dev = gpu_device
+    texels = ops.planes_to_texels(d['planes'].to(dev))
+    image = ops.decoder_pack(d['w1'].to(dev), d['b1'].to(dev), d['w2'].to(dev), d['b2'].to(dev), 10)
+    cam = look_at_cameras(1, 1.8, g)
+    cam[:, :3, 3] += 10.0 * cam[:, :3, 0]            # ten units to the side, same viewing direction: every LINE misses the cube
+    cam, focal = cam.to(dev), torch.full((1,), 1.0, device=dev)
+    args = (texels, image, 0.55, 10, d['att'].to(dev), True, d['beta'].to(dev), d['alpha'].to(dev))
+    with pytest.raises(RuntimeError, match='no ray intersects the scene cube'):
+        ops.render_fwd(cam, focal, 8, 8, 16, *args, strict=True)
+    out = ops.render_fwd(cam, focal, 8, 8, 16, *args, strict=False, want_coords=True, want_semantics=True)
+    assert float(out['mask'].abs().max()) == 0.0 and float((out['rgb'] - 1.0).abs().max()) == 0.0
+    assert float(out['coords'].abs().max()) == 0.0 and float(out['semantics'].abs().max()) == 0.0
+    # and a batch with at least one hit does not raise
+    ok = ops.render_fwd(look_at_cameras(1, 1.8, g).to(dev), focal, 8, 8, 16, *args, strict=True)
+    assert float(ok['mask'].max()) > 0.0
+
+
 @pytest.mark.parametrize('H,W,S,B', [(16, 16, 8, 1), (16, 48, 16, 3), (32, 16, 65, 2), (64, 64, 128, 1), (48, 80, 20, 9)])
 def test_work_queues_cover_every_ray_exactly_once(gpu_device, H, W, S, B):
     """Per-XCD block queues with stealing (fewer blocks than XCDs, non-square images, the wide kernel, more scenes

@@ -282,6 +282,36 @@ def test_fused_render_extra_maps(case):
         if meta.get('coords'):
             close(r['coords'], o['semantics'], 1e-5, 'coords map (oracle render)')
             close(r['coords'], t['ref_coords_map'], 1e-5, 'coords map vs committed reference output')
+    if meta['sdf']:
+        # the normal map (compute_normals): the kernel's analytic d sdf / d x against autograd of the oracle's distance,
+        # composited with the oracle's weights (lib/nerf_utils.py:149-151, 159); unit vectors from fp32 texel differences
+        def oracle_normals(pts):
+            p = pts.clone().requires_grad_()
+            q = orc.field_query(t['planes'], t['w1'], t['b1'], t['w2'], t['b2'], p, meta['scene_range'], True, t['beta'],
+                                t['alpha'], t.get('attention_values'))
+            gx, = torch.autograd.grad(q['sdf'].sum(), p)
+            return torch.nn.functional.normalize(gx, dim=-1)
+        B, H, W = meta['B'], meta['H'], meta['W']
+        n_all = oracle_normals(orc.points_on_rays(o['ro'], o['rd'], o['t_coarse']).reshape(B, -1, 3)).view(B, H, W, -1, 3)
+        if meta['fine']:
+            n_f = oracle_normals(orc.points_on_rays(o['ro'], o['rd'], o['t_fine']).reshape(B, -1, 3)).view(B, H, W, -1, 3)
+            n_all = torch.cat((n_all, n_f), dim=-2).gather(-2, o['perm'].unsqueeze(-1).expand(-1, -1, -1, -1, 3))
+        ref_map = (o['weights'][..., None] * n_all).sum(dim=-2)
+        if meta['white']:
+            ref_map = ref_map + (1. - o['mask'][..., None])
+        rn = hip_render(meta, t, dev, skip_missed_rays=True, want_normals=True, want_semantics=want_sem, want_coords=True)
+        for k in ('rgb', 'depth', 'mask'):
+            exact(rn[k], plain[k], 'normal-map launch, %s' % k)
+        close(rn['normals'], ref_map, 3e-3, 'normal map')
+        if want_sem:
+            close(rn['semantics'], o['semantics'], 1e-5, 'semantic map next to the normals')
+        rn16 = hip_render(meta, t, dev, skip_missed_rays=True, texel_dtype=ops.TEXEL_F16, want_normals=True)
+        close(rn16['normals'], ref_map, 3e-2, 'normal map, fp16 planes')
+        with pytest.raises(RuntimeError):
+            hip_render(meta, t, dev, skip_missed_rays=True, texel_dtype=ops.TEXEL_BF16, want_normals=True)
+    else:
+        with pytest.raises((RuntimeError, ValueError)):
+            hip_render(meta, t, dev, skip_missed_rays=True, want_normals=True)       # normals need the SDF decoder
     # evaluating every ray instead of skipping the missed ones changes nothing (their weights are exactly 0)
     r0 = hip_render(meta, t, dev, skip_missed_rays=False, want_semantics=want_sem, want_coords=True)
     r1 = hip_render(meta, t, dev, skip_missed_rays=True, want_semantics=want_sem, want_coords=True)

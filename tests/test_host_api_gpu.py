@@ -322,9 +322,9 @@ def test_normals_sampler_and_render(setup):
     dcfg = {'scene_range': 0.55, 'white_background': True}
     render = nfi_render.make_render(cfg, dcfg)
     H, W, S = 16, 16, 32
-    with torch.no_grad(), RandTap() as tap:
+    with torch.no_grad(), RandTap() as tap, OneRenderLaunch() as one:
         rgb, depth, mask, normal_map, sem, _ = render(model, H, W, cam, focal, None, None, z, S, compute_normals=True)
-    assert sem is None and normal_map.shape == (2, H, W, 3)
+    assert one.calls == 1 and sem is None and normal_map.shape == (2, H, W, 3)
     o = oracle_for(model, z, cam, focal, H, W, S, cfg, dcfg, tap.draws)
     close(rgb, o['rgb'], 1e-4, 'rgb')
     n_c, _ = oracle_normals(orc.points_on_rays(o['ro'], o['rd'], o['t_coarse']).reshape(2, -1, 3))
@@ -333,6 +333,30 @@ def test_normals_sampler_and_render(setup):
     n_sorted = n_all.gather(-2, o['perm'].unsqueeze(-1).expand(-1, -1, -1, -1, 3))
     ref_map = (o['weights'][..., None] * n_sorted).sum(dim=-2) + (1. - o['mask'][..., None])
     close(normal_map, ref_map, 3e-3, 'normal map')
+    # the first eval batch asks for normals AND semantics (run.py:2036-2051): still one launch, same images
+    draws = iter(tap.draws)
+    real_rand = torch.rand
+    torch.rand = lambda *a, **k: next(draws).to(cam.device)
+    try:
+        with torch.no_grad(), OneRenderLaunch() as one:
+            rgb2, depth2, mask2, nmap2, sem2, _ = render(model, H, W, cam, focal, None, None, z, S, compute_normals=True,
+                                                         compute_semantics=True)
+    finally:
+        torch.rand = real_rand
+    assert one.calls == 1 and torch.equal(rgb2, rgb) and torch.equal(mask2, mask) and torch.equal(nmap2, normal_map)
+    close(sem2.sum(-1), mask2, 1e-5, 'semantic map sums to the mask')
+    # and the staged path (what a call with a gradient still takes) gives the same normal map
+    from nerf_from_image_amd import ops as _ops
+    real_fwd = _ops.render_fwd
+    draws = iter(tap.draws)
+    torch.rand = lambda *a, **k: next(draws).to(cam.device)
+    try:
+        zg = z.clone().requires_grad_()
+        _, _, _, nmap_staged, _, _ = render(model, H, W, cam, focal, None, None, zg, S, compute_normals=True)
+    finally:
+        torch.rand = real_rand
+        _ops.render_fwd = real_fwd
+    close(nmap_staged, normal_map, 2e-3, 'staged vs fused normal map')
 
 
 def test_parallel_model_dispatch(setup):
