@@ -277,7 +277,9 @@ def extras(dev, ops):
     maps = {}
     for name in ('b8_chairs_fp32_texels', 'b8_all_rays_hit_fp32_texels', 'b2_cfg5_256px_128+128_fp32_texels'):
         n_img, radius, tdt, kw = cases[name]
-        for label, mkw in (('coords', dict(want_coords=True)), ('semantics', dict(want_semantics=True))):
+        for label, mkw in (('coords', dict(want_coords=True)), ('semantics', dict(want_semantics=True)),
+                           ('normals', dict(want_normals=True)),
+                           ('normals+semantics', dict(want_normals=True, want_semantics=True))):   # the first eval batch, run.py:2036-2051
             r, out = time_render(ops, dev, n_img, radius, tdt, **mkw, **kw)
             r['x_plain_rate'] = r['rays_per_s'] / ex['render_only'][name]['rays_per_s']
             r['rgb_bit_identical_to_plain'] = bool(torch.equal(out['rgb'], exact_out[name]['rgb']))

@@ -306,7 +306,8 @@ def test_fused_render_extra_maps(case):
         if want_sem:
             close(rn['semantics'], o['semantics'], 1e-5, 'semantic map next to the normals')
         rn16 = hip_render(meta, t, dev, skip_missed_rays=True, texel_dtype=ops.TEXEL_F16, want_normals=True)
-        close(rn16['normals'], ref_map, 3e-2, 'normal map, fp16 planes')
+        e16 = err(rn16['normals'], ref_map)     # (the oracle has the unrounded planes: a unit vector from differences of
+        assert e16['nonfinite'] == 0 and e16['mean'] < 2e-3 and e16['max'] < 0.3, ('normal map, fp16 planes', e16)   # rounded texels)
         with pytest.raises(RuntimeError):
             hip_render(meta, t, dev, skip_missed_rays=True, texel_dtype=ops.TEXEL_BF16, want_normals=True)
     else:

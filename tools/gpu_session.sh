@@ -65,6 +65,8 @@ PY
       timeout 300 python tools/bench_regulariser.py > $O/bench_regulariser.log 2>&1; tail -2 $O/bench_regulariser.log;;
     train_bwd)
       timeout 300 python tools/bench_train_backward.py 30 > $O/bench_train_backward.log 2>&1; tail -2 $O/bench_train_backward.log;;
+    mall)
+      timeout 300 python tools/probes/mall_probe.py > $O/mall_probe.log 2>&1; cat $O/mall_probe.log;;
     stress)
       timeout 900 python tools/repro_stress.py > $O/repro_stress.log 2>&1; tail -12 $O/repro_stress.log;;
   esac
