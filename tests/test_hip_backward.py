@@ -374,13 +374,16 @@ def test_render_backward_end_to_end(gpu_device, fine, ortho, S):
         rel_close(a, b, 'grad ' + n, max(2e-3, 4 * noise))
 
 
-@pytest.mark.parametrize('P,res', [(5000, 24), (333, 9), (70000, 64), (40000, 256), (9000, 600), (3, 2), (20000, 17)])
+@pytest.mark.parametrize('P,res', [(5000, 24), (333, 9), (70000, 64), (40000, 256), (9000, 600), (3, 2), (20000, 17),
+                                   (1 << 20, 128),         # 128 MB of gradient rows per scene: two point groups, 8-texel tiles
+                                   (3 << 20, 256)])        # 384 MB: eight groups, 16-texel tiles (the training step's shape)
 def test_binned_scatter_matches_atomic_scatter(gpu_device, P, res):
     """scatter_mode 1 (two-level counting sort by plane tile and texel cell + register accumulation with carried
     corners) against scatter_mode 0 (atomics per point): identical gradients up to fp32 summation order; ragged P,
     points outside the cube, zero upstream gradients (skipped by the binning), empty cells, a crowd of a quarter of the
     points in a few cells (buckets split into several 4096-entry chunks), plane sides that are not multiples of the
-    16-texel tile, the 32-texel tiles of planes above 512^2 and the smallest plane."""
+    16-texel tile, the 32-texel tiles of planes above 512^2 and the smallest plane; scenes whose gradient rows exceed the
+    Infinity-Cache window and are cut into point groups (group-major bucket ids, work items handed out in order)."""
     from nerf_from_image_amd import field_backward as fb, ops as hops
     dev = gpu_device
     g = torch.Generator().manual_seed(500 + P)

@@ -13,7 +13,12 @@ sys.path.insert(0, ROOT)
 OUT = os.path.join(ROOT, 'build', 'variants')
 VARIANTS = {
     'base': [],
-    'split_mix': ['-DNFI_SPLIT_MIX=1'],
+    # round 4: point groups of the binned scatter (rows of a group <= N MB: 268 MB per scene in the training step -> 1 / 2 /
+    # 4 / 8 / 16 groups), 16- or 8-texel tiles for the grouped buckets.  The two macros existed in nfi_backward_field.inc
+    # for this measurement only (profiles/r4/scatter_point_groups.log); the product has the winner (80 MB, 16) hard-wired.
+    'group_off': ['-DNFI_BIN_GROUP_MB=100000'], 'group_160': ['-DNFI_BIN_GROUP_MB=160'], 'group_80': ['-DNFI_BIN_GROUP_MB=80'],
+    'group_40': ['-DNFI_BIN_GROUP_MB=40'], 'group_20': ['-DNFI_BIN_GROUP_MB=20'],
+    'group_80_tile8': ['-DNFI_BIN_GROUP_MB=80', '-DNFI_BIN_GROUP_TILE=8'], 'group_40_tile8': ['-DNFI_BIN_GROUP_MB=40', '-DNFI_BIN_GROUP_TILE=8'],
 }
 
 
