@@ -449,8 +449,8 @@ def main():
     ap.add_argument('--reduce-mode', choices=('all_reduce', 'reduce_scatter'), default='all_reduce')
     ap.add_argument('--no-overlap', action='store_true', help='train mode: launch the collectives after backward')
     ap.add_argument('--texels', choices=('fp32', 'fp16', 'bf16'), default='fp32',
-                    help='render mode: storage type of the texels the kernels gather from (arithmetic stays fp32); fp16 is '
-                         'the fast storage: packed texels, three workgroups per CU')
+                    help='storage type of the texels the kernels gather from (arithmetic stays fp32; train mode: so does the '
+                         'plane gradient); fp16 is the fast storage: packed texels, three workgroups per CU in the inference kernel')
     ap.add_argument('--pipelined', action='store_true',
                     help='render mode: `value` under the two-stream schedule (the next steps\' texel hand-off, decoder pack, '
                          'noise draws and ray set-up on a second HIP stream) instead of the serial one')
@@ -694,7 +694,7 @@ def train_mode(args, dev, rank, world, use_dist):
     import torch.distributed as dist
     B = args.images_per_gpu or 4
     r = train_bench.run(dev, steps=args.steps, warmup=args.warmup, batch=B, bucket_mb=args.bucket_mb,
-                        reduce_mode=args.reduce_mode, overlap=not args.no_overlap, use_dist=use_dist)
+                        reduce_mode=args.reduce_mode, overlap=not args.no_overlap, use_dist=use_dist, texels=args.texels)
     elapsed = r['elapsed_s']
     per_rank = [r]
     if use_dist:
@@ -719,7 +719,8 @@ def train_mode(args, dev, rank, world, use_dist):
                                          args.reduce_mode, r['n_buckets'], args.bucket_mb,
                                          'launched after backward' if args.no_overlap else
                                          'launched from post-accumulate hooks during backward'),
-                       'gradient_bytes_per_step': r['gradient_bytes']},
+                       'gradient_bytes_per_step': r['gradient_bytes'],
+                       'texel_storage': args.texels + (' (arithmetic and plane gradient fp32)' if args.texels != 'fp32' else '')},
             'per_rank': [{k: pr[k] for k in ('ms_per_step', 'fwd_bwd_ms', 'allreduce_exposed_ms', 'optimiser_ms',
                                              'allreduce_alone_ms', 'buckets_launched_in_backward', 'loss')}
                          for pr in per_rank],

@@ -341,6 +341,42 @@ def test_training_stash_and_row_windows(gpu_device):
         assert torch.equal(torch.cat([p[k] for p in parts], dim=1), plain[k]), k
 
 
+def test_row_bands_with_the_image_wide_miss_fill(gpu_device):
+    """Row-sharded render of ONE image with every ray marched (skip_missed_rays off): a missed ray's near / far is the
+    batch-wide fill of lib/nerf_utils.py:258-259, which a band computes over its own rays only - so the bands differ from
+    the full render unless the fill cells of the ray set-ups are combined over the bands first (max of the two keys, sum of
+    the hit count: what parallel.allreduce_ray_setup does across ranks, done by hand here for three bands on one GPU)."""
+    d = make_inputs(1, gpu_device, radius=2.0, seed=23)
+    texels = ops.planes_to_texels(d['planes'])
+    image = ops.decoder_pack(d['w1'], d['b1'], d['w2'], d['b2'], A)
+    args = (texels, image, 0.55, A, d['att'], True, d['beta'], d['alpha'])
+    full = ops.render_fwd(d['cam'], d['focal'], R, R, S, *args, noise_coarse=d['noise_c'], noise_fine=d['noise_f'],
+                          white_background=True, skip_missed_rays=False, taps=('near_plane', 'far_plane'))
+    bands = ((0, 24), (24, 88), (88, 128))
+
+    def band_kw(r0, r1):
+        return dict(noise_coarse=d['noise_c'][:, r0:r1].contiguous(),
+                    noise_fine=d['noise_f'].view(1, R, R, S)[:, r0:r1].reshape(-1, S).contiguous(), white_background=True,
+                    row_window=(r0, R), skip_missed_rays=False, taps=('near_plane', 'far_plane'))
+    ws = [ops.render_setup(d['cam'], d['focal'], r1 - r0, R, 0.55, row_window=(r0, R)) for r0, r1 in bands]
+    cells = torch.stack([w[:12].view(torch.int32).to(torch.int64) & 0xFFFFFFFF for w in ws])
+    assert len({int(c) for c in cells[:, 0]}) > 1 or len({int(c) for c in cells[:, 1]}) > 1, 'the bands should see different fills'
+    merged = torch.stack((cells[:, 0].max(), cells[:, 1].max(), cells[:, 2].sum()))
+    own, synced = [], []
+    for (r0, r1), w in zip(bands, ws):
+        own.append(ops.render_fwd(d['cam'], d['focal'], r1 - r0, R, S, *args, **band_kw(r0, r1)))
+        w[:12].view(torch.int32).copy_(torch.where(merged >= 2 ** 31, merged - 2 ** 32, merged).to(torch.int32))
+        synced.append(ops.render_fwd(d['cam'], d['focal'], r1 - r0, R, S, *args, workspace=w, rays_ready=True, **band_kw(r0, r1)))
+    for k in ('rgb', 'depth', 'mask', 'near_plane', 'far_plane'):
+        assert torch.equal(torch.cat([p[k] for p in synced], dim=1), full[k]), k
+    # With the bands' OWN fills the missed rays' planes - hence their depth samples - differ from the full render's; the
+    # images still agree, because a ray whose line misses the cube has every sample outside it (sigma = 0) whatever its
+    # depths are: the exception the header states is about samples, and about rays within rounding of a cube edge.
+    assert not torch.equal(torch.cat([p['far_plane'] for p in own], dim=1), full['far_plane'])
+    for k in ('rgb', 'mask'):
+        assert torch.equal(torch.cat([p[k] for p in own], dim=1), full[k]), k
+
+
 def test_render_with_separate_ray_setup(gpu_device):
     """nfi_render_setup + nfi_render_fwd(rays_ready=1) - the ray set-up of a batch done ahead of its render, on another
     stream in bench.py - gives the same pixels as the one-call render, also when the set-up ran on a second stream while

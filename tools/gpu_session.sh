@@ -27,9 +27,17 @@ for w in $WHAT; do
       timeout 1200 python tools/pmc_collect.py --kernel render_fwd_kernel --out $O/pmc_render_fwd.json --marched-from-bench -- \
         python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras --no-variants > $O/pmc.log 2>&1; echo "pmc rc=$?" >> $O/env.txt; tail -30 $O/pmc.log;;
     pmc_bwd)
-      # the field backward kernel inside the training step (4 images x 128x128 rays x 64 samples per launch: the coarse and the fine half are separate launches)
-      timeout 1200 python tools/pmc_collect.py --kernel field_query_bwd_kernel --out $O/pmc_backward.json --units 4194304 -- \
+      # the field backward kernel inside the training step (4 images x 128x128 rays x (64 + 64) samples: ONE launch since the one-node render)
+      timeout 1200 python tools/pmc_collect.py --kernel field_query_bwd_kernel --out $O/pmc_backward.json --units 8388608 -- \
         python $R/bench.py --mode train --steps 4 --warmup 2 > $O/pmc_bwd.log 2>&1; echo "pmc_bwd rc=$?" >> $O/env.txt; tail -30 $O/pmc_bwd.log;;
+    pmc_reduce)
+      # the scatter's reduce kernel inside the training step: 4 scenes x 8.4 M points x 3 planes = 25.2 M entries per launch
+      timeout 1200 python tools/pmc_collect.py --kernel bin_reduce_kernel --out $O/pmc_bin_reduce.json --units 25165824 -- \
+        python $R/bench.py --mode train --steps 4 --warmup 2 > $O/pmc_reduce.log 2>&1; echo "pmc_reduce rc=$?" >> $O/env.txt; tail -25 $O/pmc_reduce.log;;
+    train_fp16)
+      timeout 600 python bench.py --mode train --steps 30 --warmup 5 --texels fp16 > $O/train_fp16.json 2> $O/train_fp16.err; tail -c 700 $O/train_fp16.json
+      (cd /tmp && export TMPDIR=/tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_train_fp16 -o tr -- python $R/bench.py --mode train --steps 20 --warmup 5 --texels fp16 > $O/prof_train_fp16.log 2>&1)
+      python tools/kstats.py $O/prof_train_fp16 8;;
     bwd)
       timeout 600 python tools/bench_backward.py > $O/bench_backward.log 2>&1; tail -20 $O/bench_backward.log;;
     handoff)

@@ -121,7 +121,7 @@ class PlaneProducer(nn.Module):
 
 
 def run(dev, steps, warmup, batch=4, res=128, samples=64, bucket_mb=32, reduce_mode='all_reduce', overlap=True,
-        use_dist=False, seed=0):
+        use_dist=False, seed=0, texels='fp32'):
     """Returns a dict of timings (this rank) - the caller aggregates over ranks."""
     import types
     import torch.distributed as dist
@@ -132,7 +132,10 @@ def run(dev, steps, warmup, batch=4, res=128, samples=64, bucket_mb=32, reduce_m
     torch.manual_seed(seed)                                   # identical replicas on every rank
     scene_range = 2.0
     model = PlaneProducer(scene_range).to(dev).train()
-    nfi_gen.attach(model)
+    from nerf_from_image_amd import ops
+    # texel storage the kernels gather from (arithmetic and the plane gradient stay fp32; 16-bit storage: the gradient is
+    # taken w.r.t. the rounded planes, straight through)
+    nfi_gen.attach(model, texel_dtype={'fp32': ops.TEXEL_F32, 'fp16': ops.TEXEL_F16, 'bf16': ops.TEXEL_BF16}[texels])
     g = torch.Generator().manual_seed(1000 + rank)            # every rank its own images
     v = torch.randn(batch, 3, generator=g)
     eye = 3.0 * v / v.norm(dim=-1, keepdim=True)
