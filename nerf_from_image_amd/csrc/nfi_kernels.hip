@@ -153,7 +153,9 @@ __global__ __launch_bounds__(256) void decoder_pack_kernel(const float* __restri
                                                            int n_out, int tex, float* __restrict__ image) {
   const float gain1 = 0.17677669529663687f;  // 1/sqrt(32)  (models/stylegan.py:171)
   const float gain2 = 0.125f;                // 1/sqrt(64)
-  for (int i = threadIdx.x; i < kImageFloats; i += blockDim.x) {
+  // one element per thread over ceil(kImageFloats / 256) workgroups (one workgroup walking the image took 11 us: 25
+  // dependent round trips to the weights)
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < kImageFloats; i += gridDim.x * blockDim.x) {
     float v = 0.0f;
     if (i < kW2F) {
       int k = i - kW1F;
@@ -228,8 +230,8 @@ extern "C" int nfi_decoder_pack(const float* w1, const float* b1, const float* w
   REQUIRE(n_attention >= 0 && n_attention <= NFI_MAX_ATTENTION, "decoder_pack: attention_values must be in [0,14]");
   REQUIRE(texel_dtype >= NFI_TEXEL_F32 && texel_dtype <= NFI_TEXEL_F16, "decoder_pack: bad texel dtype");
   int n_out = n_attention > 0 ? 1 + n_attention : 4;
-  hipLaunchKernelGGL(decoder_pack_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, w1, b1, w2, b2, n_out, texel_dtype,
-                     image);
+  hipLaunchKernelGGL(decoder_pack_kernel, dim3((kImageFloats + 255) / 256), dim3(256), 0, (hipStream_t)stream, w1, b1, w2, b2,
+                     n_out, texel_dtype, image);
   return check_launch("decoder_pack");
 }
 
