@@ -313,6 +313,21 @@ def test_fused_render_extra_maps(case):
     else:
         with pytest.raises((RuntimeError, ValueError)):
             hip_render(meta, t, dev, skip_missed_rays=True, want_normals=True)       # normals need the SDF decoder
+    if meta['fine'] and meta['sdf'] and meta['A'] > 0:
+        # the same maps from a SINGLE pass (run.py without --fine_sampling): no merge, the weights are in source order already
+        m1 = dict(meta, fine=False)
+        o1 = oracle_render(dict(m1, coords=False), t, 'cpu')
+        r1p = hip_render(m1, t, dev, skip_missed_rays=True)
+        r1m = hip_render(m1, t, dev, skip_missed_rays=True, want_semantics=True, want_coords=True, want_normals=True)
+        for k in ('rgb', 'depth', 'mask'):
+            exact(r1m[k], r1p[k], 'single pass, extra-map launch, %s' % k)
+            close(r1m[k], o1[k], ATOL, 'single pass ' + k)
+        close(r1m['semantics'], o1['semantics'], 1e-5, 'single pass semantic map')
+        pts1 = o1['ro'].unsqueeze(-2) + o1['rd'].unsqueeze(-2) * o1['t_coarse'].unsqueeze(-1)
+        close(r1m['coords'], (o1['weights'].unsqueeze(-1) * pts1).sum(-2), 1e-5, 'single pass coords map')
+        n1 = oracle_normals(pts1.reshape(meta['B'], -1, 3)).view(*pts1.shape)
+        ref1 = (o1['weights'][..., None] * n1).sum(dim=-2) + ((1. - o1['mask'][..., None]) if meta['white'] else 0.)
+        close(r1m['normals'], ref1, 3e-3, 'single pass normal map')
     # evaluating every ray instead of skipping the missed ones changes nothing (their weights are exactly 0)
     r0 = hip_render(meta, t, dev, skip_missed_rays=False, want_semantics=want_sem, want_coords=True)
     r1 = hip_render(meta, t, dev, skip_missed_rays=True, want_semantics=want_sem, want_coords=True)
