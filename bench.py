@@ -412,7 +412,8 @@ def roofline(kernel_ms, marched, n_images, live_clock_hz=None, texels='fp32'):
                               'frac': any_cycles / peak_cycles, 'frac_in_profile_run': prof.get('issue_frac'),
                               'note': '4 x SQ_ACTIVE_INST_ANY: VALU + LDS + VMEM + SALU issue of the resident waves, which '
                                       'overlap - a utilisation proxy (passes 1 at three waves per SIMD), NOT a bound'},
-             waves_per_simd=prof.get('waves_per_simd'))
+             waves_per_simd=prof.get('waves_per_simd'),
+             mfma_busy_frac=prof.get('mfma_busy_frac'), wait_frac_of_wave_time=prof.get('wait_frac_of_wave_time'))
     return r
 
 

@@ -53,6 +53,25 @@ def test_render_shapes_and_limits(gpu_device, H, W, S, A, PR, B):
     for k in ('rgb', 'depth', 'mask'):
         e = err(r[k], o[k])
         assert e['max'] <= 1e-4 and e['nonfinite'] == 0, (k, e)
+    # the same shapes with the extra maps composited by the kernel (1 ... 14 attention values: the per-wave LDS table's
+    # size; 1x1 images; 65 and 127 samples: the two-slot kernel): same pixels, maps against the oracle
+    mv = lambda t: None if t is None else t.to(gpu_device)
+    texels = ops.planes_to_texels(d['planes'].to(gpu_device))
+    image = ops.decoder_pack(mv(d['w1']), mv(d['b1']), mv(d['w2']), mv(d['b2']), A)
+    m = ops.render_fwd(mv(cam), mv(focal), H, W, S, texels, image, 0.55, A, mv(d['att']), True, mv(d['beta']), mv(d['alpha']),
+                       noise_coarse=mv(noise_c), noise_fine=mv(noise_f), white_background=(S % 2 == 0), skip_missed_rays=True,
+                       want_semantics=A > 0, want_coords=True, want_normals=True)
+    for k in ('rgb', 'depth', 'mask'):
+        assert torch.equal(m[k], r[k]), k
+    with torch.no_grad():
+        o2 = orc.render(d['planes'], d['w1'], d['b1'], d['w2'], d['b2'], cam, focal, H, W, S, 0.55, white_background=(S % 2 == 0),
+                        noise_coarse=noise_c, noise_fine=noise_f, use_sdf=True, beta=d['beta'], alpha=d['alpha'],
+                        attention_values=d['att'], want_semantics=A > 0)
+    if A > 0:
+        assert err(m['semantics'], o2['semantics'])['max'] <= 1e-5
+    pts = o2['ro'].unsqueeze(-2) + o2['rd'].unsqueeze(-2) * o2['t_sorted'].unsqueeze(-1)
+    assert err(m['coords'], (o2['weights'].unsqueeze(-1) * pts).sum(-2))['max'] <= 1e-5
+    assert torch.isfinite(m['normals']).all() and float(m['normals'].abs().max()) <= 1.0 + 1e-4 + (1.0 if S % 2 == 0 else 0.0)
 
 
 def test_density_branch_coarse_only_odd_sizes(gpu_device):
