@@ -44,7 +44,8 @@ def build(names):
 
 
 def run(names, n='20'):
-    for name in names:
+    names = names or sorted(f[11:-3] for f in os.listdir(OUT) if f.startswith('libnfi_bwd_') and f.endswith('.so'))
+    for name in names * 2:                                   # two alternating rounds
         env = dict(os.environ, NFI_PROBE_LIBRARY=os.path.join(OUT, 'libnfi_bwd_%s.so' % name))
         r = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'bench_train_backward.py'), n], env=env,
                            capture_output=True, text=True)
@@ -52,5 +53,7 @@ def run(names, n='20'):
 
 
 if __name__ == '__main__':
-    names = sys.argv[2:] or list(VARIANTS)
-    (build if sys.argv[1] == 'build' else run)(names)
+    if sys.argv[1] == 'build':
+        build(sys.argv[2:] or list(VARIANTS))
+    else:
+        run(sys.argv[2:])            # no names: every library found under build/variants
