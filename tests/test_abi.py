@@ -52,6 +52,14 @@ def test_library_contains_gfx950_code_objects_only(lib):
     assert targets == {b'gfx950'}, targets
 
 
+def test_integration_md_stub_matches_the_header():
+    """The ctypes stub INTEGRATION.md shows a maintainer (section 2) lists nfi_field_args field for field."""
+    text = open(os.path.join(ROOT, 'INTEGRATION.md')).read()
+    block = text[text.index('class nfi_field_args'):text.index('def field_query')]
+    names = re.findall(r"\('(\w+)', ctypes\.", block)
+    assert names == [n for n, _ in _lib.STRUCT_FIELDS['nfi_field_args']], names
+
+
 def test_struct_layout_matches_header():
     # spot checks: field order and the natural-alignment size ctypes derives from the parsed header
     f = [n for n, _ in _lib.STRUCT_FIELDS['nfi_render_args']]
