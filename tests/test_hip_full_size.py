@@ -169,6 +169,45 @@ def test_render_is_bit_reproducible_over_many_launches(gpu_device, case, launche
     assert bad == 0, '%d elements in %d of %d launches differed from the majority result' % (bad, bad_launches, launches)
 
 
+@pytest.mark.parametrize('texels', ['fp32', 'fp16'])
+def test_extra_maps_at_full_size(gpu_device, texels):
+    """The composited semantics / coords / normals maps of the fused kernel at BASELINE size (4 x 128^2, 64+64, every
+    ray crossing the cube): rgb / depth / mask bit-identical to the plain launch; semantics and coords against the
+    oracle evaluated with PyTorch-ROCm ops on the same GPU (its own gap to the CPU oracle is ~1e-5, so 1e-4 here; the
+    golden cases hold 1e-5 against the CPU oracle); every map's structural identities; and - the kernels mix exact-fp32
+    MFMAs, K = 32 16-bit MFMAs and packed fp32 arithmetic - bit-reproducible over 300 launches."""
+    d = make_inputs(4, gpu_device, radius=1.3, seed=31)
+    tdt = ops.TEXEL_F32 if texels == 'fp32' else ops.TEXEL_F16
+    tex = ops.planes_to_texels(d['planes'], tdt)
+    image = ops.decoder_pack(d['w1'], d['b1'], d['w2'], d['b2'], A, tdt)
+
+    def run(**kw):
+        return ops.render_fwd(d['cam'], d['focal'], R, R, S, tex, image, 0.55, A, d['att'], True, d['beta'], d['alpha'],
+                              noise_coarse=d['noise_c'], noise_fine=d['noise_f'], white_background=True, **kw)
+    plain = run()
+    maps = run(want_semantics=True, want_coords=True, want_normals=True)
+    for k in ('rgb', 'depth', 'mask'):
+        assert torch.equal(maps[k], plain[k]), k
+    assert err(maps['semantics'].sum(-1), maps['mask'])['max'] <= 1e-5
+    assert torch.isfinite(maps['normals']).all() and float(maps['normals'].abs().max()) <= 2.0 + 1e-4
+    # |sum_k w_k n_k| <= mask: the normal map minus its white background is no longer than the mask
+    nm = maps['normals'] - (1.0 - maps['mask']).unsqueeze(-1)
+    assert float((nm.norm(dim=-1) - maps['mask']).max()) <= 1e-4
+    if texels == 'fp32':
+        c = {k: v for k, v in d.items()}
+        with torch.no_grad():
+            o = orc.render(c['planes'], c['w1'], c['b1'], c['w2'], c['b2'], c['cam'], c['focal'], R, R, S, 0.55,
+                           white_background=True, noise_coarse=c['noise_c'], noise_fine=c['noise_f'], use_sdf=True,
+                           beta=c['beta'], alpha=c['alpha'], attention_values=c['att'], want_semantics=True)
+            pts = o['ro'].unsqueeze(-2) + o['rd'].unsqueeze(-2) * o['t_sorted'].unsqueeze(-1)
+            coords_ref = (o['weights'].unsqueeze(-1) * pts).sum(-2)
+        assert err(maps['semantics'], o['semantics'])['max'] <= 1e-4
+        assert err(maps['coords'], coords_ref)['max'] <= 1e-4
+    bad, bad_launches = _count_differences(lambda: run(want_semantics=True, want_coords=True, want_normals=True), 300,
+                                           ('rgb', 'mask', 'semantics', 'coords', 'normals'))
+    assert bad == 0, '%d elements in %d of 300 launches differed from the majority result' % (bad, bad_launches)
+
+
 def test_field_and_regulariser_kernels_are_bit_reproducible(gpu_device):
     """The same for the stand-alone field query (exact-fp32 and split-fp16 decoder arithmetic) and the regulariser's
     distance + gradient operator."""
