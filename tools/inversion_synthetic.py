@@ -72,7 +72,9 @@ def run(dev, res=32, samples=32, batch=2, steps=10, plane_res=48, seed=0, verbos
     z_true = torch.randn(batch, 512, generator=g).to(dev)
     cfg = types.SimpleNamespace(use_viewdir=False, use_sdf=True, attention_values=10, fine_sampling=True)
     dcfg = {'scene_range': scene_range, 'white_background': False}
-    render = nfi_render.make_render(cfg, dcfg)
+    # strict_near_far off: no host synchronisation inside the step (every camera of this loop looks at the cube), as in
+    # tools/train_bench.py; the default (on) reads the hit counter back per render, like the reference's boolean-mask min()
+    render = nfi_render.make_render(cfg, dcfg, strict_near_far=False)
     with torch.no_grad():
         ws_true = model.mapping_network(z_true)
         # make the random scene opaque enough to have a silhouette: centre the distance output so that

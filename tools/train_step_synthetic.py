@@ -39,7 +39,8 @@ def run(dev, batch=4, res=128, samples=64, steps=10, plane_res=256, verbose=True
     target_rgb = (torch.rand(batch, res, res, 3, generator=g) * 2 - 1).to(dev)
     target_mask = (torch.rand(batch, res, res, generator=g) > 0.5).float().to(dev)
     cfg = types.SimpleNamespace(use_viewdir=False, use_sdf=True, attention_values=10, fine_sampling=True)
-    render = nfi_render.make_render(cfg, {'scene_range': scene_range, 'white_background': False})
+    render = nfi_render.make_render(cfg, {'scene_range': scene_range, 'white_background': False},
+                                    strict_near_far=False)      # no host synchronisation inside the step (tools/train_bench.py)
     reg_names = ['sdf_eikonal_loss', 'sdf_distance_loss']
 
     def hip_step():
