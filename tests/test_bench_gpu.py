@@ -30,6 +30,7 @@ def test_bench_single_process(gpu_device):
     assert j['n_gpus'] == 1 and j['steps'] == 3 and j['value'] > 1e6 and j['dtype'] == 'f32'
     assert 'split-fp16' in j['config']['mlp']
     assert j['ms_per_step_stats']['min'] <= j['ms_per_step_stats']['median'] <= j['ms_per_step_stats']['max']
+    assert j['prewarm']['untimed_steps'] >= 10          # steady-state allocator / shader clock before W + K (bench.py docstring)
     assert 'one stream' in j['schedule']                # `value` is what a caller of render() gets; the two-stream figure is a side field
     for k in ('value_serial', 'value_pipelined', 'value_mlp_exact_fp32', 'value_all_rays_hit'):
         assert j[k] > 1e6, k
