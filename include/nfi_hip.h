@@ -392,7 +392,9 @@ int nfi_sdf_gradient_bwd(const nfi_sdf_gradient_args* a, nfi_stream_t stream);
  * ------------------------------------------------------------------------------------------ */
 typedef struct nfi_render_args {
   int n_scenes, height, width;
-  int n_samples;                 /* S per pass, <= NFI_MAX_SAMPLES */
+  int n_samples;                 /* S per pass, <= NFI_MAX_SAMPLES; without fine_sampling a single pass of up to
+                                  * NFI_MAX_SAMPLES_SINGLE_PASS (run.py:2271), with stage taps / stash / viewdir but
+                                  * without the extra maps, the cycle profile and termination_eps */
   int fine_sampling;             /* args.fine_sampling (run.py:259) */
   int white_background;          /* dataset_config['white_background'] (run.py:348) */
   float scene_range;             /* dataset_config['scene_range'] (run.py:200) */

@@ -2041,6 +2041,135 @@ __global__ __launch_bounds__(256, OCC) void render_fwd_wide_kernel(RenderKernelP
 template __global__ void render_fwd_wide_kernel<NFI_SINGLE_KERNEL, true, NFI_SINGLE_MODE, 1, false, NFI_RENDER_OCC>(RenderKernelParams);
 #endif
 #ifndef NFI_SINGLE_KERNEL
+// One pass of 128 < S <= 512 samples without hierarchical resampling (run.py:2271: the inversion of a model trained
+// without --fine_sampling asks for depth_samples_per_ray * 4 = 512 samples in a single pass).  Same persistent
+// one-wave-per-ray scheme; the per-sample results go to this wave's LDS rows (element e = slot*64 + lane, already in
+// ascending depth order - render_volume_density does not sort) and are composited from there.  The stage taps and the
+// training stash are run-time switches here (a handful of wave-uniform branches per 64 samples).
+struct __attribute__((aligned(16))) WaveSlabLong {
+  float srt[5][NFI_MAX_SAMPLES_SINGLE_PASS];   // depth, sigma, r, g, b
+  float stage[16 * 36];                        // field_wave's feature-tile transpose
+};
+
+template <int TEX, bool ATT, int PREC, bool VD = false>
+__global__ __launch_bounds__(256, NFI_RENDER_OCC) void render_fwd_long_kernel(RenderKernelParams k) {
+  constexpr int kImg = VD ? kVdImageFloats : kLdsImageFloats;
+  constexpr int NS = NFI_MAX_SAMPLES_SINGLE_PASS / 64;
+  __shared__ __attribute__((aligned(16))) float lds[kImg];
+  __shared__ __attribute__((aligned(16))) float vfs[4][64];
+  __shared__ WaveSlabLong slabs[4];
+  ClockProbe clock;
+  clock.start(k);
+  if (PREC == 1) {
+    for (int i = threadIdx.x; i < kB1F; i += blockDim.x) lds[i] = k.image[kW1H + i];
+    for (int i = kB1F + threadIdx.x; i < kLdsImageFloats; i += blockDim.x) lds[i] = k.image[i];
+  } else {
+    for (int i = threadIdx.x; i < kImg; i += blockDim.x) lds[i] = k.image[i];
+  }
+  __syncthreads();
+  const int lane = lane_id();
+  const int wave = threadIdx.x >> 6;
+  WaveSlabLong& slab = slabs[wave];
+  float* vf = vfs[wave];
+  const int S = k.S;
+  const int slots = (S + 63) >> 6;
+  const float fill_near = ordered_key_inv(~k.reduce[0]), fill_far = ordered_key_inv(k.reduce[1]);
+  const float bg = k.white ? 1.0f : 0.0f;
+  const size_t tb = TEX == 0 ? 128 : 64;
+  const uint32_t n_rays = (uint32_t)k.n_scenes * (uint32_t)k.hw;
+  const uint32_t tiles_x = (uint32_t)k.width >> 3;
+  auto ray_of = [&](uint32_t pos) -> uint32_t {
+    if (k.xcd_blocks || !k.tile_order) return pos;
+    const uint32_t scene = pos / (uint32_t)k.hw, p = pos - scene * (uint32_t)k.hw;
+    const uint32_t tile = p >> 6, in = p & 63u;
+    const uint32_t ty = tile / tiles_x, tx = tile - ty * tiles_x;
+    return scene * (uint32_t)k.hw + ((ty << 3) + (in >> 3)) * (uint32_t)k.width + (tx << 3) + (in & 7u);
+  };
+  FieldParams P = make_field_params(k.texels, k.res, TEX, k.A, k.use_sdf, k.beta, k.alpha, lds, kImg, k.layout);
+  P.vf = vf;
+  int cur_scene = -1;
+  RayQueue queue(k, lane);
+  uint32_t cur = queue.fetch(), nxt = 0;
+  while (cur < n_rays) {
+    nxt = queue.fetch();
+    const uint32_t ray = ray_of(cur);
+    const uint32_t hitb = k.hit[ray];
+    const size_t ts = (size_t)ray * (size_t)k.tap_stride;
+    if (k.skip_missed && !(hitb & 2)) {
+      if (lane == 0) {
+        k.rgb[(size_t)ray * 3] = bg; k.rgb[(size_t)ray * 3 + 1] = bg; k.rgb[(size_t)ray * 3 + 2] = bg;
+        k.depth[ray] = 0.0f; k.mask[ray] = 0.0f;
+      }
+      if (k.stash) {
+        for (int e = lane; e < S; e += 64) {
+          k.t_coarse[ts + e] = 0.0f; k.sigma_coarse[ts + e] = 0.0f;
+          float* q = k.rgb_coarse + (ts + e) * 3; q[0] = 0.0f; q[1] = 0.0f; q[2] = 0.0f;
+        }
+      }
+    } else {
+      const int scene = (int)fastdiv(ray, k.div_hw);
+      if (scene != cur_scene) {
+        cur_scene = scene;
+        const char* tex_scene = reinterpret_cast<const char*>(k.texels) + (size_t)scene * 3 * k.res * k.res * tb;
+        P.rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(tex_scene), 0, (int)P.scene_bytes, 0x00020000);
+        wave_lds_fence();
+        {
+          int c = lane & 3, row = lane >> 2;
+          float v = 0.0f;
+          if (k.att && c < 3 && row >= 1 && row <= k.A) v = k.att[((size_t)scene * k.A + (row - 1)) * 3 + c];
+          vf[lane] = v;
+        }
+        wave_lds_fence();
+      }
+      const size_t r3 = (size_t)ray * 3;
+      const float ox = k.ro[r3], oy = k.ro[r3 + 1], oz = k.ro[r3 + 2];
+      const float dx = k.rd[r3], dy = k.rd[r3 + 1], dz = k.rd[r3 + 2];
+      float near = k.near_raw[ray], far = k.far_raw[ray];
+      finish_planes((hitb & 1) != 0, fill_near, fill_far, near, far);
+      const float dnorm = norm3(dx, dy, dz);
+      const size_t rs = (size_t)ray * S;
+#pragma unroll 1
+      for (int j = 0; j < slots; ++j) {
+        const int e = j * 64 + lane;
+        const bool val = e < S;
+        const float nz = (k.noise_c && val) ? k.noise_c[rs + e] : 0.0f;
+        const float t = val ? stratified_depth(near, far, e, S, nz, k.noise_c != nullptr) : 0.0f;
+        SampleOut q = field_wave<TEX, ATT, true, PREC, VD>(P, k.scene_range, lane, ox + dx * t, oy + dy * t, oz + dz * t, val,
+                                                           nullptr, nullptr, slab.stage, nullptr, k.xray, (int)ray);
+        if (val) {
+          slab.srt[0][e] = t; slab.srt[1][e] = q.sigma; slab.srt[2][e] = q.r; slab.srt[3][e] = q.g; slab.srt[4][e] = q.b;
+          if (k.t_coarse) k.t_coarse[ts + e] = t;
+          if (k.sigma_coarse) k.sigma_coarse[ts + e] = q.sigma;
+          if (k.rgb_coarse) { float* o3 = k.rgb_coarse + (ts + e) * 3; o3[0] = q.r; o3[1] = q.g; o3[2] = q.b; }
+        }
+      }
+      wave_lds_fence();
+      float w[NS];
+      CompositeOut o = composite_slab<NS>(slab, S, dnorm, k.white, lane, w);
+      if (lane == 0) {
+        k.rgb[(size_t)ray * 3] = o.r; k.rgb[(size_t)ray * 3 + 1] = o.g; k.rgb[(size_t)ray * 3 + 2] = o.b;
+        k.depth[ray] = o.depth; k.mask[ray] = o.mask;
+        if (k.near_plane) k.near_plane[ray] = near;
+        if (k.far_plane) k.far_plane[ray] = far;
+      }
+      if (k.weights || k.t_sorted || k.perm) {
+#pragma unroll
+        for (int j = 0; j < NS; ++j) {
+          const int e = j * 64 + lane;
+          if (e < S) {
+            if (k.weights) k.weights[rs + e] = w[j];
+            if (k.t_sorted) k.t_sorted[rs + e] = slab.srt[0][e];
+            if (k.perm) k.perm[rs + e] = e;
+          }
+        }
+      }
+      wave_lds_fence();  // the rows are reused by the next ray
+    }
+    cur = nxt;
+  }
+  clock.stop(k);
+}
+
 extern "C" size_t nfi_render_workspace_bytes(int64_t n_rays) {
   // ro, rd, near_raw, far_raw (fp32) + hit (u8, padded) + reduce[4]
   size_t n = (size_t)n_rays;
@@ -2092,8 +2221,11 @@ extern "C" int nfi_render_setup(const nfi_render_args* a, nfi_stream_t stream) {
 extern "C" int nfi_render_fwd(const nfi_render_args* a, nfi_stream_t stream) {
   REQUIRE(a && a->cam2world && a->rgb && a->depth && a->mask && a->workspace, "render: null pointer");
   REQUIRE(a->n_scenes > 0 && a->height > 0 && a->width > 0, "render: bad image shape");
-  REQUIRE(a->n_samples >= 4 && a->n_samples <= NFI_MAX_SAMPLES, "render: n_samples must be in [4,128] per pass");
+  REQUIRE(a->n_samples >= 4 && a->n_samples <= (a->fine_sampling ? NFI_MAX_SAMPLES : NFI_MAX_SAMPLES_SINGLE_PASS),
+          "render: n_samples must be in [4,128] per pass with fine sampling, [4,512] for a single pass");
   REQUIRE(a->n_samples <= 64 || !a->profile_cycles, "render: the cycle profile exists for n_samples <= 64 only");
+  REQUIRE(a->n_samples <= NFI_MAX_SAMPLES || !(a->semantics || a->coords || a->normals),
+          "render: semantics / coords / normals maps exist for n_samples <= 128");
   REQUIRE(!a->fine_sampling || a->noise_fine, "render: fine sampling needs u (noise_fine)");
   REQUIRE(!a->semantics || a->n_attention > 0, "render: composited semantics need attention values (A > 0)");
   int rc = check_field_common(a->texels, a->plane_res, a->texel_dtype, a->decoder_image, a->n_attention,
@@ -2201,6 +2333,7 @@ extern "C" int nfi_render_fwd(const nfi_render_args* a, nfi_stream_t stream) {
   bool att = a->n_attention > 0;
   // kRenderExtra with semantics: the per-wave tables [A][pitch] in dynamic LDS
   const bool wide = a->n_samples > 64;
+  const bool lng = a->n_samples > NFI_MAX_SAMPLES;     // single pass of up to 512 samples (no fine sampling: checked above)
   // (fp16 texels, 128 + 128, at THREE workgroups per CU - 168 registers, ~40 scratch reloads per ray outside the field
   //  tiles - was measured in round 4 and is slower: 1.387 vs 1.300 ms chairs-like, 2.249 vs 2.156 ms every ray hits, images
   //  identical (profiles/r4/wide_fp16_three_workgroups.log); unlike the 64 + 64 kernel, whose fp16 form gains 8 % from the
@@ -2247,7 +2380,21 @@ extern "C" int nfi_render_fwd(const nfi_render_args* a, nfi_stream_t stream) {
     if (wide) hipLaunchKernelGGL((render_fwd_wide_kernel<TEX, ATT, kRenderTaps, 0, true>), grid, dim3(256), 0, s, k);   \
     else hipLaunchKernelGGL((render_fwd_kernel<TEX, ATT, NFI_RENDER_OCC, kRenderTaps, 0, true>), grid, dim3(256), 0, s, k);                \
   } while (0)
-  if (a->ray_features) {
+#define NFI_LAUNCH_RENDER_LONG(TEX, ATT)                                                                              \
+  do {                                                                                                                \
+    if (a->ray_features) hipLaunchKernelGGL((render_fwd_long_kernel<TEX, ATT, 0, true>), grid, dim3(256), 0, s, k);    \
+    else if (strict) hipLaunchKernelGGL((render_fwd_long_kernel<TEX, ATT, 0>), grid, dim3(256), 0, s, k);              \
+    else hipLaunchKernelGGL((render_fwd_long_kernel<TEX, ATT, 1>), grid, dim3(256), 0, s, k);                          \
+  } while (0)
+  if (lng) {
+    if (a->texel_dtype == NFI_TEXEL_F32) {
+      if (att) NFI_LAUNCH_RENDER_LONG(0, true); else NFI_LAUNCH_RENDER_LONG(0, false);
+    } else if (a->texel_dtype == NFI_TEXEL_BF16) {
+      if (att) NFI_LAUNCH_RENDER_LONG(1, true); else NFI_LAUNCH_RENDER_LONG(1, false);
+    } else {
+      if (att) NFI_LAUNCH_RENDER_LONG(2, true); else NFI_LAUNCH_RENDER_LONG(2, false);
+    }
+  } else if (a->ray_features) {
     if (a->texel_dtype == NFI_TEXEL_F32) {
       if (att) NFI_LAUNCH_RENDER_VD(0, true); else NFI_LAUNCH_RENDER_VD(0, false);
     } else if (a->texel_dtype == NFI_TEXEL_BF16) {
@@ -2270,6 +2417,7 @@ extern "C" int nfi_render_fwd(const nfi_render_args* a, nfi_stream_t stream) {
   } else {
     if (att) NFI_LAUNCH_RENDER(2, true); else NFI_LAUNCH_RENDER(2, false);
   }
+#undef NFI_LAUNCH_RENDER_LONG
 #undef NFI_LAUNCH_RENDER_VD
 #undef NFI_LAUNCH_RENDER_WIDE
 #undef NFI_LAUNCH_RENDER

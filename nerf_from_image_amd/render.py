@@ -16,8 +16,10 @@ Three execution paths, all HIP through the C ABI:
                      backward launch over the 2S points of every ray (+ its binned plane-gradient scatter) -> ray /
                      camera backward.  Replaces the ~20 launches of the staged graph;
   * staged         - one launch per stage through ``nerf_utils`` and the ``sampler`` closure: extra maps with a gradient /
-                     the view-direction decoder / the 'bbox' overlay / bf16 texels (normals), and a single pass of more
-                     than 128 samples (run.py's inversion without --fine_sampling: 512).
+                     the view-direction decoder / the 'bbox' overlay / bf16 texels (normals), or over a single pass of
+                     more than 128 samples.
+A single pass of up to 512 samples (run.py's inversion without --fine_sampling: depth_samples_per_ray * 4, run.py:2271)
+takes the fused / fused + stash paths too (render_fwd_long_kernel).
 Randomness follows the reference, in its order: ``torch.rand`` of [B,H,W,S] for the stratified
 jitter (nerf_utils.py:115) BEFORE the model is called (its synthesis network draws noise of its own
 in training), then ``torch.rand`` of [B*H*W,S] for the inverse-CDF draws (nerf_utils.py:202), even
@@ -200,7 +202,8 @@ def _render(cfg, dcfg, opts, target_model, height, width, tform_cam2world, focal
     if compute_normals and fused is not None:
         # the sampler's own condition (generator.py:599-602; torch.is_grad_enabled() is autograd's business there)
         assert fused.use_sdf and not getattr(target_model, 'training', False)
-    if fused is not None and fused_maps and not cam_grad and not fused.requires_grad and S <= 128:
+    # (one pass of 129..512 samples - no fine sampling, checked above - has its own fused kernel: plain maps only)
+    if fused is not None and fused_maps and not cam_grad and not fused.requires_grad and (S <= 128 or plain):
         # ---------------- fused inference path (the kernel generates the rays itself) ----------------
         window = None if opts.row_window is None else (int(opts.row_window[0]), height)
         extras = not plain
@@ -228,7 +231,7 @@ def _render(cfg, dcfg, opts, target_model, height, width, tform_cam2world, focal
     if opts.row_window is not None:
         raise NotImplementedError('row_window is an option of the fused inference path (no gradient, no extra maps)')
 
-    if fused is not None and plain and S <= 128 and (ray_features is None or fused.texels.dtype == torch.float32):
+    if fused is not None and plain and (ray_features is None or fused.texels.dtype == torch.float32):
         # ---------------- fused render + stash as one differentiable node ----------------
         # (with or without fine sampling, plain or view-direction decoder; the view-direction rays of run.py:216-222 were
         #  computed above for the model - the kernel regenerates the same rays, and the camera gradient of the viewdirs
@@ -239,7 +242,7 @@ def _render(cfg, dcfg, opts, target_model, height, width, tform_cam2world, focal
             white, cam_grad, fine=bool(cfg.fine_sampling), strict=bool(opts.strict_near_far))
         return rgb_map, depth_map, mask, None, None, model_outputs
 
-    # ---------------- staged path (extra maps with a gradient, one pass of more than 128 samples) ----------------
+    # ---------------- staged path (extra maps with a gradient or over a pass of more than 128 samples) ----------------
     ray_origins, ray_directions = rays if rays is not None else nerf_utils.get_ray_bundle_normalized(
         height, width, focal_length, tform_cam2world, bbox, center)
     with torch.no_grad():

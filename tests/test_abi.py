@@ -75,10 +75,11 @@ def test_bad_arguments_are_rejected_before_any_launch(lib):
     assert rc == -1 and b'null' in lib.nfi_last_error()
     rc = lib.nfi_planes_to_texels(ctypes.c_void_p(16), ctypes.c_void_p(16), 1, 4096, 0, None)
     assert rc == -1 and b'plane_res' in lib.nfi_last_error()
-    a = _lib.make_args('nfi_render_args', n_scenes=1, height=4, width=4, n_samples=200, cam2world=16, rgb=16, depth=16,
-                       mask=16, workspace=16)
-    rc = lib.nfi_render_fwd(ctypes.byref(a), None)
-    assert rc == -1 and b'n_samples' in lib.nfi_last_error()
+    for S, fine in ((200, 1), (513, 0), (3, 0)):        # at most 128 per pass with fine sampling, 512 in a single pass
+        a = _lib.make_args('nfi_render_args', n_scenes=1, height=4, width=4, n_samples=S, fine_sampling=fine, cam2world=16,
+                           rgb=16, depth=16, mask=16, workspace=16)
+        rc = lib.nfi_render_fwd(ctypes.byref(a), None)
+        assert rc == -1 and b'n_samples' in lib.nfi_last_error()
     a = _lib.make_args('nfi_composite_args', n_rays=4, n_a=100, n_b=100, ray_directions=16, depth_a=16, sigma_a=16,
                        rgb_a=16, rgb_map=16, depth_map=16, mask=16)
     assert lib.nfi_composite_fwd(ctypes.byref(a), None) == -1

@@ -304,11 +304,9 @@ def test_field_query_backward_viewdir(gpu_device, A, use_sdf, N, S):
                                           (False, False, 128)])    # run.py without --fine_sampling: one pass of 128
 def test_render_backward_end_to_end(gpu_device, fine, ortho, S):
     """d(rgb, mask)/d(planes producer params, decoder, beta, alpha, attention values, camera, focal) through
-    nfi_render.render - up to 128 samples per pass, with or without fine sampling, the fused render + training stash as
-    ONE autograd node (asserted: one render launch, no stage kernel of the staged path); one pass of 512 samples (the
-    inversion loop without --fine_sampling, run.py:2271) the staged path - against autograd of the oracle with the same
-    noise."""
-    import contextlib
+    nfi_render.render - up to 128 samples per pass with fine sampling, up to 512 in a single pass (the inversion loop
+    without --fine_sampling, run.py:2271), the fused render + training stash as ONE autograd node (asserted: one render
+    launch, no stage kernel of the staged path) - against autograd of the oracle with the same noise."""
     from test_host_api_gpu import OneRenderLaunch, RandTap
     dev = gpu_device
     torch.manual_seed(7)
@@ -331,14 +329,14 @@ def test_render_backward_end_to_end(gpu_device, fine, ortho, S):
 
     cam = cam0.to(dev).requires_grad_()
     focal = None if ortho else focal0.to(dev).requires_grad_()
-    with RandTap() as tap, (OneRenderLaunch() if S <= 128 else contextlib.nullcontext()) as one:
+    with RandTap() as tap, OneRenderLaunch() as one:
         rgb, depth, mask, _, _, _ = render(model, H, W, cam, focal, None, None, z, S)
         loss = (rgb * w_rgb.to(dev)).sum() + (mask * w_mask.to(dev)).sum()
         params = [model.decoder.net[0].weight, model.decoder.net[0].bias, model.decoder.net[2].weight,
                   model.decoder.net[2].bias, model.beta, model.alpha, model.synthesis_network.basis,
                   model.texture_mapper.lin.weight, cam] + ([] if ortho else [focal])
         got = torch.autograd.grad(loss, params)
-    assert one is None or one.calls == 1
+    assert one.calls == 1
 
     # ---- oracle with identical noise: float64 (reference value) and float32 (the precision the
     # reference runs at; its distance to float64 calibrates how much rounding alone moves a gradient

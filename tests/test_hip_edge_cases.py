@@ -113,7 +113,12 @@ def test_rejected_inputs(gpu_device):
     with pytest.raises(RuntimeError):
         ops.render_fwd(cam, focal, 4, 4, 3, *args)            # fewer than 4 samples
     with pytest.raises(RuntimeError):
-        ops.render_fwd(cam, focal, 4, 4, 129, *args)          # more than 128 samples per pass
+        ops.render_fwd(cam, focal, 4, 4, 129, *args)          # more than 128 samples per pass with fine sampling
+    with pytest.raises(RuntimeError):
+        ops.render_fwd(cam, focal, 4, 4, 513, *args, fine_sampling=False)     # more than 512 in a single pass
+    with pytest.raises(RuntimeError):
+        ops.render_fwd(cam, focal, 4, 4, 129, *args, fine_sampling=False, want_semantics=True)   # extra maps: <= 128
+    assert ops.render_fwd(cam, focal, 4, 4, 129, *args, fine_sampling=False)['rgb'].isfinite().all()
     with pytest.raises((RuntimeError, TypeError, ValueError)):
         ops.render_fwd(cam.cpu(), focal.cpu(), 4, 4, 8, *args)   # CPU tensors: no CPU path
     with pytest.raises((RuntimeError, ValueError)):

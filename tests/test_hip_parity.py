@@ -215,7 +215,9 @@ def staged_render(meta, t, dev):
 
 
 def test_single_pass_beyond_128_samples(gpu_device):
-    """512 samples in one pass (run.py without --fine_sampling, inversion: ray_multiplier 4): stage kernels only."""
+    """512 samples in one pass (run.py without --fine_sampling, inversion: ray_multiplier 4, run.py:2271): the stage
+    kernels and the fused single-pass kernel (render_fwd_long_kernel), with its taps, the training stash and the
+    skipped rays."""
     meta, t = load_golden('persp_s512_coarse_only_rand')
     o = oracle_render(meta, t, 'cpu')
     r = staged_render(meta, t, gpu_device)
@@ -226,8 +228,32 @@ def test_single_pass_beyond_128_samples(gpu_device):
     for k in ('rgb', 'depth', 'mask'):
         close(r[k], o[k], 1e-5, k)
         close(r[k], t['ref_' + k], 1e-5, k + ' vs committed reference output')
+    f = hip_render(meta, t, gpu_device, taps=ops.TAP_NAMES)
+    exact(f['t_coarse'], o['t_coarse'], 'fused depths')
+    sigma_close(f['sigma_coarse'], o['sigma_coarse'], 'fused sigma')
+    close(f['weights'], o['weights'], 1e-6, 'fused weights')
+    exact(f['t_sorted'], f['t_coarse'], 'a single pass is composited in the order given')
+    for k in ('rgb', 'depth', 'mask'):
+        close(f[k], o[k], ATOL, 'fused ' + k)
+        close(f[k], t['ref_' + k], ATOL, 'fused %s vs committed reference output' % k)
+    # the plain launch (split-fp16 decoder arithmetic like every fused inference launch), rays that miss the cube skipped
+    p = hip_render(meta, t, gpu_device, skip_missed_rays=True)
+    for k in ('rgb', 'depth', 'mask'):
+        close(p[k], f[k], 1e-5, 'skip_missed_rays ' + k)
+    # the training stash is the tapped per-sample state, ray-major
+    st = hip_render(meta, t, gpu_device, stash=True, skip_missed_rays=True)
+    hit = (f['hit'] & 2).bool().to(gpu_device)
+    exact(st['stash_t'][hit], f['t_coarse'][hit], 'stash depths')
+    exact(st['stash_sigma'][hit], f['sigma_coarse'][hit], 'stash sigma')
+    exact(st['stash_rgb'][hit], f['rgb_coarse'][hit], 'stash rgb')
+    assert float(st['stash_sigma'][~hit].abs().sum()) == 0.0
+    exact(st['rgb'], p['rgb'], 'stash launch image')
+    # what stays out of the single-pass kernel is refused, not mis-rendered
     with pytest.raises(RuntimeError):
-        hip_render(meta, t, gpu_device)                  # the fused kernel holds at most 128 samples per pass
+        hip_render(meta, t, gpu_device, want_coords=True)
+    m2 = dict(meta, fine=True)
+    with pytest.raises(RuntimeError):
+        hip_render(m2, t, gpu_device)                    # with fine sampling a pass holds at most 128 samples
 
 
 def test_fused_render(case):

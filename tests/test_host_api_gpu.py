@@ -131,6 +131,33 @@ class OneRenderLaunch:
             setattr(self.ops, k, v)
 
 
+@pytest.mark.parametrize('S', [200, 512])
+def test_render_dropin_single_pass_beyond_128_samples(setup, S):
+    """One pass of more than 128 samples without fine sampling (run.py:2271: 512): ONE fused launch for the plain maps;
+    an extra map over such a pass keeps the staged path and agrees with it."""
+    model, cam, focal, z = setup
+    cfg = types.SimpleNamespace(use_viewdir=False, use_sdf=True, attention_values=10, fine_sampling=False)
+    dcfg = {'scene_range': 0.55, 'white_background': True}
+    render = nfi_render.make_render(cfg, dcfg)
+    H, W = 16, 24
+    with torch.no_grad(), RandTap() as tap, OneRenderLaunch() as one:
+        rgb, depth, mask, normals, sem, _ = render(model, H, W, cam, focal, None, None, z, S)
+    assert one.calls == 1 and normals is None and sem is None
+    assert tuple(tap.draws[0].shape) == (2, H, W, S) and len(tap.draws) == 1
+    o = oracle_for(model, z, cam, focal, H, W, S, cfg, dcfg, tap.draws)
+    close(rgb, o['rgb'], 1e-4, 'rgb'); close(depth, o['depth'], 1e-4, 'depth'); close(mask, o['mask'], 1e-4, 'mask')
+    with torch.no_grad():
+        torch.manual_seed(5)
+        a = render(model, H, W, cam, focal, None, None, z, S)
+        torch.manual_seed(5)
+        b = render(model, H, W, cam, focal, None, None, z, S, compute_coords=True)      # staged
+    assert b[4].shape == (2, H, W, 3)
+    close(a[0], b[0], 1e-5, 'fused vs staged rgb'); close(a[2], b[2], 1e-5, 'fused vs staged mask')
+    cfg_f = types.SimpleNamespace(use_viewdir=False, use_sdf=True, attention_values=10, fine_sampling=True)
+    with pytest.raises(NotImplementedError):
+        nfi_render.make_render(cfg_f, dcfg)(model, H, W, cam, focal, None, None, z, S)
+
+
 def test_render_dropin_fused_semantics(setup):
     """compute_semantics without a gradient (every inversion eval batch, run.py:2036-2051): one fused launch, the
     semantic map against the oracle, rgb / depth / mask identical to the call without it."""

@@ -52,7 +52,11 @@ def pose_matrix(cam0, delta):
     return M
 
 
-def run(dev, res=32, samples=32, batch=2, steps=10, plane_res=48, seed=0, verbose=False, teacher=False, hip_only=False):
+def run(dev, res=32, samples=32, batch=2, steps=10, plane_res=48, seed=0, verbose=False, teacher=False, hip_only=False,
+        fine=True, staged=False):
+    """fine=False: one pass of `samples` samples (run.py without --fine_sampling; the inversion loop then asks for
+    4 x 128 = 512, run.py:2271).  staged=True (A/B): the sampler closure is handed to render() without its `.fused`
+    handle, which sends the call down the stage-by-stage path (exact-fp32 decoder arithmetic there)."""
     from stand_in import StandInGenerator, look_at_cameras
     import nerf_from_image_amd.generator as nfi_gen
     import nerf_from_image_amd.render as nfi_render
@@ -70,8 +74,16 @@ def run(dev, res=32, samples=32, batch=2, steps=10, plane_res=48, seed=0, verbos
     cam_true = look_at_cameras(batch, 1.5, g).to(dev)
     focal = torch.full((batch,), 1.0254, device=dev)
     z_true = torch.randn(batch, 512, generator=g).to(dev)
-    cfg = types.SimpleNamespace(use_viewdir=False, use_sdf=True, attention_values=10, fine_sampling=True)
+    cfg = types.SimpleNamespace(use_viewdir=False, use_sdf=True, attention_values=10, fine_sampling=fine)
     dcfg = {'scene_range': scene_range, 'white_background': False}
+    assert fine or not teacher
+    target_model = model
+    if staged:
+        def target_model(viewdirs, model_input, request, extra_inputs={}):
+            out = model(viewdirs, model_input, request, extra_inputs)
+            closure = out['sampler']
+            out['sampler'] = lambda x, req=['sigma', 'rgb']: closure(x, req)
+            return out
     # strict_near_far off: no host synchronisation inside the step (every camera of this loop looks at the cube), as in
     # tools/train_bench.py; the default (on) reads the hit counter back per render, like the reference's boolean-mask min()
     render = nfi_render.make_render(cfg, dcfg, strict_near_far=False)
@@ -92,8 +104,9 @@ def run(dev, res=32, samples=32, batch=2, steps=10, plane_res=48, seed=0, verbos
         planes, att = model.planes_and_values(ws)
         dec = model.decoder.net
         o = orc.render(planes, dec[0].weight, dec[0].bias, dec[2].weight, dec[2].bias, cam, focal, res, res, samples,
-                       scene_range, white_background=False, fine_sampling=True, noise_coarse=draws[0],
-                       noise_fine=draws[1], use_sdf=True, beta=model.beta, alpha=model.alpha, attention_values=att)
+                       scene_range, white_background=False, fine_sampling=fine, noise_coarse=draws[0],
+                       noise_fine=draws[1] if fine else None, use_sdf=True, beta=model.beta, alpha=model.alpha,
+                       attention_values=att)
         return o['rgb'], o['mask']
 
     def evaluate(which, ws, delta, nc, nf):
@@ -103,7 +116,7 @@ def run(dev, res=32, samples=32, batch=2, steps=10, plane_res=48, seed=0, verbos
             real_rand = torch.rand
             torch.rand = lambda *a, **k: next(draws)          # inject the shared noise
             try:
-                rgb, _, mask, _, _, _ = render(model, res, res, cam, focal, None, None, ws, samples)
+                rgb, _, mask, _, _, _ = render(target_model, res, res, cam, focal, None, None, ws, samples)
             finally:
                 torch.rand = real_rand
         else:
@@ -151,7 +164,9 @@ def run(dev, res=32, samples=32, batch=2, steps=10, plane_res=48, seed=0, verbos
     shadow_hist = []
     h_hip, t_hip = optimise('hip')
     if hip_only:                                             # profiling: the HIP loop alone
-        print('render fwd+bwd per step (median): HIP %.2f ms' % (t_hip * 1e3))
+        print('render fwd+bwd per step (median): HIP %.2f ms  (B=%d, %dx%d, %s samples%s)' % (
+            t_hip * 1e3, batch, res, res, '%d+%d' % (samples, samples) if fine else '%d single-pass' % samples,
+            ', staged path' if staged else ''))
         return h_hip, None, t_hip, None
     h_ref, t_ref = optimise('oracle', shadow='hip' if teacher else None)
     if teacher:
@@ -200,5 +215,8 @@ if __name__ == '__main__':
     ap.add_argument('--steps', type=int, default=30)
     ap.add_argument('--plane-res', type=int, default=256)
     ap.add_argument('--hip-only', action='store_true')
+    ap.add_argument('--no-fine', action='store_true', help='one pass of --samples samples (run.py without --fine_sampling)')
+    ap.add_argument('--staged', action='store_true', help='A/B: force the stage-by-stage path')
     a = ap.parse_args()
-    run(torch.device('cuda:0'), a.res, a.samples, a.batch, a.steps, a.plane_res, verbose=True, hip_only=a.hip_only)
+    run(torch.device('cuda:0'), a.res, a.samples, a.batch, a.steps, a.plane_res, verbose=True, hip_only=a.hip_only,
+        fine=not a.no_fine, staged=a.staged)
