@@ -1556,16 +1556,13 @@ __global__ __launch_bounds__(256, OCC) void render_fwd_kernel(RenderKernelParams
   unsigned long long tk0 = PROF ? __builtin_readcyclecounter() : 0;
   if (cur < n_rays) load_inputs(ray_of(cur), in);
   while (cur < n_rays) {
-    fly = fetch();
     if (nxt < n_rays) load_inputs(ray_of(nxt), pre);
     const uint32_t ray = ray_of(cur);
     const uint32_t hitb = in.hit;
+    // the ray's five results: stored after the work fetch at the end of the iteration (see there)
+    float out_r = bg, out_g = bg, out_b = bg, out_d = 0.0f, out_m = 0.0f;
     if (k.skip_missed && !(hitb & 2)) {
       // the ray's line stays outside the (inflated) scene cube: every sample has sigma == 0
-      if (lane == 0) {
-        k.rgb[(size_t)ray * 3] = bg; k.rgb[(size_t)ray * 3 + 1] = bg; k.rgb[(size_t)ray * 3 + 2] = bg;
-        k.depth[ray] = 0.0f; k.mask[ray] = 0.0f;
-      }
       if constexpr (EXTRA) {
         if (k.coords && lane < 3) k.coords[(size_t)ray * 3 + lane] = 0.0f;
         if (k.semantics && lane < k.A) k.semantics[(size_t)ray * k.A + lane] = 0.0f;
@@ -1671,10 +1668,7 @@ __global__ __launch_bounds__(256, OCC) void render_fwd_kernel(RenderKernelParams
       }
       float w[2];
       CompositeOut o = composite_slab<2>(slab, n, dnorm, k.white, lane, w);
-      if (lane == 0) {
-        k.rgb[(size_t)ray * 3] = o.r; k.rgb[(size_t)ray * 3 + 1] = o.g; k.rgb[(size_t)ray * 3 + 2] = o.b;
-        k.depth[ray] = o.depth; k.mask[ray] = o.mask;
-      }
+      out_r = o.r; out_g = o.g; out_b = o.b; out_d = o.depth; out_m = o.mask;
       if constexpr (EXTRA) {
         if (k.coords) composite_coords<2>(slab, w, n, lane, ox, oy, oz, dx, dy, dz, k.coords + (size_t)ray * 3);
         float wc = 0.0f, wf = 0.0f;
@@ -1733,6 +1727,14 @@ __global__ __launch_bounds__(256, OCC) void render_fwd_kernel(RenderKernelParams
         unsigned long long t6 = __builtin_readcyclecounter();
         pc[4] += t1 - t0; pc[5] += t2 - t1; pc[6] += t3 - t2; pc[7] += t4 - t3; pc[8] += t5 - t4; pc[9] += t6 - t5; pc[10] += 1;
       }
+    }
+    // The work fetch waits for its atomic's round trip - and, vmcnt being ONE in-order counter of loads and stores, for
+    // every store the wave has in flight.  Here, after the ray's arithmetic and BEFORE its result stores, nothing of this
+    // ray is in flight any more (the taps / extra maps of those variants excepted): the wait is the atomic's alone.
+    fly = fetch();
+    if (lane == 0) {
+      k.rgb[(size_t)ray * 3] = out_r; k.rgb[(size_t)ray * 3 + 1] = out_g; k.rgb[(size_t)ray * 3 + 2] = out_b;
+      k.depth[ray] = out_d; k.mask[ray] = out_m;
     }
     in = pre;
     cur = nxt;
