@@ -1111,6 +1111,11 @@ __device__ __forceinline__ SampleOut field_wave(const FieldParams& P, float scen
     const int tb = pair ? __builtin_ctz(tm) : ta;
     tm &= tm - 1;                                 // (no-op when tm is already 0)
     float feat[2][8];
+    // the gather half of the loop body (address arithmetic, 24 loads per tile, interpolation) at raised issue priority,
+    // the MFMA half at the default: the waves of a SIMD then tend to take turns instead of both queueing for the
+    // same pipe (measured, images identical: fp16 texels 3 workgroups per CU -2 % chairs-like / -3 % every ray hits, fp32
+    // -0.2 .. -0.7 %; raising the MLP half instead: nothing)
+    __builtin_amdgcn_s_setprio(3);
     const int fa = gather_tile(ta, feat[0]);
     int fb = fa;
     if (pair) {
@@ -1120,6 +1125,7 @@ __device__ __forceinline__ SampleOut field_wave(const FieldParams& P, float scen
       for (int s8 = 0; s8 < 8; ++s8) feat[1][s8] = feat[0][s8];
     }
     unsigned long long c2 = prof ? __builtin_readcyclecounter() : 0;
+    __builtin_amdgcn_s_setprio(0);
     const float outs[2] = {(fa & 1) ? 1.0f : 0.0f, (fb & 1) ? 1.0f : 0.0f};
     // a point's semantics: row [A] of the global output, or its column of the wave's LDS table (SEMP > 0)
     const size_t sem_pt = SEMP > 0 ? (size_t)1 : (size_t)P.n_attention;
