@@ -1,7 +1,9 @@
 """A/B builds of the CURRENT tree's forward translation unit with extra compiler flags, timed on the render workloads.
 
     python tools/probes/ab_render.py build name=-DFLAG[,-DFLAG2] [name2=...]     # here: build/ab/libnfi_<name>.so
+    python tools/probes/ab_render.py build-bwd name=-DFLAG ...                   # the same for the backward unit
     python tools/probes/ab_render.py run [names]                                 # GPU box: ms per launch, checksums
+    python tools/probes/with_lib.py build/ab/libnfi_<name>.so tools/inversion_synthetic.py --hip-only    # any tool on a variant
 
 (round-3 variants built from knobs that have left the tree: tools/probes/render_variants.py)"""
 import os
@@ -13,18 +15,20 @@ sys.path.insert(0, ROOT)
 OUT = os.path.join(ROOT, 'build', 'ab')
 
 
-def build(specs):
+def build(specs, unit=0):
     import __graft_entry__ as entry
     from concurrent.futures import ThreadPoolExecutor
     os.makedirs(OUT, exist_ok=True)
-    bwd_obj = os.path.join(ROOT, 'build', 'nfi_backward_field.o')
+    units = [u for u, _ in entry.UNITS]
+    bwd_obj = os.path.join(ROOT, 'build', units[1 - unit].replace('.hip', '.o'))      # the OTHER unit, as built for the product
     assert os.path.exists(bwd_obj), 'run python __graft_entry__.py first'
-    src = os.path.join(entry.CSRC, 'nfi_kernels.hip')
+    src = os.path.join(entry.CSRC, units[unit])
+    unit_flags = entry.UNITS[unit][1]
 
     def one(spec):
         name, _, flags = spec.partition('=')
         obj = os.path.join(OUT, '%s.o' % name)
-        entry.compile_unit(src, [f for f in flags.split(',') if f], obj)
+        entry.compile_unit(src, unit_flags + [f for f in flags.split(',') if f], obj)
         subprocess.check_call([os.environ.get('HIPCC', '/opt/rocm/bin/hipcc'), '--offload-arch=gfx950', '-fPIC', '-shared', obj,
                                bwd_obj, '-o', os.path.join(OUT, 'libnfi_%s.so' % name)])
         os.remove(obj)
@@ -57,4 +61,7 @@ def run(names, iters=60):
 
 
 if __name__ == '__main__':
-    (build if sys.argv[1] == 'build' else run)(sys.argv[2:])
+    if sys.argv[1] == 'build-bwd':
+        build(sys.argv[2:], unit=1)
+    else:
+        (build if sys.argv[1] == 'build' else run)(sys.argv[2:])
