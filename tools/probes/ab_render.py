@@ -45,7 +45,8 @@ def run(names, iters=60):
     dev = torch.device('cuda:0')
     names = names or sorted(f[7:-3] for f in os.listdir(OUT) if f.startswith('libnfi_') and f.endswith('.so'))
     cases = {'chairs_b8': (8, bench.RADIUS, 0, {}), 'all_hit_b8': (8, 1.3, 0, {}), 'chairs_b1': (1, bench.RADIUS, 0, {}),
-             'cfg5_b2': (2, bench.RADIUS, 0, {'R': 256, 'S': 128}), 'chairs_b8_fp16': (8, bench.RADIUS, 2, {}),
+             'cfg5_b2': (2, bench.RADIUS, 0, {'R': 256, 'S': 128}), 'cfg5_b2_fp16': (2, bench.RADIUS, 2, {'R': 256, 'S': 128}),
+             'chairs_b8_fp16': (8, bench.RADIUS, 2, {}),
              'all_hit_b8_fp16': (8, 1.3, 2, {}), 'chairs_b8_exact': (8, bench.RADIUS, 0, {'tuning': 8})}
     for rep in range(2):                                   # two rounds: clock / thermal drift shows as a difference between them
         for name in names:
