@@ -502,8 +502,9 @@ int nfi_render_setup(const nfi_render_args* a, nfi_stream_t stream);
  * lib/pose_estimation.py:30-131 (compute_pose_pnp) that run.py:1709-1740 (estimate_poses_batch) makes for every
  * inversion batch.  Per image and focal proposal: Hartley-normalised DLT start, polar decomposition, Levenberg-Marquardt
  * on the reprojection error; per image the proposal with the smallest RMS reprojection error (OpenCV's definition,
- * sqrt(sum |r|^2 / 2N)) among the solutions with t_z > 0; images without a solution (or with fewer than 6 foreground
- * pixels; the reference: fewer than 4) get the reference's dummy pose (t = (0,0,-10), focal 1, error 10).
+ * sqrt(sum |r|^2 / 2N)) among the solutions with t_z > 0; images without a solution (or with fewer than 4 foreground
+ * pixels, as in the reference) get the reference's dummy pose (t = (0,0,-10), focal 1, error 10).  4 or 5 pixels,
+ * coplanar points and linear starts that end behind the camera: refinement from the 24 axis-aligned rotations instead.
  * PARITY UNPINNED: OpenCV is not available offline, no golden vectors exist (see csrc/nfi_pnp.inc).
  * ------------------------------------------------------------------------------------------ */
 typedef struct nfi_pnp_args {

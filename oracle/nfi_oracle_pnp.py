@@ -45,24 +45,72 @@ def dlt(P, xy, f):
     return U @ Vt, M[:, 3] / S.mean()
 
 
+def dlt_is_degenerate(P, xy, f):
+    """Coplanar (or otherwise degenerate) points: the constraint matrix has a null space of more than one dimension
+    (second-smallest singular value ~ 0) and the linear start is an arbitrary member of it."""
+    u = xy / f
+    c3, c2 = P.mean(0), u.mean(0)
+    s3 = np.sqrt(3) / np.linalg.norm(P - c3, axis=1).mean()
+    s2 = np.sqrt(2) / np.linalg.norm(u - c2, axis=1).mean()
+    Pn, un = (P - c3) * s3, (u - c2) * s2
+    ph = np.concatenate([Pn, np.ones((len(P), 1))], axis=1)
+    z = np.zeros_like(ph)
+    A = np.concatenate([np.concatenate([ph, z, -un[:, :1] * ph], axis=1), np.concatenate([z, ph, -un[:, 1:] * ph], axis=1)])
+    sv = np.linalg.svd(A, compute_uv=False)
+    return not (sv[-2] ** 2 > 1e-8 * sv[0] ** 2)
+
+
+def axis_aligned_rotations():
+    """The 24 rotations that map coordinate axes onto coordinate axes."""
+    out = []
+    for perm, parity in (((0, 1, 2), 1), ((1, 2, 0), 1), ((2, 0, 1), 1), ((0, 2, 1), -1), ((1, 0, 2), -1), ((2, 1, 0), -1)):
+        for s0 in (1, -1):
+            for s1 in (1, -1):
+                R = np.zeros((3, 3))
+                R[0, perm[0]], R[1, perm[1]], R[2, perm[2]] = s0, s1, parity * s0 * s1
+                out.append(R)
+    return out
+
+
 def solve_one(P, xy, f, refine=True):
-    """Returns (R, t, rmse) or None."""
-    if len(P) < 6:
+    """Returns (R, t, rmse) or None.  >= 6 points in general position: the linear start + refinement.  4 or 5 points
+    (pose_estimation.py:58 solves from 4 on), coplanar points, or a refinement that ends behind the camera (OpenCV falls
+    back to EPNP there): refinement from the 24 axis-aligned rotations at the weak-perspective depth, best valid result."""
+    if len(P) < 4:
         return None
-    R, t = dlt(P, xy, f)
-    if refine:
-        def res(p):
-            pr, z = project(Rotation.from_rotvec(p[:3]).as_matrix(), p[3:], f, P)
-            r = pr - xy
-            r[z <= 1e-9] = 1.0
-            return r.ravel()
-        sol = least_squares(res, np.concatenate([Rotation.from_matrix(R).as_rotvec(), t]), method='lm', xtol=1e-15, ftol=1e-15,
-                            gtol=1e-15, max_nfev=400)
-        R, t = Rotation.from_rotvec(sol.x[:3]).as_matrix(), sol.x[3:]
-    pr, z = project(R, t, f, P)
-    r = pr - xy
-    r[z <= 1e-9] = 1.0
-    return R, t, float(np.sqrt((r ** 2).sum() / (2 * len(P))))
+
+    def res(p):
+        pr, z = project(Rotation.from_rotvec(p[:3]).as_matrix(), p[3:], f, P)
+        r = pr - xy
+        r[z <= 1e-9] = 1.0
+        return r.ravel()
+
+    def polish(R, t, do=True):
+        if do and len(P) >= 3:
+            sol = least_squares(res, np.concatenate([Rotation.from_matrix(R).as_rotvec(), t]), method='lm' if 2 * len(P) >= 6 else 'trf',
+                                xtol=1e-15, ftol=1e-15, gtol=1e-15, max_nfev=400)
+            R, t = Rotation.from_rotvec(sol.x[:3]).as_matrix(), sol.x[3:]
+        pr, z = project(R, t, f, P)
+        r = pr - xy
+        r[z <= 1e-9] = 1.0
+        return R, t, float(np.sqrt((r ** 2).sum() / (2 * len(P))))
+
+    if len(P) >= 6 and not dlt_is_degenerate(P, xy, f):
+        R, t = dlt(P, xy, f)
+        if np.isfinite(R).all() and np.isfinite(t).all():
+            first = polish(R, t, refine)
+            if first[1][2] > 0 and np.isfinite(first[2]):
+                return first
+    u = xy / f
+    c3, c2 = P.mean(0), u.mean(0)
+    d0 = np.linalg.norm(P - c3, axis=1).mean() / np.sqrt(3) * np.sqrt(2) / max(np.linalg.norm(u - c2, axis=1).mean(), 1e-300)
+    best = None
+    for R0 in axis_aligned_rotations():
+        t0 = d0 * np.array([c2[0], c2[1], 1.0]) - R0 @ c3
+        cand = polish(R0, t0)
+        if cand[1][2] > 0 and np.isfinite(cand[2]) and (best is None or cand[2] < best[2]):
+            best = cand
+    return best
 
 
 def compute_pose_pnp(coords, masks, focal_proposals, refine=True):

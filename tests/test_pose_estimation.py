@@ -26,7 +26,7 @@ def test_oracle_recovers_known_poses_and_focal():
     for b in range(3):
         m = FLIP @ w2c[b]
         assert rot_angle_deg(m[:3, :3], Rs[b]) < 0.05 and np.abs(m[:3, 3] - ts[b]).max() < 1e-3
-    # fewer than 6 foreground pixels: the reference's dummy pose
+    # no foreground pixels (fewer than 4: pose_estimation.py:58): the reference's dummy pose
     masks[0] = False
     w2c, focal, err = orp.compute_pose_pnp(coords[:1], masks[:1], [1.2])
     assert np.allclose(w2c[0], FLIP @ np.array([[1, 0, 0, 0], [0, 1, 0, 0], [0, 0, 1, -10.0], [0, 0, 0, 1]])) and err[0] == 10.0
@@ -54,7 +54,7 @@ def test_hip_pose_matches_independent_solver_on_noisy_input(gpu_device):
     import nerf_from_image_amd.pose_estimation as pe
     coords, masks, Rs, ts = orp.synthetic_correspondences(3, 64, seed=2, noise=0.02, focal=1.0)
     masks[2] = False
-    masks[2, :2, :2] = True                                   # 4 foreground pixels: nothing to solve
+    masks[2, 0, :3] = True                                    # 3 foreground pixels: nothing to solve
     proposals = np.array([0.8, 1.0, 1.25])
     ref_w2c, ref_f, ref_e = orp.compute_pose_pnp(coords, masks, proposals)
     w2c, focal, err = pe.compute_pose_pnp(torch.from_numpy(coords).to(gpu_device), torch.from_numpy(masks).to(gpu_device), proposals)
@@ -62,6 +62,57 @@ def test_hip_pose_matches_independent_solver_on_noisy_input(gpu_device):
     assert np.allclose(err.cpu().numpy(), ref_e, rtol=1e-4, atol=1e-6), (err, ref_e)
     assert np.abs(w2c.cpu().double().numpy() - ref_w2c).max() < 2e-4
     assert float(err[2]) == 10.0 and float(focal[2]) == 1.0
+
+
+def few_point_case(n, seed, planar=False, res=16, focal=1.2):
+    """n pixels of a res x res image whose canonical coordinates are exact for a known pose; planar: the points lie in a
+    plane (the linear start of the solvers is degenerate there)."""
+    from scipy.spatial.transform import Rotation
+    rng = np.random.default_rng(seed)
+    R = Rotation.from_rotvec(rng.normal(size=3) * 0.9).as_matrix()
+    t = np.array([rng.normal() * 0.05, rng.normal() * 0.05, 2.5])
+    pix = rng.choice(res * res, size=n, replace=False)
+    xy = orp.screen_grid(res, res)[pix]
+    if planar:
+        nrm, c = np.array([0.3, -0.2, 1.0]), 2.5
+        z = c / (nrm[0] * xy[:, 0] / focal + nrm[1] * xy[:, 1] / focal + nrm[2])
+    else:
+        z = rng.uniform(2.0, 3.0, size=n)
+    P_cam = np.stack([xy[:, 0] * z / focal, xy[:, 1] * z / focal, z], axis=1)
+    coords = np.zeros((1, res * res, 3), np.float32)
+    coords[0, pix] = (P_cam - t) @ R                          # R^T (P_cam - t)
+    masks = np.zeros((1, res * res), bool)
+    masks[0, pix] = True
+    return coords.reshape(1, res, res, 3), masks.reshape(1, res, res), R, t
+
+
+def test_oracle_solves_few_and_coplanar_points():
+    """4 or 5 pixels (the reference solves from 4 on) and coplanar points (no linear start): the multi-start refinement."""
+    for n, planar, seed in ((5, False, 0), (5, False, 1), (12, True, 2), (40, True, 3)):
+        coords, masks, R, t = few_point_case(n, seed, planar)
+        w2c, focal, err = orp.compute_pose_pnp(coords, masks, [1.2])
+        m = FLIP @ w2c[0]
+        assert err[0] < 1e-5 and rot_angle_deg(m[:3, :3], R) < 0.1 and np.abs(m[:3, 3] - t).max() < 2e-3, (n, planar, err, m, R, t)
+    coords, masks, R, t = few_point_case(4, 5)
+    w2c, focal, err = orp.compute_pose_pnp(coords, masks, [1.2])
+    assert err[0] < 1e-5 and (FLIP @ w2c[0])[2, 3] > 0           # four points: A solution (there can be several)
+
+
+@pytest.mark.gpu
+def test_hip_solves_few_and_coplanar_points(gpu_device):
+    import nerf_from_image_amd.pose_estimation as pe
+    for n, planar, seed in ((5, False, 0), (5, False, 1), (12, True, 2), (40, True, 3), (6, False, 4)):
+        coords, masks, R, t = few_point_case(n, seed, planar)
+        w2c, focal, err = pe.compute_pose_pnp(torch.from_numpy(coords).to(gpu_device), torch.from_numpy(masks).to(gpu_device), [1.0, 1.2])
+        m = FLIP @ w2c[0].cpu().double().numpy()
+        assert float(err[0]) < 1e-4 and float(focal[0]) == pytest.approx(1.2), (n, planar, err, focal)
+        assert rot_angle_deg(m[:3, :3], R) < 0.5 and np.abs(m[:3, 3] - t).max() < 5e-3, (n, planar, m, R, t)
+    coords, masks, R, t = few_point_case(4, 5)
+    w2c, focal, err = pe.compute_pose_pnp(torch.from_numpy(coords).to(gpu_device), torch.from_numpy(masks).to(gpu_device), [1.2])
+    assert float(err[0]) < 1e-4 and float((FLIP @ w2c[0].cpu().double().numpy())[2, 3]) > 0
+    coords, masks, R, t = few_point_case(3, 6)
+    w2c, focal, err = pe.compute_pose_pnp(torch.from_numpy(coords).to(gpu_device), torch.from_numpy(masks).to(gpu_device), [1.2])
+    assert float(err[0]) == 10.0                               # three points: the dummy pose, like the reference
 
 
 @pytest.mark.gpu
