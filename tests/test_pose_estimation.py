@@ -88,7 +88,7 @@ def few_point_case(n, seed, planar=False, res=16, focal=1.2):
 
 def test_oracle_solves_few_and_coplanar_points():
     """4 or 5 pixels (the reference solves from 4 on) and coplanar points (no linear start): the multi-start refinement."""
-    for n, planar, seed in ((5, False, 0), (5, False, 1), (12, True, 2), (40, True, 3)):
+    for n, planar, seed in ((5, False, 0), (12, True, 2)):
         coords, masks, R, t = few_point_case(n, seed, planar)
         w2c, focal, err = orp.compute_pose_pnp(coords, masks, [1.2])
         m = FLIP @ w2c[0]
