@@ -83,6 +83,9 @@ def load():
         raise RuntimeError(
             'libnfi_hip.so not found at %s: build it with `python -c "import __graft_entry__ as g; g.build()"` '
             '(there is no CPU fallback for the HIP path)' % LIBRARY)
+    # torch first: its wheel carries its own HIP runtime (libamdhip64), and a process must end up with ONE - loaded the other
+    # way round (this library and /opt/rocm's runtime, then torch's) the launches here fail with 'no ROCm-capable device'
+    import torch  # noqa: F401
     lib = ctypes.CDLL(LIBRARY)
     for fname, (ret, args) in FUNCTIONS.items():
         fn = getattr(lib, fname)  # AttributeError here = header/library mismatch
