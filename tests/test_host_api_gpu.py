@@ -417,9 +417,10 @@ def _viewdir_oracle(model, z, cam, focal, H, W, S, draws, white, double=False):
     mapper = model.viewdir_mapper if double else copy.deepcopy(model.viewdir_mapper).cpu()
     x = mapper(rd.unsqueeze(-2)).reshape(cam.shape[0], H * W, 32)
     return orc.render(conv(planes), conv(dec[0].weight), conv(dec[0].bias), conv(dec[2].weight), conv(dec[2].bias),
-                      conv(cam), conv(focal), H, W, S, 0.55, white_background=white, fine_sampling=True,
+                      conv(cam), conv(focal), H, W, S, 0.55, white_background=white, fine_sampling=len(draws) > 1,
                       noise_coarse=draws[0] if not double else draws[0].double(),
-                      noise_fine=draws[1] if not double else draws[1].double(), use_sdf=True, beta=conv(model.beta),
+                      noise_fine=None if len(draws) < 2 else (draws[1] if not double else draws[1].double()), use_sdf=True,
+                      beta=conv(model.beta),
                       alpha=conv(model.alpha), attention_values=conv(att),
                       viewdir=dict(x=x, w3=conv(mapper.output.weight), b3=conv(mapper.output.bias)))
 
@@ -467,6 +468,55 @@ def test_render_with_view_directions(gpu_device):
         o = _viewdir_oracle(model, z, cam, focal, H, W, S, tap.draws, False)
     close(rgb, o['rgb'], 1e-4, 'fused rgb'); close(mask, o['mask'], 1e-4, 'fused mask'); close(depth, o['depth'], 1e-4, 'depth')
     assert o['mask'].mean() > 0.05
+
+
+def test_single_pass_kernel_other_instantiations(setup, gpu_device):
+    """render_fwd_long_kernel (one pass of 129..512 samples) with 16-bit texel storage - against the stage kernels on the
+    SAME storage (an extra map over such a pass keeps the staged path) - and with the view-direction decoder, inference
+    and gradient, against the oracle."""
+    import copy
+    from nerf_from_image_amd import ops
+    model, cam, focal, z = setup
+    cfg = types.SimpleNamespace(use_viewdir=False, use_sdf=True, attention_values=10, fine_sampling=False)
+    dcfg = {'scene_range': 0.55, 'white_background': True}
+    H, W, S = 12, 16, 200
+    for tdt in (ops.TEXEL_F16, ops.TEXEL_BF16):
+        m2 = nfi_gen.attach(copy.deepcopy(model), texel_dtype=tdt)
+        render = nfi_render.make_render(cfg, dcfg)
+        with torch.no_grad():
+            torch.manual_seed(3)
+            with OneRenderLaunch() as one:
+                a = render(m2, H, W, cam, focal, None, None, z, S)
+            assert one.calls == 1
+            torch.manual_seed(3)
+            b = render(m2, H, W, cam, focal, None, None, z, S, compute_coords=True)       # staged
+        close(a[0], b[0], 2e-5, 'rgb, 16-bit texels'); close(a[1], b[1], 2e-5, 'depth'); close(a[2], b[2], 2e-5, 'mask')
+    # view-direction decoder
+    torch.manual_seed(78)
+    vd = StandInGenerator(0.55, attention_values=10, use_sdf=True, plane_res=48, use_viewdir=True).to(gpu_device).eval()
+    nfi_gen.attach(vd)
+    cfg_v = types.SimpleNamespace(use_viewdir=True, use_sdf=True, attention_values=10, fine_sampling=False)
+    render = nfi_render.make_render(cfg_v, {'scene_range': 0.55, 'white_background': False})
+    S = 160
+    with torch.no_grad(), RandTap() as tap, OneRenderLaunch() as one:
+        rgb, depth, mask, _, _, _ = render(vd, H, W, cam, focal, None, None, z, S)
+    assert one.calls == 1 and len(tap.draws) == 1
+    with torch.no_grad():
+        o = _viewdir_oracle(vd, z, cam, focal, H, W, S, tap.draws, False)
+    close(rgb, o['rgb'], 1e-4, 'viewdir rgb'); close(mask, o['mask'], 1e-4, 'viewdir mask'); close(depth, o['depth'], 1e-4, 'depth')
+    w_rgb = torch.randn(2, H, W, 3, device=gpu_device)
+    params = [vd.viewdir_mapper.output.weight, vd.decoder.net[2].weight]
+    with RandTap() as tap, OneRenderLaunch() as one:
+        rgb2, _, mask2, _, _, _ = render(vd, H, W, cam, focal, None, None, z, S)
+        got = torch.autograd.grad((rgb2 * w_rgb).sum() + mask2.sum(), params)
+    assert one.calls == 1
+    m64 = copy.deepcopy(vd).cpu().double()
+    o2 = _viewdir_oracle(m64, z.cpu().double(), cam.cpu().double(), focal, H, W, S, tap.draws, False, double=True)
+    ref = torch.autograd.grad((o2['rgb'] * w_rgb.cpu().double()).sum() + o2['mask'].sum(),
+                              [m64.viewdir_mapper.output.weight, m64.decoder.net[2].weight])
+    for name, a_, b_ in zip(['output.weight', 'decoder w2'], got, ref):
+        scale = b_.abs().max().item()
+        assert (a_.cpu().double() - b_).abs().max().item() <= 2e-3 * scale, (name, (a_.cpu().double() - b_).abs().max().item(), scale)
 
 
 def test_bbox_overlay(setup):
