@@ -30,6 +30,7 @@ process-wide - the reference calls render from one thread per GPU):
   termination_eps   0 = off (default).  eps in (0,1): the fused inference kernel does not evaluate fine samples behind the
                     depth at which the COARSE transmittance has fallen below eps and compacts the rest by wave ballot
                     (coarse pass, pdf and sample indices untouched; |d rgb| <= ~eps; ops.render_fwd(termination_eps=...));
+                    without fine sampling, and for calls that ask for extra maps, it has nothing to act on and is ignored;
   strict_near_far   True (default, the reference's behaviour): every path raises when no ray of the batch meets the scene
                     cube (lib/nerf_utils.py:258 fails on min() of an empty selection) - one host synchronisation per
                     call (the hit counter of the ray set-up is read back); a loop that cannot see such a batch may clear
@@ -222,7 +223,7 @@ def _render(cfg, dcfg, opts, target_model, height, width, tform_cam2world, focal
             bbox=None if bbox is None else bbox.detach(), center=None if center is None else center.detach(),
             noise_coarse=noise_c, noise_fine=inverse_cdf_draws(), fine_sampling=bool(cfg.fine_sampling),
             white_background=bool(white), skip_missed_rays=True, ray_features=ray_features,
-            termination_eps=0.0 if extras else opts.termination_eps, row_window=window,
+            termination_eps=opts.termination_eps if (cfg.fine_sampling and not extras) else 0.0, row_window=window,
             want_semantics=compute_semantics and not compute_coords, want_coords=compute_coords,
             want_normals=compute_normals, workspace=ws, rays_ready=ws is not None, strict=bool(opts.strict_near_far))
         # run.py:337-338: coords take the semantics slot of render_volume_density when both are asked for
