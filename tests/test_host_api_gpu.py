@@ -156,6 +156,11 @@ def test_render_dropin_single_pass_beyond_128_samples(setup, S):
     cfg_f = types.SimpleNamespace(use_viewdir=False, use_sdf=True, attention_values=10, fine_sampling=True)
     with pytest.raises(NotImplementedError):
         nfi_render.make_render(cfg_f, dcfg)(model, H, W, cam, focal, None, None, z, S)
+    # termination_eps acts on the fine pass: a configuration without one ignores it
+    with torch.no_grad():
+        torch.manual_seed(5)
+        c = nfi_render.make_render(cfg, dcfg, termination_eps=1e-5)(model, H, W, cam, focal, None, None, z, S)
+    assert torch.equal(c[0], a[0]) and torch.equal(c[2], a[2])
 
 
 def test_render_dropin_fused_semantics(setup):
