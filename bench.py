@@ -21,9 +21,12 @@ the driver's `--steps 20 --warmup 5` - reads the same rate as a long one (141 M 
 `prewarm`.
 
 Printed JSON (rank 0, one line) carries, besides the contract fields:
-  value_mlp_exact_fp32 / value_all_rays_hit / value_pipelined - the same whole step, same K, same protocol, with the
-                      decoder MLP on exact-fp32 MFMA (tuning bit 3) / with cameras at radius 1.3 (every ray crosses the
-                      scene cube, nothing is skipped) / under the two-stream schedule;
+  config.value_mlp_exact_fp32 / .value_all_rays_hit / .value_pipelined - the same whole step, same K, same protocol, with
+                      the decoder MLP on exact-fp32 MFMA (tuning bit 3) / with cameras at radius 1.3 (every ray crosses
+                      the scene cube, nothing is skipped) / under the two-stream schedule (scalars inside `config`, where
+                      the driver's parser keeps them);
+  config.x_pytorch_rocm_reference - `value` over the reference renderer's rays/s on this very GPU (run.py::render + the
+                      real Generator sampler under PyTorch-ROCm, best of B = 1 / 4 / 8; extras.pytorch_rocm_reference_path);
   ms_per_step_stats - min / median / max over the K timed steps (HIP events per step);
   roofline          - the fused render kernel against SURVEY.md 8(d)'s arithmetic: achieved = algorithmic decoder FLOPs
                       (704 512 per marched ray x rays marched per launch) / kernel duration (live HIP events on the launch
@@ -31,7 +34,8 @@ Printed JSON (rank 0, one line) carries, besides the contract fields:
                       (FETCH_SIZE x2 + WRITE_SIZE from the committed rocprofv3 PMC profile named in `source`, scaled by
                       the live ray count).  The pipe that binds by the counters is the vector ALU: `valu_pipe.frac`
                       = 4 x SQ_ACTIVE_INST_VALU per marched ray x rays / kernel time / (1024 SIMDs x the shader clock
-                      measured in the timed launches).  `any_issue_proxy` (SQ_ACTIVE_INST_ANY: VALU + LDS + VMEM + SALU
+                      measured in the timed launches), also as the scalar `valu_frac`; `bound` is 'valu' (the MFMA pipe is
+                      busy 9 % of the time).  `any_issue_proxy` (SQ_ACTIVE_INST_ANY: VALU + LDS + VMEM + SALU
                       issue of the resident waves, which overlap) is a utilisation figure, not a bound.  `levels` carries
                       the byte-side figures, each against its own peak: L2 request bytes (34.5 TB/s), fabric bytes
                       (8 TB/s), compulsory HBM bytes, the cache-served algorithmic gather stream (196 608 B per marched
@@ -39,8 +43,9 @@ Printed JSON (rank 0, one line) carries, besides the contract fields:
   per_rank          - ms per step, kernel ms, fraction of rays marched for every rank (N > 1);
   parity            - max |error| of ONE image of this very workload rendered by the timed code path against the CPU
                       oracle (untimed; budget 1e-4 on rgb / depth / mask);
-  cpu_baseline      - the oracle (CPU restatement of the reference, reference ATen numerics) timed on this box's host
-                      cores on ONE image of the same workload.
+  cpu_baseline      - kind 'reference': run.py::render + the real Generator's sampler (oracle/_ref, staged by
+                      oracle/make_ref.py) timed on this box's host cores on ONE image of the same workload; kind 'port' (the
+                      oracle restatement) only where the staged sources are missing.
 """
 import argparse
 import ctypes
@@ -125,9 +130,33 @@ def stats(xs):
     return {'min': xs[0], 'median': xs[len(xs) // 2], 'max': xs[-1]}
 
 
+def reference_renderer(d, device, scripted=True):
+    """run.py::render (AST-sliced) on the real models/generator.py::Generator carrying this workload's field tensors,
+    plane producer frozen to the synthetic planes (render only).  Sources: oracle/reference.py (the checkout, or the
+    copy oracle/make_ref.py staged for the GPU box).  Returns call(cam, focal, n_images) -> 6-tuple, or None."""
+    from oracle import reference
+    if not reference.available():
+        return None
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    import reference_cases as rc
+    gen = rc.generator_from_tensors(d['planes'], d['w1'], d['b1'], d['w2'], d['b2'], d['beta'], d['alpha'], SCENE_RANGE, device)
+    ren, _ = reference.load_render(reference.render_args(), {'scene_range': SCENE_RANGE, 'white_background': True},
+                                   unscripted_stages=not scripted)
+    att = d['att'].to(device)
+
+    def call(cam, focal, n):
+        return ren(gen, R, R, cam, focal, None, None, rc.dummy_ws(n, device), S, extra_model_inputs={'attention_values': att[:n]})
+    return call
+
+
 def cpu_baseline_and_parity(seed, dev, ops, texels='fp32'):
-    """Oracle (kind 'port': the CPU restatement pinned bit-exactly to the reference) on one image of the workload; the
-    same image, same noise, rendered by the timed HIP code path is compared with it (the bench's own parity figure)."""
+    """CPU baseline on one image of the workload, and the bench's own parity figure on that image.
+
+    kind 'reference': the reference itself - run.py::render + the real Generator's sampler, TorchScript on as run.py has
+    it - on this box's host cores (sources: oracle/_ref, staged by oracle/make_ref.py).  Without the sources: kind 'port',
+    the oracle (the CPU restatement pinned bit-exactly to the reference).  The same image, same noise, rendered by the
+    timed HIP code path is compared with the oracle AND - where available - with the reference itself (unscripted stage
+    functions, so that the noise can be handed over)."""
     from oracle import nfi_oracle as orc
     d = synthetic_inputs(1, seed, 'cpu')
     if texels != 'fp32':
@@ -136,18 +165,28 @@ def cpu_baseline_and_parity(seed, dev, ops, texels='fp32'):
     g = torch.Generator().manual_seed(seed + 1)
     nc = torch.rand(1, R, R, S, generator=g)
     nf = torch.rand(R * R, S, generator=g)
+
+    def oracle_once():
+        return orc.render(d['planes'], d['w1'], d['b1'], d['w2'], d['b2'], d['cam'], d['focal'], R, R, S, SCENE_RANGE,
+                          white_background=True, noise_coarse=nc, noise_fine=nf, use_sdf=True, beta=d['beta'],
+                          alpha=d['alpha'], attention_values=d['att'])
+    ref_call = reference_renderer(d, 'cpu', scripted=True)
     times = []
     with torch.no_grad():
         for i in range(4):
             t0 = time.perf_counter()
-            ref = orc.render(d['planes'], d['w1'], d['b1'], d['w2'], d['b2'], d['cam'], d['focal'], R, R, S, SCENE_RANGE,
-                             white_background=True, noise_coarse=nc, noise_fine=nf, use_sdf=True, beta=d['beta'],
-                             alpha=d['alpha'], attention_values=d['att'])
+            if ref_call is not None:
+                ref_call(d['cam'], d['focal'], 1)
+            else:
+                oracle_once()
             if i > 0:
                 times.append(time.perf_counter() - t0)
+        ref = oracle_once()
     med = sorted(times)[len(times) // 2]
-    base = {'value': R * R / med, 'unit': 'rays/s', 'cores': torch.get_num_threads(), 'kind': 'port',
-            'sample': '1 image 128x128, 64+64 samples, planes precomputed (render only), fp32, 1 warm-up + 3 timed runs, median'}
+    base = {'value': R * R / med, 'unit': 'rays/s', 'cores': torch.get_num_threads(),
+            'kind': 'reference' if ref_call is not None else 'port',
+            'sample': ('run.py::render + the real Generator sampler (oracle/_ref), ' if ref_call is not None else 'oracle restatement, ') +
+                      '1 image 128x128, 64+64 samples, planes precomputed (render only), fp32, 1 warm-up + 3 timed runs, median'}
     dd = {k: v.to(dev) for k, v in d.items()}
     tdt = {'fp32': ops.TEXEL_F32, 'fp16': ops.TEXEL_F16, 'bf16': ops.TEXEL_BF16}[texels]
     texel_t = ops.planes_to_texels(dd['planes'], tdt)
@@ -155,23 +194,40 @@ def cpu_baseline_and_parity(seed, dev, ops, texels='fp32'):
     out = ops.render_fwd(dd['cam'], dd['focal'], R, R, S, texel_t, image, SCENE_RANGE, A, dd['att'], True, dd['beta'],
                          dd['alpha'], noise_coarse=nc.to(dev), noise_fine=nf.to(dev), fine_sampling=True,
                          white_background=True, skip_missed_rays=True)
-    # the same image through the oracle evaluated with PyTorch-ROCm ops on this GPU = the reference's own GPU numerics
-    # (its elementwise kernels contract a*b+c into FMAs, so the two oracles differ from EACH OTHER: the gap is printed)
-    with torch.no_grad():
-        ref_gpu = orc.render(dd['planes'], dd['w1'], dd['b1'], dd['w2'], dd['b2'], dd['cam'], dd['focal'], R, R, S, SCENE_RANGE,
-                             white_background=True, noise_coarse=nc.to(dev), noise_fine=nf.to(dev), use_sdf=True,
-                             beta=dd['beta'], alpha=dd['alpha'], attention_values=dd['att'])
     keys = ('rgb', 'depth', 'mask')
     vs_cpu = {k: float((out[k].cpu() - ref[k]).abs().max()) for k in keys}
-    vs_gpu = {k: float((out[k] - ref_gpu[k]).abs().max()) for k in keys}
-    gap = {k: float((ref_gpu[k].cpu() - ref[k]).abs().max()) for k in keys}
     parity = dict(vs_cpu)                    # top-level rgb / depth / mask: against the pinned CPU oracle
     parity.update(budget=1e-4, against='CPU oracle (reference ATen numerics, pinned to the live reference), 1 image of this '
                                        'workload, same noise' + ('' if texels == 'fp32' else ', planes rounded to the %s storage' % texels),
-                  vs_pytorch_rocm_oracle=vs_gpu, oracle_cpu_vs_pytorch_rocm_gap=gap,
                   ok=bool(max(vs_cpu.values()) <= 1e-4 and all(bool(torch.isfinite(out[k]).all()) for k in keys)),
-                  ok_vs_pytorch_rocm=bool(all(vs_gpu[k] <= gap[k] + 1e-4 for k in keys)),
                   mask_mean=float(ref['mask'].mean()))
+    # the reference itself, same image, same noise: on the CPU (must equal the oracle bit for bit) and on this GPU
+    # (PyTorch-ROCm: its elementwise kernels contract a*b+c into FMAs, so it differs from its own CPU path: gap printed)
+    if ref_call is not None:
+        sys.path.insert(0, os.path.join(ROOT, 'tests'))
+        import reference_cases as rc
+        plain_cpu = reference_renderer(d, 'cpu', scripted=False)
+        plain_gpu = reference_renderer(dd, dev, scripted=False)
+        with torch.no_grad():
+            with rc.ReplayNoise([nc, nf]):
+                r_cpu = dict(zip(keys, plain_cpu(d['cam'], d['focal'], 1)[:3]))
+            with rc.ReplayNoise([nc.to(dev), nf.to(dev)]):
+                r_gpu = dict(zip(keys, plain_gpu(dd['cam'], dd['focal'], 1)[:3]))
+        vs_gpu = {k: float((out[k] - r_gpu[k]).abs().max()) for k in keys}
+        gap = {k: float((r_gpu[k].cpu() - r_cpu[k]).abs().max()) for k in keys}
+        parity.update(vs_reference_cpu={k: float((out[k].cpu() - r_cpu[k]).abs().max()) for k in keys},
+                      oracle_equals_reference_cpu_bit_for_bit=bool(all(torch.equal(r_cpu[k], ref[k]) for k in keys)),
+                      vs_reference_pytorch_rocm=vs_gpu, reference_cpu_vs_pytorch_rocm_gap=gap,
+                      ok_vs_reference_pytorch_rocm=bool(all(vs_gpu[k] <= gap[k] + 1e-4 for k in keys)))
+    else:
+        with torch.no_grad():
+            ref_gpu = orc.render(dd['planes'], dd['w1'], dd['b1'], dd['w2'], dd['b2'], dd['cam'], dd['focal'], R, R, S, SCENE_RANGE,
+                                 white_background=True, noise_coarse=nc.to(dev), noise_fine=nf.to(dev), use_sdf=True,
+                                 beta=dd['beta'], alpha=dd['alpha'], attention_values=dd['att'])
+        vs_gpu = {k: float((out[k] - ref_gpu[k]).abs().max()) for k in keys}
+        gap = {k: float((ref_gpu[k].cpu() - ref[k]).abs().max()) for k in keys}
+        parity.update(vs_pytorch_rocm_oracle=vs_gpu, oracle_cpu_vs_pytorch_rocm_gap=gap,
+                      ok_vs_pytorch_rocm=bool(all(vs_gpu[k] <= gap[k] + 1e-4 for k in keys)))
     return base, parity
 
 
@@ -242,9 +298,43 @@ def time_staged_semantics(ops, dev, n_img, radius, iters=20):
     return {'rays_per_s': n_img * R * R * iters / (sum(per) * 1e-3), 'ms': stats(per), 'iters': iters}
 
 
+def pytorch_rocm_reference(dev):
+    """The >= 10x target's denominator: the reference renderer on PyTorch-ROCm on this GPU - run.py::render + the real
+    Generator's sampler (TorchScript on, as run.py runs it), planes precomputed (render only), B = 1 / 4 / 8 images of
+    the workload, HIP events, best of 3 after 2 warm-up calls.  Without the staged sources: the oracle's op sequence."""
+    from oracle import nfi_oracle as orc
+    dd = synthetic_inputs(8, 4321, dev)
+    call = reference_renderer(dd, dev, scripted=True)
+    res = {'unit': 'rays/s', 'kind': 'reference' if call is not None else 'port'}
+    for n in (1, 4, 8):
+        cam, focal = dd['cam'][:n].contiguous(), dd['focal'][:n].contiguous()
+        times = []
+        with torch.no_grad():
+            for i in range(5):
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record()
+                if call is not None:
+                    call(cam, focal, n)
+                else:
+                    orc.render(dd['planes'][:n], dd['w1'], dd['b1'], dd['w2'], dd['b2'], cam, focal, R, R, S, SCENE_RANGE,
+                               white_background=True, noise_coarse=torch.rand((n, R, R, S), device=dev),
+                               noise_fine=torch.rand((n * R * R, S), device=dev), use_sdf=True, beta=dd['beta'],
+                               alpha=dd['alpha'], attention_values=dd['att'][:n])
+                b.record()
+                torch.cuda.synchronize()
+                times.append(a.elapsed_time(b) * 1e-3)
+        res['b%d' % n] = n * R * R / min(times[2:])
+    res['value'] = max(res['b1'], res['b4'], res['b8'])
+    res['sample'] = (('run.py::render (oracle/_ref) + the real Generator sampler' if call is not None else
+                      'oracle (reference ATen op sequence)') +
+                     ' on this GPU under PyTorch-ROCm, 1 / 4 / 8 images 128x128, 64+64, render only, fp32, best of 3 '
+                     'after 2 warm-up calls, HIP events; value = the best of the three batch sizes')
+    torch.cuda.empty_cache()
+    return res
+
+
 def extras(dev, ops):
     """Untimed-side measurements reported next to the headline (never part of `value`)."""
-    from oracle import nfi_oracle as orc
     ex = {'render_only': {}}
     cases = {
         'b1_chairs_fp32_texels': (1, RADIUS, ops.TEXEL_F32, {}),
@@ -294,24 +384,7 @@ def extras(dev, ops):
         maps['b8_chairs_fp32_texels_semantics_staged_path']['rays_per_s'] / ex['render_only']['b8_chairs_fp32_texels']['rays_per_s'])
     ex['extra_maps_fused'] = maps
     del exact_out
-    # reference numerics on PyTorch-ROCm: the oracle with GPU ATen ops, 2 images, planes precomputed
-    dd = synthetic_inputs(2, 4321, dev)
-    nc = torch.rand((2, R, R, S), device=dev)
-    nf = torch.rand((2 * R * R, S), device=dev)
-    times = []
-    with torch.no_grad():
-        for i in range(4):
-            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            a.record()
-            orc.render(dd['planes'], dd['w1'], dd['b1'], dd['w2'], dd['b2'], dd['cam'], dd['focal'], R, R, S, SCENE_RANGE,
-                       white_background=True, noise_coarse=nc, noise_fine=nf, use_sdf=True, beta=dd['beta'],
-                       alpha=dd['alpha'], attention_values=dd['att'])
-            b.record()
-            torch.cuda.synchronize()
-            times.append(a.elapsed_time(b) * 1e-3)
-    ex['pytorch_rocm_reference_path'] = {'value': 2 * R * R / min(times[1:]), 'unit': 'rays/s',
-                                         'sample': 'oracle (reference ATen op sequence) on this GPU, 2 images, '
-                                                   'render only, fp32, best of 3 after warm-up, HIP events'}
+    ex['pytorch_rocm_reference_path'] = pytorch_rocm_reference(dev)
     sys.path.insert(0, os.path.join(ROOT, 'tools'))
     sys.path.insert(0, os.path.join(ROOT, 'tests'))
     # BASELINE config 3 stand-in (no p3d_car data / checkpoint exists offline): synthetic inversion, 30 Adam steps on
@@ -377,7 +450,7 @@ def roofline(kernel_ms, marched, n_images, live_clock_hz=None, texels='fp32'):
                  'frac_of_fp16_matrix_peak_issued': 3 * mlp_tflops / MFMA_F16_PEAK_TFLOPS},
     }
     # algorithmic decoder FLOPs per launch / kernel time against the fp32 matrix / vector peak
-    r = {'bound': 'mfma', 'kernel': 'render_fwd_kernel', 'kernel_ms': kernel_ms, 'rays_marched_per_launch': marched,
+    r = {'bound': 'valu', 'kernel': 'render_fwd_kernel', 'kernel_ms': kernel_ms, 'rays_marched_per_launch': marched,
          'achieved': mlp_tflops, 'peak': MFMA_F32_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': mlp_tflops / MFMA_F32_PEAK_TFLOPS,
          'frac_flops': mlp_tflops / MFMA_F32_PEAK_TFLOPS, 'flop_per_marched_ray': MLP_FLOP_PER_RAY, 'traffic': None,
          'source': src, 'levels': levels,
@@ -405,6 +478,7 @@ def roofline(kernel_ms, marched, n_images, live_clock_hz=None, texels='fp32'):
                                 'is mostly the write-back of the preceding kernels\' dirty lines (texel hand-off, rand)'}
     any_cycles = prof['issue_cycles_per_marched_ray'] * marched / t
     r.update(traffic=fab, shader_clock_hz=clk,
+             valu_frac=None if valu_per_ray is None else valu_per_ray * marched / t / peak_cycles,
              shader_clock_source='live: s_memtime / s_memrealtime of a persistent wave of the timed launches'
              if live_clock_hz else 'the PMC profile (GRBM_GUI_ACTIVE / 8 / kernel time of its clock pass)',
              valu_pipe={'cycles_per_marched_ray': valu_per_ray,
@@ -455,29 +529,19 @@ def main():
     ap.add_argument('--reduce-mode', choices=('all_reduce', 'reduce_scatter'), default='all_reduce')
     ap.add_argument('--no-overlap', action='store_true', help='train mode: launch the collectives after backward')
     ap.add_argument('--texels', choices=('fp32', 'fp16', 'bf16'), default='fp32',
-                    help='storage type of the texels the kernels gather from (arithmetic stays fp32; train mode: so does the '
-                         'plane gradient); fp16 is the fast storage: packed texels, three workgroups per CU in the inference kernel')
+                    help='storage type of the texels the kernels gather from (arithmetic stays fp32)')
     ap.add_argument('--pipelined', action='store_true',
-                    help='render mode: `value` under the two-stream schedule (the next steps\' texel hand-off, decoder pack, '
-                         'noise draws and ray set-up on a second HIP stream) instead of the serial one')
+                    help='render mode: `value` under the two-stream schedule instead of the serial one (DESIGN.md 4.3)')
     ap.add_argument('--prewarm-ms', type=float, default=300.0,
-                    help='render mode: untimed steps for this long BEFORE the W warm-up steps, so that the allocator and the '
-                         'shader clock (2.30 GHz in the first 25 steps after idle, 2.38 GHz settled) are in steady state when '
-                         'the K timed steps start - with the driver\'s --steps 20 --warmup 5 the headline otherwise reads '
-                         '134 M instead of 142 M rays/s for the same code; 0 switches it off')
+                    help='render mode: untimed steps for this long before the W warm-up steps (allocator and shader clock '
+                         'in steady state, DESIGN.md 4.3); 0 switches it off')
     ap.add_argument('--no-variants', action='store_true',
                     help='render mode: skip the value_mlp_exact_fp32 / value_all_rays_hit / value_pipelined legs')
     ap.add_argument('--prefetch-depth', type=int, default=2,
-                    help='render mode, two-stream schedule: how many steps ahead the front of a step is prepared '
-                         '(slots = depth + 1).  The persistent render kernel leaves the other stream few CU slots, so a front '
-                         'started one step ahead tends to finish only as that render drains and the next render waits for '
-                         'it; two steps ahead it never does (146 -> 150 M rays/s)')
+                    help='render mode, two-stream schedule: how many steps ahead the front of a step is prepared')
     ap.add_argument('--render-streams', type=int, default=None,
-                    help='render mode, pipelined schedule: consecutive render kernels alternate over this many streams, so '
-                         'that the first workgroups of step i+1 take the slots the draining step i frees.  Default 1 with '
-                         'fp32 / bf16 texels (2: 143 vs 151 M rays/s), 2 with fp16 texels (that kernel fills every slot of '
-                         'the chip: with one render stream the front of the next steps only runs between renders - 166 M '
-                         'pipelined, 173 M serial, 180 M with two)')
+                    help='render mode, two-stream schedule: consecutive render kernels alternate over this many streams '
+                         '(default 1; 2 with fp16 texels)')
     ap.add_argument('--serial', action='store_true', help='render mode: one stream, every step after the previous one (the default)')
     args = ap.parse_args()
 
@@ -669,7 +733,9 @@ def main():
             'prewarm': {'ms': args.prewarm_ms, 'untimed_steps': prewarm_steps,
                         'why': 'allocator + shader clock in steady state before the W warm-up and K timed steps'},
             'schedule': two_stream if pipelined else 'one stream, serial steps: what a caller of the drop-in render() gets',
-            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'dtype': 'f32 (decoder MLP operands split-fp16 hi+lo, 22 bits; strict fp32: config.value_mlp_exact_fp32)',
+            'data': 'synthetic',
             'config': {'workload': 'cfg2: shapenet_chairs-like forward render, %d images/GPU, 128x128 rays/image, '
                                    '64 coarse + 64 fine samples, 3x256x256x32 fp32 triplanes, SDF decoder, A=10; '
                                    'step = texel hand-off + decoder pack + 2 rand draws + ray set-up + fused render kernel'
@@ -683,21 +749,32 @@ def main():
                        'skip_missed_rays': not args.no_skip, 'sharding': 'images across ranks, no collective'},
         }
         if variants:
+            # scalar keys inside `config`: the driver's parser keeps config / roofline / cpu_baseline and drops unknown
+            # top-level keys, so the strict-fp32 and all-rays-hit whole-step rates live here
             other = 'pipelined' if not pipelined else 'serial'
-            res['value_serial' if not pipelined else 'value_pipelined'] = value
-            res['value_' + other] = variants[other]['value']
-            res['value_mlp_exact_fp32'] = variants['mlp_exact_fp32']['value']
-            res['value_all_rays_hit'] = variants['all_rays_hit']['value']
+            cfg = res['config']
+            cfg['value_serial' if not pipelined else 'value_pipelined'] = value
+            cfg['value_' + other] = variants[other]['value']
+            cfg['value_mlp_exact_fp32'] = variants['mlp_exact_fp32']['value']
+            cfg['value_all_rays_hit'] = variants['all_rays_hit']['value']
+            cfg['rays_marched_fraction_all_rays_hit'] = marched_rays(d_hit) / n_rays
             res['variants'] = dict(variants, note='the SAME whole step, K, warm-up and max-over-ranks protocol as `value`: '
                                    'mlp_exact_fp32 = decoder MLP on v_mfma_f32_16x16x4_f32 (tuning bit 3), the strictly-fp32 '
-                                   'rate; all_rays_hit = cameras at radius 1.3, every ray crosses the scene cube (rays '
-                                   'marched fraction %.3f); %s = %s' % (marched_rays(d_hit) / n_rays, other,
-                                                                       two_stream if other == 'pipelined' else 'one stream'))
+                                   'rate; all_rays_hit = cameras at radius 1.3, every ray crosses the scene cube; %s = %s'
+                                   % (other, two_stream if other == 'pipelined' else 'one stream'))
         res['roofline'] = roofline(kernel_ms, marched, B, live_clock, args.texels)
         res['kernel_ms_stats'] = stats(k_ms)
         res['per_rank'] = per_rank
         if world == 1 and not args.no_extras:
             res['extras'] = extras(dev, ops)      # before the CPU leg: its OpenMP workers keep spinning for a while
+            ref_gpu = res['extras'].get('pytorch_rocm_reference_path') or {}
+            if ref_gpu.get('value'):
+                # the north star's ">= 10x the reference PyTorch-ROCm renderer at 1 GPU": this step's whole-job rate over
+                # the reference's best batch size on the same GPU (render only, which favours the reference: `value`
+                # also pays for the texel hand-off, the decoder pack and the noise draws)
+                res['config']['pytorch_rocm_reference_rays_per_s'] = ref_gpu['value']
+                res['config']['pytorch_rocm_reference_kind'] = ref_gpu['kind']
+                res['config']['x_pytorch_rocm_reference'] = value / ref_gpu['value']
         if world == 1 and not args.no_cpu_baseline:
             res['cpu_baseline'], res['parity'] = cpu_baseline_and_parity(1234, dev, ops, args.texels)
         else:

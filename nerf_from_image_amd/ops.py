@@ -394,8 +394,10 @@ def render_fwd(cam2world, focal, height, width, num_samples, texels, decoder_ima
     termination_eps: 0 = off; eps in (0,1): fine samples behind the depth at which the COARSE transmittance has fallen
     below eps are not evaluated and the rest is compacted by wave ballot (the coarse pass, the pdf and every sample index
     are untouched; |d rgb| <= ~eps, see include/nfi_hip.h).
-    strict: raise when no ray of the batch meets the scene cube, as the reference does (lib/nerf_utils.py:258 fails on
-    min() of an empty selection); reads the hit counter of the ray set-up back = one host synchronisation.
+    strict: True - raise when no ray of the batch meets the scene cube, as the reference does (lib/nerf_utils.py:258 fails
+    on min() of an empty selection): the ray set-up runs as its own launch and its hit counter is read back before the
+    render kernel is launched (one host synchronisation, on the set-up only); 'deferred' - no synchronisation: the counter
+    is copied to pinned memory behind the render and checked by the next strict call / flush_strict().
     want_semantics / want_coords: also return 'semantics' [B,H,W,A] (composited softmax probabilities, run.py:312-335)
     / 'coords' [B,H,W,3] (composited query points, run.py:337-338) / 'normals' [B,H,W,3] (composited unit normals of the
     SDF, + 1 - mask on a white background, lib/nerf_utils.py:149-151, 159; fp32 / fp16 texels) from the SAME launch."""
@@ -444,6 +446,20 @@ def render_fwd(cam2world, focal, height, width, num_samples, texels, decoder_ima
             raise ValueError('render_fwd: the normals map needs the SDF decoder (use_sdf)')
         tap_t['normals'] = torch.empty((B, height, width, 3), dtype=torch.float32, device=dev)
     ws_bytes = lib.nfi_render_workspace_bytes(n)
+    check_after = False
+    if strict == 'deferred':
+        _raise_pending(dev)                      # an EARLIER batch of this device that met no ray
+    elif strict:
+        if not rays_ready and not stash and not any(name in tap_t for name in ('ray_origins', 'ray_directions', 'hit')):
+            # the ray set-up as its own launch, its hit count read back BEFORE the render kernel goes out: the host waits
+            # for the set-up only, and a batch without a hit never pays for a render
+            workspace = render_setup(cam2world, focal, height, width, scene_range, bbox=bbox, center=center,
+                                     workspace=workspace, row_window=row_window)
+            rays_ready = True
+        if rays_ready and workspace is not None and workspace.numel() >= ws_bytes:
+            _raise_if_no_hit(workspace)
+        else:
+            check_after = True                   # (stash / ray taps: the set-up writes rays to the caller's tensors)
     if rays_ready:
         # the kernel would march whatever the workspace holds: refuse anything that is not nfi_render_setup's own result
         if workspace is None or workspace.numel() < ws_bytes:
@@ -482,10 +498,55 @@ def render_fwd(cam2world, focal, height, width, num_samples, texels, decoder_ima
             full_height=0 if row_window is None else int(row_window[1]), rays_ready=int(bool(rays_ready)), **tap_t)
     out.update(tap_t)
     out['_workspace'] = workspace
-    if strict and int(workspace[8:12].view(torch.int32).item()) == 0:      # the hit count of the ray set-up (csrc: reduce[2])
-        raise RuntimeError('compute_near_far_planes: no ray intersects the scene cube '
-                           '(the reference fails on min() of an empty selection here)')
+    if strict == 'deferred':
+        _defer_hit_count(workspace, dev)
+    elif check_after:
+        _raise_if_no_hit(workspace)
     return out
+
+
+_NO_HIT = ('compute_near_far_planes: no ray intersects the scene cube (the reference fails on min() of an empty '
+           'selection here)')
+_PENDING = {}          # device index -> dict(host=pinned int32 ring, slot, queue=[(event, slot)]); one thread per device
+
+
+def _raise_if_no_hit(workspace):
+    if int(workspace[8:12].view(torch.int32).item()) == 0:      # the hit count of the ray set-up (csrc: reduce[2])
+        raise RuntimeError(_NO_HIT)
+
+
+def _defer_hit_count(workspace, dev):
+    """strict='deferred': the hit count goes to pinned host memory behind the render (async copy + event), no wait."""
+    st = _PENDING.setdefault(dev.index, {'host': torch.zeros(64, dtype=torch.int32).pin_memory(), 'slot': 0, 'queue': []})
+    if len(st['queue']) >= 64:
+        _raise_pending(dev, wait=True)
+    slot = st['slot']
+    st['slot'] = (slot + 1) % 64
+    st['host'][slot:slot + 1].copy_(workspace[8:12].view(torch.int32), non_blocking=True)
+    ev = torch.cuda.Event()
+    ev.record(torch.cuda.current_stream(dev))
+    st['queue'].append((ev, slot))
+
+
+def _raise_pending(dev, wait=False):
+    st = _PENDING.get(dev.index)
+    while st and st['queue']:
+        ev, slot = st['queue'][0]
+        if not ev.query():
+            if not wait:
+                return
+            ev.synchronize()
+        st['queue'].pop(0)
+        if int(st['host'][slot]) == 0:
+            st['queue'].clear()
+            raise RuntimeError(_NO_HIT + ' [an earlier batch, strict_near_far="deferred"]')
+
+
+def flush_strict(device=None):
+    """strict='deferred': waits for the hit counts still in flight on `device` (default: the current one) and raises if
+    one of those batches met no ray.  Call it where a loop synchronises anyway (end of an epoch, before a report)."""
+    dev = torch.device('cuda', torch.cuda.current_device()) if device is None else torch.device(device)
+    _raise_pending(dev, wait=True)
 
 
 # --------------------------------------------------------------------------- #

@@ -86,17 +86,31 @@ def allreduce_ray_setup(workspace, group=None):
     cells.copy_(torch.where(v >= 2 ** 31, v - 2 ** 32, v).to(torch.int32))
 
 
-def render_image_rows(render_rows, height, dim=1):
+def join_ray_setup(device, group=None):
+    """What a rank WITHOUT rows does while the others run :func:`allreduce_ray_setup` (row_window_sync): it enters the
+    same reductions with the neutral element - zero-initialised cells are what the ray set-up starts from (csrc:
+    reduce[0..2], atomicMax / atomicAdd on zeroed memory) - so that every rank of the group issues the same collectives.
+    Pass it as ``render_image_rows(..., on_empty=lambda: join_ray_setup(device))`` when the bands are rendered with
+    row_window_sync on."""
+    allreduce_ray_setup(torch.zeros(16, dtype=torch.uint8, device=device), group)
+
+
+def render_image_rows(render_rows, height, dim=1, on_empty=None):
     """One image over all ranks: `render_rows(row0, row1)` renders this rank's band (e.g. a render bound with
     ``make_render(..., row_window=(row0, row1 - row0))`` or ops.render_fwd(row_window=(row0, height))) and returns a tensor
     or a tuple of tensors with the rows along `dim`; the bands are gathered into full images on every rank.
 
     A rank whose band is EMPTY (more ranks than 8-row strips: a 32-row image on 8 ranks) does not call `render_rows` -
     the render kernels refuse a zero-row image - and contributes zero-row tensors instead; their shapes and dtypes come
-    from a small metadata exchange with the ranks that did render, so every rank still enters the same collectives."""
+    from a small metadata exchange with the ranks that did render, so every rank still enters the same collectives.
+    If `render_rows` itself runs collectives (a render bound with row_window_sync reduces the miss-fill over the ranks
+    between its ray set-up and its render kernel), the empty-band ranks have to enter those too: `on_empty()` is called
+    on them instead of `render_rows` (``on_empty=lambda: join_ray_setup(device)``)."""
     r0, r1 = shard_rows(height)
     rank, w = world()
     out = render_rows(r0, r1) if r1 > r0 else None
+    if r1 <= r0 and on_empty is not None and w > 1:
+        on_empty()
     if w == 1:
         if out is None:
             raise ValueError('render_image_rows: the image has no rows')

@@ -30,11 +30,18 @@ process-wide - the reference calls render from one thread per GPU):
   termination_eps   0 = off (default).  eps in (0,1): the fused inference kernel does not evaluate fine samples behind the
                     depth at which the COARSE transmittance has fallen below eps and compacts the rest by wave ballot
                     (coarse pass, pdf and sample indices untouched; |d rgb| <= ~eps; ops.render_fwd(termination_eps=...));
-                    without fine sampling, and for calls that ask for extra maps, it has nothing to act on and is ignored;
+                    without fine sampling, for calls that ask for extra maps and with the view-direction decoder it has
+                    nothing to act on and is ignored;
   strict_near_far   True (default, the reference's behaviour): every path raises when no ray of the batch meets the scene
-                    cube (lib/nerf_utils.py:258 fails on min() of an empty selection) - one host synchronisation per
-                    call (the hit counter of the ray set-up is read back); a loop that cannot see such a batch may clear
-                    it and then gets the background image instead;
+                    cube (lib/nerf_utils.py:258 fails on min() of an empty selection; its boolean indexing synchronises
+                    the host there too).  The fused paths read the hit counter of the ray set-up back BEFORE the render
+                    kernel is launched: the host waits for the set-up kernels only, and a batch without a hit does not
+                    pay for a render.  'deferred': no synchronisation at all - the counter travels to pinned host memory
+                    behind the render and is looked at by the NEXT strict call on that device (or ops.flush_strict()),
+                    which raises for the earlier batch; for serving / pipelined loops.  False: never raises, such a
+                    batch renders as background.  With row_window the check is the whole image's: it runs only when
+                    row_window_sync has summed the hit count over the bands (a band of background rows is legitimate);
+                    without row_window_sync a windowed call does not check;
   row_window        None, or (row_offset, rows): render only these image rows (fused inference path; one image sharded
                     over the ranks of a node, parallel.shard_rows); the outputs then have `rows` rows;
   row_window_sync   False, or True / a process group: the ranks of the group render bands of the SAME image, and the
@@ -88,6 +95,11 @@ def render(target_model, height, width, tform_cam2world, focal_length, center, b
     return _render(args, dataset_config, options, target_model, height, width, tform_cam2world, focal_length, center,
                    bbox, model_input, depth_samples_per_ray, randomize, compute_normals, compute_semantics, compute_coords,
                    extra_model_outputs, extra_model_inputs, force_no_cam_grad)
+
+
+def _strict(opts):
+    v = opts.strict_near_far
+    return 'deferred' if v == 'deferred' else bool(v)
 
 
 def _needs_grad(*tensors):
@@ -223,9 +235,13 @@ def _render(cfg, dcfg, opts, target_model, height, width, tform_cam2world, focal
             bbox=None if bbox is None else bbox.detach(), center=None if center is None else center.detach(),
             noise_coarse=noise_c, noise_fine=inverse_cdf_draws(), fine_sampling=bool(cfg.fine_sampling),
             white_background=bool(white), skip_missed_rays=True, ray_features=ray_features,
-            termination_eps=opts.termination_eps if (cfg.fine_sampling and not extras) else 0.0, row_window=window,
-            want_semantics=compute_semantics and not compute_coords, want_coords=compute_coords,
-            want_normals=compute_normals, workspace=ws, rays_ready=ws is not None, strict=bool(opts.strict_near_far))
+            termination_eps=opts.termination_eps if (cfg.fine_sampling and not extras and ray_features is None) else 0.0,
+            row_window=window, want_semantics=compute_semantics and not compute_coords, want_coords=compute_coords,
+            want_normals=compute_normals, workspace=ws, rays_ready=ws is not None,
+            # a band's own hit count says nothing about the image (the top rows of a centred object are all background):
+            # the check applies to the whole image - every call without a window, windowed calls only once
+            # row_window_sync has summed the count over the bands
+            strict=_strict(opts) if (window is None or ws is not None) else False)
         # run.py:337-338: coords take the semantics slot of render_volume_density when both are asked for
         extra_map = out['coords'] if compute_coords else (out['semantics'] if compute_semantics else None)
         return out['rgb'], out['depth'], out['mask'], out.get('normals'), extra_map, model_outputs
@@ -240,7 +256,7 @@ def _render(cfg, dcfg, opts, target_model, height, width, tform_cam2world, focal
         det = (lambda t: None if t is None else t.detach())
         rgb_map, depth_map, mask = _render_with_stash(
             fused, height, width, S, tform_cam2world, focal_length, det(bbox), det(center), noise_c, inverse_cdf_draws(),
-            white, cam_grad, fine=bool(cfg.fine_sampling), strict=bool(opts.strict_near_far))
+            white, cam_grad, fine=bool(cfg.fine_sampling), strict=_strict(opts))
         return rgb_map, depth_map, mask, None, None, model_outputs
 
     # ---------------- staged path (extra maps with a gradient or over a pass of more than 128 samples) ----------------

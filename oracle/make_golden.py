@@ -2,7 +2,7 @@
 
 TEST INFRASTRUCTURE ONLY (see oracle/nfi_oracle.py header).
 
-Runs only where /root/reference exists (the build container).  It
+Runs where the reference sources exist (/root/reference in the build container, else the staged oracle/_ref).  It
   1. imports lib.nerf_utils / models.generator from /root/reference with
      PYTORCH_JIT=0 (scripted functions become plain Python, so the two
      torch.rand* draws can be intercepted),
@@ -28,11 +28,14 @@ import warnings
 import numpy as np
 import torch
 
-REF = '/root/reference'
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
-sys.path.insert(0, REF)
 sys.path.insert(0, ROOT)
+from oracle import reference                  # noqa: E402
+
+REF = reference.root()                        # /root/reference, or the copy oracle/make_ref.py staged
+assert REF is not None, 'no reference sources (neither /root/reference nor oracle/_ref)'
+sys.path.insert(0, REF)
 warnings.filterwarnings('ignore')
 
 from lib import nerf_utils as ref_nu          # noqa: E402

@@ -107,7 +107,7 @@ def test_bench_roofline_is_reproducible_from_the_committed_profile():
     assert src in bench.PMC_PROFILES and prof == json.load(open(os.path.join(ROOT, src)))
     kernel_ms, marched = prof['kernel_ns_in_clock_pass'] * 1e-6, prof['rays_marched_per_launch']
     r = bench.roofline(kernel_ms, marched, 8)
-    assert r['source'] == src and r['bound'] == 'mfma' and r['unit'] == 'TFLOP/s' and r['peak'] == 157.3
+    assert r['source'] == src and r['bound'] == 'valu' and r['valu_frac'] == r['valu_pipe']['frac'] and r['unit'] == 'TFLOP/s' and r['peak'] == 157.3
     assert abs(r['achieved'] - 704512 * marched / (kernel_ms * 1e-3) / 1e12) < 1e-9
     assert abs(r['frac'] - r['achieved'] / r['peak']) < 1e-12 and r['frac'] == r['frac_flops'] and 0.2 < r['frac'] < 1.0
     assert r['traffic'] == prof['fabric_bytes_per_launch']

@@ -1,5 +1,5 @@
-"""CPU test of the Generator wrapper against the LIVE reference class (needs /root/reference; skipped on
-the GPU box): the original forward keeps producing path-length / regulariser outputs, the planes and the
+"""CPU test of the Generator wrapper against the LIVE reference class (needs the reference sources: the
+checkout, or the copy oracle/make_ref.py staged): the original forward keeps producing path-length / regulariser outputs, the planes and the
 attention table captured for the HIP sampler are exactly what the reference's own sampler would use."""
 import os
 import sys
@@ -7,16 +7,14 @@ import sys
 import pytest
 import torch
 
-REF = '/root/reference'
-pytestmark = pytest.mark.skipif(not os.path.isdir(REF), reason='reference checkout not available')
+from oracle import reference
+
+REF = reference.root()          # the checkout, or the copy oracle/make_ref.py staged
+pytestmark = pytest.mark.skipif(REF is None, reason='reference sources not available (oracle/make_ref.py)')
 
 
 def test_wrapped_forward_keeps_reference_outputs_and_captures_planes(monkeypatch):
-    sys.path.insert(0, REF)
-    try:
-        from models import generator as ref_gen
-    finally:
-        sys.path.remove(REF)
+    ref_gen = reference.modules().generator
     import nerf_from_image_amd.generator as nfi_gen
     torch.manual_seed(0)
     model = ref_gen.Generator(512, 0.55, attention_values=10, use_sdf=True, disable_stylegan_noise=True)
@@ -64,11 +62,7 @@ def test_wrapped_forward_keeps_reference_outputs_and_captures_planes(monkeypatch
 def test_wrapped_forward_hands_over_the_view_direction_feature(monkeypatch):
     """--use_viewdir: the per-ray feature captured from ViewDirectionMapper.fc6 and the mapper's output layer,
     fed to the oracle's restatement of the closure, reproduce the reference's own sampler."""
-    sys.path.insert(0, REF)
-    try:
-        from models import generator as ref_gen
-    finally:
-        sys.path.remove(REF)
+    ref_gen = reference.modules().generator
     import nerf_from_image_amd.generator as nfi_gen
     from oracle import nfi_oracle as orc
     torch.manual_seed(0)
@@ -105,11 +99,7 @@ def test_wrapped_forward_hands_over_the_view_direction_feature(monkeypatch):
 
 def test_oracle_bbox_overlay_matches_reference():
     """The 'bbox' visualisation overlay (generator.py:645-659) restated in the oracle, against the live closure."""
-    sys.path.insert(0, REF)
-    try:
-        from models import generator as ref_gen
-    finally:
-        sys.path.remove(REF)
+    ref_gen = reference.modules().generator
     from oracle import nfi_oracle as orc
     torch.manual_seed(3)
     model = ref_gen.Generator(512, 0.55, attention_values=10, use_sdf=True, disable_stylegan_noise=True).eval()
@@ -129,11 +119,7 @@ def test_oracle_bbox_overlay_matches_reference():
 def test_oracle_regularisers_match_reference():
     """The regulariser branch (generator.py:505-585: eikonal with its double backward, distance, total variation,
     entropy) restated in the oracle against the live Generator: losses AND their gradients w.r.t. the decoder."""
-    sys.path.insert(0, REF)
-    try:
-        from models import generator as ref_gen
-    finally:
-        sys.path.remove(REF)
+    ref_gen = reference.modules().generator
     from oracle import nfi_oracle as orc
     torch.manual_seed(5)
     model = ref_gen.Generator(512, 0.55, attention_values=10, use_sdf=True, disable_stylegan_noise=True).train()
@@ -173,11 +159,7 @@ def test_oracle_regularisers_match_reference():
 def test_wrapped_forward_can_hand_the_regularisers_to_hip(monkeypatch):
     """attach(..., hip_regularisers=True): the four regulariser names are withheld from the reference forward (which
     still produces the planes) and served by generator.regulariser_outputs on the captured planes."""
-    sys.path.insert(0, REF)
-    try:
-        from models import generator as ref_gen
-    finally:
-        sys.path.remove(REF)
+    ref_gen = reference.modules().generator
     import nerf_from_image_amd.generator as nfi_gen
     torch.manual_seed(0)
     model = ref_gen.Generator(512, 0.55, attention_values=10, use_sdf=True, disable_stylegan_noise=True).train()

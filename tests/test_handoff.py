@@ -1,7 +1,7 @@
 """Plane-producer hand-off: the fused tail of the last synthesis block writes texels directly
 (interleaved layout = channels-last [B,96,R,R]), and every field kernel reads / differentiates that layout in place.
 
-CPU: the oracle restatement against the committed vector from the live SynthesisBlock; with /root/reference, the
+CPU: the oracle restatement against the committed vector from the live SynthesisBlock; with the reference sources, the
 block wrapper's glue on the real SynthesisNetwork (kernel replaced by the oracle function).  GPU: the HIP kernels."""
 import os
 import sys
@@ -14,7 +14,9 @@ import torch
 from conftest import GOLDEN
 from oracle import nfi_oracle_neighbours as orn
 
-REF = '/root/reference'
+from oracle import reference
+
+REF = reference.root()          # the checkout, or the copy oracle/make_ref.py staged (GPU box); None: neither
 
 
 def gold():
@@ -28,16 +30,12 @@ def test_oracle_tail_matches_committed_reference_vector():
     assert torch.allclose(got, t['handoff_ref'], rtol=0, atol=1e-5)
 
 
-@pytest.mark.skipif(not os.path.isdir(REF), reason='reference checkout not available')
+@pytest.mark.skipif(REF is None, reason='reference sources not available (oracle/make_ref.py)')
 def test_fused_block_glue_on_the_real_synthesis_network(monkeypatch):
     """fuse_last_block on the reference's SynthesisNetwork: same state_dict keys, and - with the kernel swapped for
     the oracle function on CPU - the same image as the unfused network, bit for bit (style computation, ws iteration,
     upsample + add order)."""
-    sys.path.insert(0, REF)
-    try:
-        from models import stylegan as ref_sg
-    finally:
-        sys.path.remove(REF)
+    ref_sg = reference.modules().stylegan
     import nerf_from_image_amd.handoff as handoff
     torch.manual_seed(0)
     net = ref_sg.SynthesisNetwork(w_dim=32, img_resolution=32, img_channels=96, channel_base=512, channel_max=32,

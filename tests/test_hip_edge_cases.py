@@ -145,8 +145,55 @@ def test_no_ray_meets_the_cube(gpu_device):
     assert float(out['mask'].abs().max()) == 0.0 and float((out['rgb'] - 1.0).abs().max()) == 0.0
     assert float(out['coords'].abs().max()) == 0.0 and float(out['semantics'].abs().max()) == 0.0
     # and a batch with at least one hit does not raise
-    ok = ops.render_fwd(look_at_cameras(1, 1.8, g).to(dev), focal, 8, 8, 16, *args, strict=True)
+    good = look_at_cameras(1, 1.8, g).to(dev)
+    ok = ops.render_fwd(good, focal, 8, 8, 16, *args, strict=True)
     assert float(ok['mask'].max()) > 0.0
+    # strict=True reads the set-up's hit count BEFORE the render is launched (split launch): same image as the one call
+    one = ops.render_fwd(good, focal, 8, 8, 16, *args, strict=False)
+    assert all(torch.equal(ok[k], one[k]) for k in ('rgb', 'depth', 'mask'))
+    # the training stash redirects the ray set-up (no split): the check comes after the launch, still raises
+    with pytest.raises(RuntimeError, match='no ray intersects the scene cube'):
+        ops.render_fwd(cam, focal, 8, 8, 16, *args, strict=True, stash=True)
+    # 'deferred': nothing is read back at the call; the NEXT strict call on the device (or flush_strict) raises
+    ops.flush_strict(dev)
+    ops.render_fwd(cam, focal, 8, 8, 16, *args, strict='deferred')               # no hit, no exception yet
+    torch.cuda.synchronize()
+    with pytest.raises(RuntimeError, match='an earlier batch'):
+        ops.render_fwd(good, focal, 8, 8, 16, *args, strict='deferred')
+    ops.render_fwd(good, focal, 8, 8, 16, *args, strict='deferred')
+    ops.flush_strict(dev)                                                        # a batch with hits: silent
+    ops.render_fwd(cam, focal, 8, 8, 16, *args, strict='deferred')
+    with pytest.raises(RuntimeError, match='an earlier batch'):
+        ops.flush_strict(dev)
+    ops.flush_strict(dev)                                                        # the queue was cleared by the raise
+
+
+def test_a_band_of_background_rows_is_not_an_error(gpu_device):
+    """row_window without row_window_sync under the default options: the top band of a centred object holds no ray that
+    meets the cube - legitimate for a band (the image has hits), so the windowed call must not apply the batch check
+    to its own counter (it used to raise there and leave the other ranks hanging in the gather)."""
+    import types
+    import nerf_from_image_amd.render as nfi_render
+    from nerf_from_image_amd.generator import FusedField
+    d, g = scene(1, 10, 16, 11)
+    dev = gpu_device
+    texels = ops.planes_to_texels(d['planes'].to(dev))
+    image = ops.decoder_pack(d['w1'].to(dev), d['b1'].to(dev), d['w2'].to(dev), d['b2'].to(dev), 10)
+    fused = FusedField(texels, image, d['att'].to(dev), 10, True, d['beta'].to(dev), d['alpha'].to(dev), 0.2)
+    fused.ray_features, fused.bbox_overlay = None, False
+
+    def model(viewdir, c, req, extra):
+        smp = lambda x, r=None: None
+        smp.fused = fused
+        return {'sampler': smp}
+    cam = look_at_cameras(1, 2.0, g).to(dev)
+    focal = torch.full((1,), 1.0, device=dev)
+    cfg = types.SimpleNamespace(use_viewdir=False, use_sdf=True, attention_values=10, fine_sampling=True)
+    dcfg = {'scene_range': 0.2, 'white_background': True}                      # a small cube: the outer bands see none of it
+    full = nfi_render.make_render(cfg, dcfg)(model, 64, 64, cam, focal, None, None, None, 16, randomize=False)
+    assert float(full[2][:, :8].abs().max()) == 0.0 and float(full[2].max()) > 0.0
+    top = nfi_render.make_render(cfg, dcfg, row_window=(0, 8))(model, 64, 64, cam, focal, None, None, None, 16, randomize=False)
+    assert top[0].shape == (1, 8, 64, 3) and torch.equal(top[0], full[0][:, :8]) and torch.equal(top[2], full[2][:, :8])
 
 
 @pytest.mark.parametrize('H,W,S,B', [(16, 16, 8, 1), (16, 48, 16, 3), (32, 16, 65, 2), (64, 64, 128, 1), (48, 80, 20, 9)])

@@ -43,6 +43,23 @@ def case(request, gpu_device):
     return request.param, meta, t, o, gpu_device
 
 
+def _fine_case_names():
+    import json
+    import os
+    from conftest import GOLDEN
+    cases = json.load(open(os.path.join(GOLDEN, 'cases.json')))
+    return [n for n in golden_case_names() if 's512' not in n and cases[n]['fine']]
+
+
+@pytest.fixture(scope='module', params=_fine_case_names())
+def fine_case(request, gpu_device):
+    """The golden cases WITH a fine pass (the single-pass cases have no resampling stage to test: they are left out of
+    the parametrisation instead of being skipped)."""
+    meta, t = load_golden(request.param)
+    o = oracle_render(meta, t, 'cpu')
+    return request.param, meta, t, o, gpu_device
+
+
 def close(a, b, tol, what):
     e = err(a, b)
     assert e['nonfinite'] == 0 and e['max'] <= tol, (what, e)
@@ -130,10 +147,8 @@ def test_field_query_ragged_and_far_points(gpu_device):
     close(q['sdf'], ref['sdf'], 1e-5, 'sdf')
 
 
-def test_sampling_stages(case):
-    name, meta, t, o, dev = case
-    if not meta['fine']:
-        pytest.skip('no fine sampling in this case')
+def test_sampling_stages(fine_case):
+    name, meta, t, o, dev = fine_case
     S = meta['S']
     n = o['weights_coarse'].shape[0]
     w = ops.ray_weights(o['sigma_coarse'].to(dev), o['rd'].to(dev), o['t_coarse'].to(dev))

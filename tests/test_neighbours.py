@@ -2,7 +2,7 @@
 and the PSNR / IoU monitors of lib/metrics.py.
 
 CPU: the oracle restatement against the committed vectors (tests/golden/neighbours.npz, written from the live
-functions by oracle/make_golden.py) and - where /root/reference exists - the host-side pose algebra and RNG draw order
+functions by oracle/make_golden.py) and - where the reference sources exist - the host-side pose algebra and RNG draw order
 of nerf_from_image_amd.augment against the live augment_impl.  GPU: the HIP kernels against the oracle through the
 C ABI (forward, backward = adjoint identity and autograd of the oracle, drop-in API)."""
 import ast
@@ -17,7 +17,9 @@ import torch
 from conftest import GOLDEN
 from oracle import nfi_oracle_neighbours as orn
 
-REF = '/root/reference'
+from oracle import reference
+
+REF = reference.root()          # the checkout, or the copy oracle/make_ref.py staged (GPU box); None: neither
 
 
 def gold():
@@ -37,13 +39,9 @@ def test_oracle_matches_committed_reference_vectors():
     assert torch.equal(orn.iou(t['metric_mask_a'], t['metric_mask_b']), t['metric_iou'])
 
 
-@pytest.mark.skipif(not os.path.isdir(REF), reason='reference checkout not available')
+@pytest.mark.skipif(REF is None, reason='reference sources not available (oracle/make_ref.py)')
 def test_pose_algebra_and_draw_order_match_live_reference():
-    sys.path.insert(0, REF)
-    try:
-        from lib import pose_utils
-    finally:
-        sys.path.remove(REF)
+    pose_utils = reference.modules().pose_utils
     import torch.nn.functional as F
     import nerf_from_image_amd.augment as aug
     tree = ast.parse(open(os.path.join(REF, 'run.py')).read())

@@ -1,17 +1,19 @@
 """BASELINE cfg1 at its exact shape (B=4, 64x64, 32 coarse samples; and 32+32) on the CPU: the oracle against the
 LIVE reference - real Generator incl. the StyleGAN2 synthesis network, run.py::render AST-sliced - bit for bit.
 Runs in a subprocess because the reference's scripted functions must be imported with PYTORCH_JIT=0 (the noise
-draws are intercepted).  Needs /root/reference (build container only)."""
+draws are intercepted).  Needs the reference sources (the checkout, or the staged oracle/_ref)."""
 import os
 import subprocess
 import sys
 
 import pytest
 
+from oracle import reference
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.skipif(not os.path.isdir('/root/reference'), reason='reference checkout not available')
+@pytest.mark.skipif(not reference.available(), reason='reference sources not available (oracle/make_ref.py)')
 def test_cfg1_oracle_equals_live_reference():
     env = dict(os.environ, PYTORCH_JIT='0')
     r = subprocess.run([sys.executable, os.path.join(ROOT, 'oracle', 'make_golden.py'), '--cfg1'], env=env,

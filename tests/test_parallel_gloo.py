@@ -242,6 +242,16 @@ def _accumulate_worker(rank, world, port, q):
         assert torch.equal(full, small) and torch.equal(first, small[..., 0].to(torch.int32))
         one = parallel.render_image_rows(lambda a, b: strict_rows(a, b)[0], 8)
         assert torch.is_tensor(one) and torch.equal(one, small)
+        # ... and when the bands are rendered with row_window_sync (the render reduces its miss-fill cells over the ranks),
+        # the rank without rows enters the same reduction with the neutral element instead of going straight to the gather
+        def synced_rows(a, b):
+            cells_ = torch.zeros(16, dtype=torch.uint8)
+            cells_[:12].view(torch.int32).copy_(torch.tensor([5, 9, 3], dtype=torch.int32))
+            parallel.allreduce_ray_setup(cells_)
+            assert cells_[:12].view(torch.int32).tolist() == [5, 9, 3]          # the other rank added nothing
+            return small[:, a:b]
+        joined = parallel.render_image_rows(synced_rows, 8, on_empty=lambda: parallel.join_ray_setup('cpu'))
+        assert torch.equal(joined, small)
         # the miss-fill cells of a row-sharded render: max of the two order-preserving keys (unsigned), sum of the count
         ws = torch.zeros(64, dtype=torch.uint8)
         cells = ws[:12].view(torch.int32)
