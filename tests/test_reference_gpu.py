@@ -62,11 +62,10 @@ def test_normal_map_matches_the_real_reference(gpu_device):
     kernels analytically; maps agree to 3e-3 (the normalisation amplifies the decoder's 1e-5 where |grad| is small)."""
     _require_reference()
     sc = rc.build_scene('chairs', 2, gpu_device)
-    noise = rc.draw_noise(sc, 64, 32)
-    ours = rc.hip_render(sc, 64, 32, noise, compute_normals=True)
-    ref = rc.reference_render(sc, 64, 32, noise, grad=True, compute_normals=True)     # (its sampler needs autograd)
-    assert rc.max_err(ours[0], ref[0]) <= BUDGET and rc.max_err(ours[2], ref[2]) <= BUDGET
-    assert rc.max_err(ours[3], ref[3]) <= 3e-3, rc.max_err(ours[3], ref[3])
+    rep = rc.compare(sc, 64, 32, cpu_images=2, grad=True, compute_normals=True)       # (the reference's sampler needs autograd)
+    _check(rep)
+    assert rep['vs_reference_cpu']['normals'] <= 3e-3, rep
+    assert rep['vs_reference_gpu']['normals'] <= rep['reference_cpu_vs_gpu_gap']['normals'] + 3e-3, rep
 
 
 def test_view_direction_decoder_matches_the_real_reference(gpu_device):
