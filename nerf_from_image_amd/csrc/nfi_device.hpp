@@ -504,9 +504,7 @@ __device__ __forceinline__ void tile_bilinear(const TileTex<TEX>& T, float fx, f
 // fp16 texel storage: the texels stay PACKED (48 registers instead of 96) and the blend reads each half in place with
 // v_fma_mix_f32 - fma(w, float(texel), acc) in one instruction, the same arithmetic as conversion + fma - so 16-bit
 // storage costs no conversion instructions (round 2-3: 96 v_cvt_f32_f16 per tile on top of the blend made fp16 texels
-// slower than fp32 ones in an instruction-bound kernel).  (gfx950 has no bf16 form of the instruction; a packed bf16 tile
-// with the widening shifts at the blend was tried: the compiler widens early anyway - 219 registers, 220 B of scratch when
-// capped at 168 - so bf16 texels stay converted at load time, two blocks per CU.)
+// slower than fp32 ones in an instruction-bound kernel).  (gfx950 has no bf16 form of the instruction: TileTex<1> below.)
 template <>
 struct TileTex<2> {
   uint32_t r[3][4][4];
@@ -542,6 +540,52 @@ __device__ __forceinline__ void tile_bilinear<2>(const TileTex<2>& T, float fx, 
       for (int c = 0; c < 4; ++c) {
         asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[0,1,0]" : "+v"(feat[2 * i]) : "v"(w[c]), "v"(T.r[pl][c][i]));
         asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[0,1,0] op_sel_hi:[0,1,0]" : "+v"(feat[2 * i + 1]) : "v"(w[c]), "v"(T.r[pl][c][i]));
+      }
+    }
+  }
+}
+
+// bf16 texel storage, packed as well (round 5).  gfx950 has no bf16 form of v_fma_mix, and left to itself the compiler
+// widens the texels as they arrive (96 registers again, round 4's attempt: 219 registers, scratch when capped).  Here the
+// widening shift / mask and the fma are ONE asm statement per texel half with an early-clobber temporary: the widened
+// value never lives beyond it, so the tile is 48 packed registers and the inference kernel fits three workgroups per CU
+// like the fp16 one.  Same arithmetic and order as conversion at load time + fmaf (bit-identical images).
+template <>
+struct TileTex<1> {
+  uint32_t r[3][4][4];
+};
+template <>
+__device__ __forceinline__ void tile_issue<1>(const FieldParams& P, int g, uint32_t xi, TileTex<1>& T) {
+  const uint32_t x0 = xi & 1023u, y0 = (xi >> 10) & 1023u, z0 = (xi >> 20) & 1023u;
+#pragma unroll
+  for (int pl = 0; pl < 3; ++pl) {
+    const uint32_t a0 = (pl == 2) ? y0 : x0, b0 = (pl == 0) ? y0 : z0;
+    const uint32_t voff = (uint32_t)pl * P.plane_bytes + __umul24(b0 * (uint32_t)P.res + a0, P.pix_bytes) + (uint32_t)g * 16u;
+    const uint32_t soff[4] = {0u, P.pix_bytes, P.row_bytes, P.row_pix_bytes};
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const u32x4 a = __builtin_amdgcn_raw_buffer_load_b128(P.rsrc, voff, soff[c], 0);
+      T.r[pl][c][0] = a.x; T.r[pl][c][1] = a.y; T.r[pl][c][2] = a.z; T.r[pl][c][3] = a.w;
+    }
+  }
+}
+template <>
+__device__ __forceinline__ void tile_bilinear<1>(const TileTex<1>& T, float fx, float fy, float fz, float (&feat)[8]) {
+#pragma unroll
+  for (int s = 0; s < 8; ++s) feat[s] = 0.0f;
+#pragma unroll
+  for (int pl = 0; pl < 3; ++pl) {
+    const float fa = (pl == 2) ? fy : fx;
+    const float fb = (pl == 0) ? fy : fz;
+    const float ga = 1.0f - fa, gb = 1.0f - fb;
+    const float w[4] = {ga * gb, fa * gb, ga * fb, fa * fb};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        uint32_t tmp;
+        asm("v_lshlrev_b32 %1, 16, %3\n\tv_fmac_f32 %0, %2, %1" : "+v"(feat[2 * i]), "=&v"(tmp) : "v"(w[c]), "v"(T.r[pl][c][i]));
+        asm("v_and_b32 %1, 0xffff0000, %3\n\tv_fmac_f32 %0, %2, %1" : "+v"(feat[2 * i + 1]), "=&v"(tmp) : "v"(w[c]), "v"(T.r[pl][c][i]));
       }
     }
   }
@@ -931,7 +975,7 @@ __device__ __forceinline__ void tile_mlp(const FieldParams& P, int lane, const f
 // through), layer 3 over K = those 48 accumulator rows - the accumulator layout of one layer is the B
 // operand of the next, as between layers 1 and 2.  xr[n][t]: rows 16t+4g..+3 of the padded ray feature
 // of tile n's point j.  P.lds holds the nfi_decoder_pack_viewdir image.
-template <bool ATT, int N>
+template <bool ATT, int N, int SEMP = 0>
 __device__ __forceinline__ void tile_mlp_vd(const FieldParams& P, int lane, const float (&feat)[N][8],
                                             const f32x4 (&xr)[N][3], const float (&outside)[N], float* const (&sem)[N],
                                             TileOut (&res)[N]) {
@@ -1010,7 +1054,7 @@ __device__ __forceinline__ void tile_mlp_vd(const FieldParams& P, int lane, cons
   }
 #pragma unroll
   for (int n = 0; n < N; ++n) o[n] = o[n] + oB[n];
-  tile_epilogue<ATT, N>(P, lane, o, outside, sem, res);
+  tile_epilogue<ATT, N, SEMP>(P, lane, o, outside, sem, res);
 }
 
 struct SampleOut {
@@ -1134,7 +1178,7 @@ __device__ __forceinline__ SampleOut field_wave(const FieldParams& P, float scen
         (sem_base && pair && (fb & 2)) ? sem_base + (size_t)(16 * tb + j) * sem_pt : nullptr};
     TileOut to[2];
     if constexpr (VD) {
-      static_assert(PREC == 0 && SEMP == 0, "the view-direction decoder exists in exact fp32 only, without the LDS semantics table");
+      static_assert(PREC == 0 && !NRM, "the view-direction decoder exists in exact fp32 only, without the normal map");
       const int ra = __shfl(ray_idx, 16 * ta + j, 64), rb = __shfl(ray_idx, 16 * tb + j, 64);
       f32x4 xr[2][3];
 #pragma unroll
@@ -1142,7 +1186,7 @@ __device__ __forceinline__ SampleOut field_wave(const FieldParams& P, float scen
         xr[0][t] = *reinterpret_cast<const f32x4*>(xray + (size_t)ra * kRayFeatPad + 16 * t + 4 * g);
         xr[1][t] = *reinterpret_cast<const f32x4*>(xray + (size_t)rb * kRayFeatPad + 16 * t + 4 * g);
       }
-      tile_mlp_vd<ATT, 2>(P, lane, feat, xr, outs, sems, to);
+      tile_mlp_vd<ATT, 2, SEMP>(P, lane, feat, xr, outs, sems, to);
     } else if constexpr (NRM) {
       f32x4 gh[2][4];
       tile_mlp<ATT, 2, PREC, SEMP, true>(P, lane, feat, outs, sems, to, gh);

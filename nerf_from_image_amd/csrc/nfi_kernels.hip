@@ -2317,8 +2317,14 @@ extern "C" int nfi_render_fwd(const nfi_render_args* a, nfi_stream_t stream) {
   REQUIRE(!term || a->fine_sampling, "render: termination_eps acts on the fine pass (fine_sampling)");
   REQUIRE(!term || !(any_tap || extra || a->profile_cycles || a->ray_features || strict),
           "render: termination_eps cannot be combined with stage taps, extra maps, the cycle profile, the view-direction decoder or the exact-fp32 MLP");
-  REQUIRE(!extra || !(any_tap || a->profile_cycles || a->ray_features || strict),
-          "render: semantics / coords / normals maps cannot be combined with stage taps, the cycle profile, the view-direction decoder or the exact-fp32 MLP");
+  REQUIRE(!extra || !(any_tap || a->profile_cycles || strict),
+          "render: semantics / coords / normals maps cannot be combined with stage taps, the cycle profile or the exact-fp32 MLP");
+  REQUIRE(!(extra && a->ray_features) || (!a->normals && a->texel_dtype == NFI_TEXEL_F32),
+          "render: with the view-direction decoder the semantics / coords maps exist for fp32 texels (no normals map)");
+  // the exact-fp32 MLP (a diagnostic of the split-fp16 arithmetic) and the cycle profile are built for fp32 texels only:
+  // with 16-bit texel storage the texels, not the MLP operands, set the precision
+  REQUIRE(!(strict || a->profile_cycles) || a->texel_dtype == NFI_TEXEL_F32,
+          "render: the exact-fp32 MLP (tuning bit 3) and the cycle profile exist for fp32 texels");
   k.term_eps = a->termination_eps;
   k.semantics = a->semantics; k.coords = a->coords; k.normals = a->normals;
   REQUIRE(!(a->ray_features && a->profile_cycles), "render: no cycle profile with the view-direction decoder");
@@ -2355,11 +2361,11 @@ extern "C" int nfi_render_fwd(const nfi_render_args* a, nfi_stream_t stream) {
       NFI_ENSURE_DYNAMIC_LDS((render_fwd_kernel<TEX, ATT, NFI_RENDER_OCC, kRenderExtra, 1>), kSemLdsMax, "render");    \
       hipLaunchKernelGGL((render_fwd_kernel<TEX, ATT, NFI_RENDER_OCC, kRenderExtra, 1>), grid, dim3(256), sem_lds, s, k); \
     } else if (term) hipLaunchKernelGGL((render_fwd_kernel<TEX, ATT, NFI_RENDER_OCC, kRenderTerm, 1>), grid, dim3(256), 0, s, k); \
-    else if (k.prof) hipLaunchKernelGGL((render_fwd_kernel<TEX, ATT, NFI_RENDER_OCC, kRenderProf, 1>), grid, dim3(256), 0, s, k);    \
-    else if (any_tap && strict) hipLaunchKernelGGL((render_fwd_kernel<TEX, ATT, NFI_RENDER_OCC, kRenderTaps, 0>), grid, dim3(256), 0, s, k); \
+    else if (k.prof) hipLaunchKernelGGL((render_fwd_kernel<0, ATT, NFI_RENDER_OCC, kRenderProf, 1>), grid, dim3(256), 0, s, k);      \
+    else if (any_tap && strict) hipLaunchKernelGGL((render_fwd_kernel<0, ATT, NFI_RENDER_OCC, kRenderTaps, 0>), grid, dim3(256), 0, s, k);   \
     else if (any_tap) hipLaunchKernelGGL((render_fwd_kernel<TEX, ATT, NFI_RENDER_OCC, kRenderTaps, 1>), grid, dim3(256), 0, s, k);          \
-    else if (strict) hipLaunchKernelGGL((render_fwd_kernel<TEX, ATT, NFI_RENDER_OCC, kRenderPlain, 0>), grid, dim3(256), 0, s, k);          \
-    else if (TEX == 2) hipLaunchKernelGGL((render_fwd_kernel<2, ATT, 3, kRenderPlain, 1>), grid3, dim3(256), 0, s, k);        \
+    else if (strict) hipLaunchKernelGGL((render_fwd_kernel<0, ATT, NFI_RENDER_OCC, kRenderPlain, 0>), grid, dim3(256), 0, s, k);            \
+    else if (TEX != 0) hipLaunchKernelGGL((render_fwd_kernel<TEX, ATT, 3, kRenderPlain, 1>), grid3, dim3(256), 0, s, k);      \
     else hipLaunchKernelGGL((render_fwd_kernel<TEX, ATT, NFI_RENDER_OCC, kRenderPlain, 1>), grid, dim3(256), 0, s, k);                      \
   } while (0)
 #define NFI_LAUNCH_RENDER_WIDE(TEX, ATT)                                                                             \
@@ -2372,20 +2378,28 @@ extern "C" int nfi_render_fwd(const nfi_render_args* a, nfi_stream_t stream) {
       NFI_ENSURE_DYNAMIC_LDS((render_fwd_wide_kernel<TEX, ATT, kRenderExtra, 1>), kSemLdsMaxWide, "render");           \
       hipLaunchKernelGGL((render_fwd_wide_kernel<TEX, ATT, kRenderExtra, 1>), grid, dim3(256), sem_lds, s, k);         \
     } else if (term) hipLaunchKernelGGL((render_fwd_wide_kernel<TEX, ATT, kRenderTerm, 1>), grid, dim3(256), 0, s, k);   \
-    else if (any_tap && strict) hipLaunchKernelGGL((render_fwd_wide_kernel<TEX, ATT, kRenderTaps, 0>), grid, dim3(256), 0, s, k); \
+    else if (any_tap && strict) hipLaunchKernelGGL((render_fwd_wide_kernel<0, ATT, kRenderTaps, 0>), grid, dim3(256), 0, s, k);   \
     else if (any_tap) hipLaunchKernelGGL((render_fwd_wide_kernel<TEX, ATT, kRenderTaps, 1>), grid, dim3(256), 0, s, k);        \
-    else if (strict) hipLaunchKernelGGL((render_fwd_wide_kernel<TEX, ATT, kRenderPlain, 0>), grid, dim3(256), 0, s, k);        \
+    else if (strict) hipLaunchKernelGGL((render_fwd_wide_kernel<0, ATT, kRenderPlain, 0>), grid, dim3(256), 0, s, k);          \
     else hipLaunchKernelGGL((render_fwd_wide_kernel<TEX, ATT, kRenderPlain, 1>), grid, dim3(256), 0, s, k);                    \
   } while (0)
 #define NFI_LAUNCH_RENDER_VD(TEX, ATT)                                                                                        \
   do {                                                                                                                      \
-    if (wide) hipLaunchKernelGGL((render_fwd_wide_kernel<TEX, ATT, kRenderTaps, 0, true>), grid, dim3(256), 0, s, k);   \
+    if (extra && TEX == 0) {      /* semantics / coords maps with the view-direction decoder (fp32 texels: checked above) */ \
+      if (wide) {                                                                                                           \
+        NFI_ENSURE_DYNAMIC_LDS((render_fwd_wide_kernel<0, ATT, kRenderExtra, 0, true>), kSemLdsMaxWide, "render");           \
+        hipLaunchKernelGGL((render_fwd_wide_kernel<0, ATT, kRenderExtra, 0, true>), grid, dim3(256), sem_lds, s, k);         \
+      } else {                                                                                                              \
+        NFI_ENSURE_DYNAMIC_LDS((render_fwd_kernel<0, ATT, NFI_RENDER_OCC, kRenderExtra, 0, true>), kSemLdsMax, "render");    \
+        hipLaunchKernelGGL((render_fwd_kernel<0, ATT, NFI_RENDER_OCC, kRenderExtra, 0, true>), grid, dim3(256), sem_lds, s, k); \
+      }                                                                                                                     \
+    } else if (wide) hipLaunchKernelGGL((render_fwd_wide_kernel<TEX, ATT, kRenderTaps, 0, true>), grid, dim3(256), 0, s, k);   \
     else hipLaunchKernelGGL((render_fwd_kernel<TEX, ATT, NFI_RENDER_OCC, kRenderTaps, 0, true>), grid, dim3(256), 0, s, k);                \
   } while (0)
 #define NFI_LAUNCH_RENDER_LONG(TEX, ATT)                                                                              \
   do {                                                                                                                \
     if (a->ray_features) hipLaunchKernelGGL((render_fwd_long_kernel<TEX, ATT, 0, true>), grid, dim3(256), 0, s, k);    \
-    else if (strict) hipLaunchKernelGGL((render_fwd_long_kernel<TEX, ATT, 0>), grid, dim3(256), 0, s, k);              \
+    else if (strict) hipLaunchKernelGGL((render_fwd_long_kernel<0, ATT, 0>), grid, dim3(256), 0, s, k);                \
     else hipLaunchKernelGGL((render_fwd_long_kernel<TEX, ATT, 1>), grid, dim3(256), 0, s, k);                          \
   } while (0)
   if (lng) {

@@ -296,13 +296,10 @@ def test_fused_render_extra_maps(case):
     come out of the SAME launch, rgb / depth / mask stay bit-identical to the plain render, the maps match the oracle
     and the committed reference output."""
     name, meta, t, o, dev = case
-    if 'viewdir_x' in t:
-        with pytest.raises(RuntimeError):
-            hip_render(meta, t, dev, skip_missed_rays=True, want_coords=True)     # view-direction decoder: staged path only
-        return
+    vd = 'viewdir_x' in t          # --use_viewdir (carla): semantics / coords from the same launch too (fp32 texels), normals staged
     plain = hip_render(meta, t, dev, skip_missed_rays=True)
     want_sem = meta['A'] > 0 and not meta.get('coords')
-    for texel_dtype in (ops.TEXEL_F32, ops.TEXEL_F16):
+    for texel_dtype in ((ops.TEXEL_F32,) if vd else (ops.TEXEL_F32, ops.TEXEL_F16)):
         base = plain if texel_dtype == ops.TEXEL_F32 else hip_render(meta, t, dev, skip_missed_rays=True, texel_dtype=texel_dtype)
         r = hip_render(meta, t, dev, skip_missed_rays=True, texel_dtype=texel_dtype, want_semantics=want_sem, want_coords=True)
         for k in ('rgb', 'depth', 'mask'):
@@ -323,6 +320,12 @@ def test_fused_render_extra_maps(case):
         if meta.get('coords'):
             close(r['coords'], o['semantics'], 1e-5, 'coords map (oracle render)')
             close(r['coords'], t['ref_coords_map'], 1e-5, 'coords map vs committed reference output')
+    if vd:
+        with pytest.raises((RuntimeError, ValueError)):
+            hip_render(meta, t, dev, skip_missed_rays=True, want_normals=True)       # staged path only (render.py)
+        with pytest.raises(RuntimeError):
+            hip_render(meta, t, dev, skip_missed_rays=True, texel_dtype=ops.TEXEL_F16, want_coords=True)
+        return
     if meta['sdf']:
         # the normal map (compute_normals): the kernel's analytic d sdf / d x against autograd of the oracle's distance,
         # composited with the oracle's weights (lib/nerf_utils.py:149-151, 159); unit vectors from fp32 texel differences

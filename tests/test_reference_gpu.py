@@ -75,6 +75,11 @@ def test_view_direction_decoder_matches_the_real_reference(gpu_device):
     sc = rc.build_scene('carla', 2, gpu_device)
     rep = rc.compare(sc, 64, 32, cpu_images=1)
     _check(rep)
+    # the eval callers on carla (run.py:1444-1454, 2036-2051): semantics / coords with the view-direction decoder, composited
+    # by the fused kernel itself since round 5 (ONE render launch; the normal map stays staged)
+    for kw in (dict(compute_semantics=True), dict(compute_coords=True)):
+        rep = rc.compare(sc, 64, 32, cpu_images=1, **kw)
+        _check(rep, ('rgb', 'depth', 'mask', 'extra'))
 
 
 @pytest.mark.parametrize('geometry', ['chairs', 'p3d', 'cub'])

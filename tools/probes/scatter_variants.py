@@ -13,6 +13,14 @@ sys.path.insert(0, ROOT)
 OUT = os.path.join(ROOT, 'build', 'variants')
 VARIANTS = {
     'base': [],
+    # round 5: moments instead of corner sums in the reduce's walk, one upstream-gradient peek per chunk, the gather of the
+    # field backward at raised issue priority
+    'moments': ['-DNFI_BIN_MOMENTS'], 'peek': ['-DNFI_BWD_CHUNK_PEEK'], 'prio': ['-DNFI_BWD_GATHER_PRIO'],
+    'depth8': ['-DNFI_BIN_DEPTH=8'], 'depth32': ['-DNFI_BIN_DEPTH=32'], 'reload16': ['-DNFI_BIN_RELOAD'],
+    'reload32': ['-DNFI_BIN_RELOAD', '-DNFI_BIN_DEPTH=32'], 'reload64': ['-DNFI_BIN_RELOAD', '-DNFI_BIN_DEPTH=64'],
+    'q16': ['-DNFI_ROWS_Q16_DEFAULT'], 'q16_g2': ['-DNFI_ROWS_Q16_DEFAULT', '-DNFI_BIN_ROW_BYTES=64'],
+    'q16_all': ['-DNFI_ROWS_Q16_DEFAULT', '-DNFI_BIN_ROW_BYTES=64', '-DNFI_BIN_MOMENTS', '-DNFI_BWD_CHUNK_PEEK'],
+    'r5all': ['-DNFI_BIN_MOMENTS', '-DNFI_BWD_CHUNK_PEEK', '-DNFI_BWD_GATHER_PRIO'],
     # round 4: point groups of the binned scatter (rows of a group <= N MB: 268 MB per scene in the training step -> 1 / 2 /
     # 4 / 8 / 16 groups), 16- or 8-texel tiles for the grouped buckets.  The two macros existed in nfi_backward_field.inc
     # for this measurement only (profiles/r4/scatter_point_groups.log); the product has the winner (80 MB, 16) hard-wired.

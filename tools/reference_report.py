@@ -32,6 +32,8 @@ def main():
     rep['forward']['p3d_b4_coords'] = rc.compare(sc, 128, 64, cpu_images=1, compute_coords=True)
     sc = rc.build_scene('carla', 2, dev)
     rep['forward']['carla_viewdir_b2_64px_32+32'] = rc.compare(sc, 64, 32, cpu_images=1)
+    rep['forward']['carla_viewdir_b2_semantics'] = rc.compare(sc, 64, 32, cpu_images=1, compute_semantics=True)
+    rep['forward']['carla_viewdir_b2_coords'] = rc.compare(sc, 64, 32, cpu_images=1, compute_coords=True)
     sc = rc.build_scene('chairs', 2, dev)
     rep['forward']['chairs_b2_normals_64px_32+32'] = rc.compare(sc, 64, 32, cpu_images=2, grad=True, compute_normals=True)
     for geometry in ('chairs', 'p3d', 'cub'):
