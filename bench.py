@@ -584,8 +584,8 @@ def main():
     def prepare(v, slot_ws=None):
         """Everything of a step in front of the render kernel: texel hand-off of the producer's planes, decoder operand
         image, the two noise draws, the ray set-up (rays, scene-cube test, miss-fill reduction) into the slot's workspace."""
-        dv = v['d']
-        return dict(texels=ops.planes_to_texels(dv['planes'], tdt), image=ops.decoder_pack(dv['w1'], dv['b1'], dv['w2'], dv['b2'], A, tdt),
+        dv, vt = v['d'], v.get('tdt', tdt)
+        return dict(texels=ops.planes_to_texels(dv['planes'], vt), image=ops.decoder_pack(dv['w1'], dv['b1'], dv['w2'], dv['b2'], A, vt),
                     noise_c=torch.rand((B, R, R, S), dtype=torch.float32, device=dev),
                     noise_f=torch.rand([n_rays, S], dtype=torch.float32, device=dev),
                     ws=ops.render_setup(dv['cam'], dv['focal'], R, R, SCENE_RANGE, workspace=slot_ws))
@@ -688,8 +688,12 @@ def main():
 
     variants = {}
     if not args.no_variants:
-        for name, v, pl in (('mlp_exact_fp32', {'d': d, 'tuning': 8}, pipelined), ('all_rays_hit', {'d': d_hit, 'tuning': 0}, pipelined),
-                            ('pipelined' if not pipelined else 'serial', {'d': d, 'tuning': 0}, not pipelined)):
+        legs = [('mlp_exact_fp32', {'d': d, 'tuning': 8}, pipelined), ('all_rays_hit', {'d': d_hit, 'tuning': 0}, pipelined),
+                ('pipelined' if not pipelined else 'serial', {'d': d, 'tuning': 0}, not pipelined)]
+        if args.texels == 'fp32':
+            # BASELINE cfg2 names bf16: the same whole step with the triplanes handed over as bf16 texels (arithmetic fp32)
+            legs.append(('bf16_texels', {'d': d, 'tuning': 0, 'tdt': ops.TEXEL_BF16}, pipelined))
+        for name, v, pl in legs:
             e_v, per_v, _ = timed(v, pl)
             variants[name] = {'value': world * n_rays * args.steps / e_v, 'ms_per_step': e_v / args.steps * 1e3,
                               'ms_per_step_stats': stats(per_v)}
@@ -757,10 +761,13 @@ def main():
             cfg['value_' + other] = variants[other]['value']
             cfg['value_mlp_exact_fp32'] = variants['mlp_exact_fp32']['value']
             cfg['value_all_rays_hit'] = variants['all_rays_hit']['value']
+            if 'bf16_texels' in variants:
+                cfg['value_bf16_texels'] = variants['bf16_texels']['value']
             cfg['rays_marched_fraction_all_rays_hit'] = marched_rays(d_hit) / n_rays
             res['variants'] = dict(variants, note='the SAME whole step, K, warm-up and max-over-ranks protocol as `value`: '
                                    'mlp_exact_fp32 = decoder MLP on v_mfma_f32_16x16x4_f32 (tuning bit 3), the strictly-fp32 '
-                                   'rate; all_rays_hit = cameras at radius 1.3, every ray crosses the scene cube; %s = %s'
+                                   'rate; all_rays_hit = cameras at radius 1.3, every ray crosses the scene cube; bf16_texels = the triplanes handed over '
+                                   'as bf16 texels (the storage type BASELINE cfg2 names; arithmetic fp32, parity against the rounded planes); %s = %s'
                                    % (other, two_stream if other == 'pipelined' else 'one stream'))
         res['roofline'] = roofline(kernel_ms, marched, B, live_clock, args.texels)
         res['kernel_ms_stats'] = stats(k_ms)

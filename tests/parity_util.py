@@ -49,3 +49,23 @@ def err(a, b):
     fin = torch.isfinite(d)
     return dict(max=float(d[fin].max()) if fin.any() else 0.0, mean=float(d[fin].mean()) if fin.any() else 0.0,
                 exact=float((a == b).float().mean()), nonfinite=int((~fin).sum()))
+
+
+def oracle_normal_map(meta, t, o):
+    """The composited normal map of a golden case as the reference computes it (generator.py:599-623 + lib/nerf_utils.py:
+    149-151, 159): autograd of the oracle's distance at every sample, normalised, composited with the oracle's weights."""
+    def oracle_normals(pts):
+        p = pts.clone().requires_grad_()
+        q = orc.field_query(t['planes'], t['w1'], t['b1'], t['w2'], t['b2'], p, meta['scene_range'], True, t['beta'],
+                            t['alpha'], t.get('attention_values'))
+        gx, = torch.autograd.grad(q['sdf'].sum(), p)
+        return torch.nn.functional.normalize(gx, dim=-1)
+    B, H, W = meta['B'], meta['H'], meta['W']
+    n_all = oracle_normals(orc.points_on_rays(o['ro'], o['rd'], o['t_coarse']).reshape(B, -1, 3)).view(B, H, W, -1, 3)
+    if meta['fine']:
+        n_f = oracle_normals(orc.points_on_rays(o['ro'], o['rd'], o['t_fine']).reshape(B, -1, 3)).view(B, H, W, -1, 3)
+        n_all = torch.cat((n_all, n_f), dim=-2).gather(-2, o['perm'].unsqueeze(-1).expand(-1, -1, -1, -1, 3))
+    ref_map = (o['weights'][..., None] * n_all).sum(dim=-2)
+    if meta['white']:
+        ref_map = ref_map + (1. - o['mask'][..., None])
+    return ref_map

@@ -243,7 +243,7 @@ def gradients(sc, res, samples, seed=5):
                 sc.ws, sc.cam, sc.focal = keep
         loss = (out[0] * w_rgb).sum() + (out[2] * w_mask).sum()
         loss.backward()
-        return float(loss), ws.grad, cam.grad, None if focal is None else focal.grad
+        return float(loss.detach()), ws.grad, cam.grad, None if focal is None else focal.grad
     for mod in (sc.gen, sc.hip):
         mod.requires_grad_(False)
     l_h, gws_h, gcam_h, gf_h = run('hip')
@@ -277,3 +277,82 @@ def generator_from_tensors(planes, w1, b1, w2, b2, beta, alpha, scene_range, dev
 
 def dummy_ws(batch, device):
     return torch.zeros(batch, 15, 512, device=device)
+
+
+def _psnr_iou(rgb, mask, t_rgb, t_mask):
+    """lib/metrics.py psnr (images in [-1, 1]: peak-to-peak 2) and iou of the thresholded masks, batch means."""
+    mse = ((rgb - t_rgb) ** 2).flatten(1).mean(1) / 4.0
+    psnr = float((-10.0 * torch.log10(mse.clamp_min(1e-10))).mean())
+    a, b = mask > 0.5, t_mask > 0.5
+    iou = float(((a & b).flatten(1).sum(1).float() / (a | b).flatten(1).sum(1).clamp_min(1).float()).mean())
+    return psnr, iou
+
+
+def inversion(sc, res, samples, steps=8, lr=2e-3, seed=11):
+    """The --run_inversion loop's shape (run.py:2232-2299) on the REAL Generator with a synthetic target: the target is the
+    reference's own render of the scene; latents and camera start perturbed; Adam(lr, betas 0.9 / 0.95, run.py:2007) on
+    ws + camera matrix (+ focal) for `steps` steps, fresh noise every step.
+
+    Adam normalises the update, so free-running trajectories are chaotic; what is compared without chaos is, at every
+    point of the REFERENCE's trajectory, the loss and the gradients of the HIP path at the same parameters and noise.
+    The HIP path also runs its own trajectory (its own Adam), for the PSNR / IoU figures.  Returns a dict."""
+    g = torch.Generator().manual_seed(seed)
+    dev = sc.dev
+    with torch.no_grad():
+        tgt = reference_render(sc, res, samples, draw_noise(sc, res, samples, seed=1000))
+    t_rgb, t_mask = tgt[0].detach(), tgt[2].detach()
+    ws0 = sc.ws + 0.25 * torch.randn(sc.ws.shape, generator=g).to(dev) * sc.ws.std()
+    cam0 = sc.cam.clone()
+    cam0[:, :3, 3] += 0.03 * torch.randn(sc.batch, 3, generator=g).to(dev)
+    focal0 = None if sc.focal is None else sc.focal * (1.0 + 0.02 * torch.randn(sc.batch, generator=g).to(dev))
+    for mod in (sc.gen, sc.hip):
+        mod.requires_grad_(False)
+
+    def make_params():
+        p = [ws0.clone().requires_grad_(), cam0.clone().requires_grad_()]
+        if focal0 is not None:
+            p.append(focal0.clone().requires_grad_())
+        return p
+
+    def forward(which, params, noise):
+        ws, cam = params[0], params[1]
+        focal = params[2] if len(params) > 2 else None
+        if which == 'hip':
+            out = hip_render(sc, res, samples, noise, grad=True, ws=ws, cam=cam, focal=focal)
+        else:
+            keep = sc.ws, sc.cam, sc.focal
+            sc.ws, sc.cam, sc.focal = ws, cam, focal
+            try:
+                out = reference_render(sc, res, samples, noise, grad=True)
+            finally:
+                sc.ws, sc.cam, sc.focal = keep
+        loss = ((out[0] - t_rgb) ** 2).mean() + ((out[2] - t_mask) ** 2).mean()
+        return loss, out
+
+    def grads_of(which, params, noise):
+        for p in params:
+            p.grad = None
+        loss, out = forward(which, params, noise)
+        loss.backward()
+        return float(loss.detach()), [p.grad.clone() for p in params], _psnr_iou(out[0].detach(), out[2].detach(), t_rgb, t_mask)
+
+    p_ref, p_hip = make_params(), make_params()
+    opt_ref = torch.optim.Adam(p_ref, lr=lr, betas=(0.9, 0.95))
+    opt_hip = torch.optim.Adam(p_hip, lr=lr, betas=(0.9, 0.95))
+    along, traj_ref, traj_hip = [], [], []
+    for step in range(steps):
+        noise = draw_noise(sc, res, samples, seed=2000 + step)
+        # the HIP path at the reference trajectory's parameters (shadow copies: no optimiser state involved)
+        shadow = [p.detach().clone().requires_grad_() for p in p_ref]
+        l_h, g_h, _ = grads_of('hip', shadow, noise)
+        l_r, g_r, m_r = grads_of('ref', p_ref, noise)
+        along.append({'loss_rel': abs(l_h - l_r) / abs(l_r), 'g_ws': rel_err(g_h[0], g_r[0]), 'g_cam': rel_err(g_h[1][:, :3], g_r[1][:, :3]),
+                      **({'g_focal': rel_err(g_h[2], g_r[2])} if len(g_r) > 2 else {})})
+        for p, gr in zip(p_ref, g_r):
+            p.grad = gr
+        opt_ref.step()
+        traj_ref.append((l_r,) + m_r)
+        l_o, g_o, m_o = grads_of('hip', p_hip, noise)
+        opt_hip.step()
+        traj_hip.append((l_o,) + m_o)
+    return {'along_reference_trajectory': along, 'reference': traj_ref, 'hip': traj_hip}

@@ -97,6 +97,22 @@ def test_gradients_match_the_real_reference(gpu_device, geometry):
         assert rep['g_focal'] <= 1e-2, rep
 
 
+def test_inversion_steps_match_the_real_reference(gpu_device):
+    """BASELINE cfg3's loop on the real Generator at size (p3d_car-like geometry, 4 images x 128 x 128 x (64 + 64), Adam on
+    latents + camera + focal, run.py:2232-2299) with a synthetic target (no p3d_car data / checkpoint exists offline): at
+    every point of the REFERENCE's trajectory the HIP path gives the same loss and gradients, and its own trajectory
+    reaches the same PSNR / IoU."""
+    _require_reference()
+    sc = rc.build_scene('p3d', 4, gpu_device)
+    r = rc.inversion(sc, 128, 64, steps=8)
+    for a in r['along_reference_trajectory']:
+        assert a['loss_rel'] <= 1e-4 and a['g_ws'] <= 2e-3 and a['g_cam'] <= 1e-2 and a.get('g_focal', 0.0) <= 1e-2, a
+    (l0, p0, i0), (l1, p1, i1) = r['reference'][0], r['reference'][-1]
+    (h0, q0, j0), (h1, q1, j1) = r['hip'][0], r['hip'][-1]
+    assert l1 < l0 and h1 < h0, (r['reference'], r['hip'])                 # both descend
+    assert abs(q1 - p1) <= 0.5 and abs(j1 - i1) <= 0.02, (r['reference'][-1], r['hip'][-1])
+
+
 def test_same_seed_gives_the_reference_noise(gpu_device):
     """No interception: the SCRIPTED reference (as run.py runs it) and the drop-in after the same torch.manual_seed draw
     the same two noise tensors from PyTorch-ROCm's Philox stream (same shapes, same order: lib/nerf_utils.py:115, 202)."""

@@ -1,6 +1,6 @@
 #!/bin/bash
 # One GPU-box session: tests, parity report, bench (render + train), rocprofv3 stats + PMC of the render kernel.
-# usage (via gpurun): bash tools/gpu_session.sh <tag> [what...]   what: tests report bench train pmc pmc_bwd bwd handoff prof_inv prof_train prof_bench regulariser train_bwd stress   (default: tests report bench train pmc)
+# usage (via gpurun): bash tools/gpu_session.sh <tag> [what...]   what: tests report refreport bench train pmc pmc_bwd bwd handoff prof_inv prof_train prof_bench regulariser train_bwd stress   (default: tests report bench train pmc)
 TAG=${1:-s}
 shift
 WHAT=${@:-tests report bench train pmc}
@@ -9,7 +9,7 @@ O=$R/gpurun_out/$TAG
 mkdir -p $O
 cd $R
 export HSA_ENABLE_IPC_MODE_LEGACY=0
-echo "reference checkout on the GPU box: $(ls -d /root/reference 2>&1)" > $O/env.txt
+echo "reference checkout on the GPU box: $(ls -d /root/reference 2>&1); staged copy: $(python oracle/make_ref.py --check 2>&1)" > $O/env.txt
 rocm-smi --showproductname 2>/dev/null | head -8 >> $O/env.txt
 nproc >> $O/env.txt
 for w in $WHAT; do
@@ -18,6 +18,8 @@ for w in $WHAT; do
       timeout 1500 python -m pytest tests -m gpu -q --durations=15 > $O/pytest.log 2>&1; echo "pytest rc=$?" >> $O/env.txt; tail -5 $O/pytest.log;;
     report)
       timeout 600 python tools/parity_report.py > $O/parity_report.json 2> $O/parity_report.err; echo "report rc=$?" >> $O/env.txt;;
+    refreport)
+      timeout 600 python tools/reference_report.py > $O/reference_parity.json 2> $O/reference_parity.err; echo "refreport rc=$?" >> $O/env.txt;;
     bench)
       timeout 900 python bench.py > $O/bench.json 2> $O/bench.err; echo "bench rc=$?" >> $O/env.txt; tail -c 600 $O/bench.json;;
     train)

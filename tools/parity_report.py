@@ -14,7 +14,7 @@ import torch  # noqa: E402
 
 def main():
     from conftest import golden_case_names, load_golden
-    from parity_util import err, hip_render, oracle_render
+    from parity_util import err, hip_render, oracle_normal_map, oracle_render
     from nerf_from_image_amd import ops
     from oracle import nfi_oracle as orc
     import test_hip_full_size as fs
@@ -38,6 +38,12 @@ def main():
             _, taps = ops.resample(o['sigma_coarse'].to(dev), o['rd'].to(dev), o['t_coarse'].to(dev), u, want_taps=True)
             e['inds_flip_rate'] = float((taps['inds'].cpu() != o['inds']).float().mean())
             e['t_fine'] = err(r['t_fine'], o['t_fine'])['max']
+        if meta['sdf'] and 'viewdir_x' not in t and meta['S'] <= 128:
+            # the composited normal map (fused kernel, analytic derivative) against autograd of the oracle's distance
+            ref_map = oracle_normal_map(meta, t, o)
+            e['normal_map'] = err(hip_render(meta, t, dev, skip_missed_rays=True, want_normals=True)['normals'], ref_map)['max']
+            e16 = err(hip_render(meta, t, dev, skip_missed_rays=True, texel_dtype=ops.TEXEL_F16, want_normals=True)['normals'], ref_map)
+            e['normal_map_fp16_texels_max'], e['normal_map_fp16_texels_mean'] = e16['max'], e16['mean']
         rep[name] = e
     for tag, B, radius, seed, R, S in (('cfg2_b1', 1, 1.6, 1234, 128, 64), ('cfg2_b8_chairs', 8, 2.0, 1234, 128, 64),
                                        ('cfg2_b8_all_hit', 8, 1.3, 77, 128, 64), ('cfg5_b1', 1, 1.6, 1234, 256, 128)):
