@@ -69,7 +69,7 @@ MFMA_F32_PEAK_TFLOPS = 157.3
 MFMA_F16_PEAK_TFLOPS = 2500.0
 MLP_FLOP_PER_RAY = 704512
 N_SIMD = 1024
-PMC_PROFILES = ('profiles/r4/pmc_render_fwd.json', 'profiles/r3/pmc_render_fwd.json', 'profiles/r2/pmc_render_fwd.json', 'profiles/r1/pmc_render_fwd_derived.json')
+PMC_PROFILES = ('profiles/r5/pmc_render_fwd.json', 'profiles/r4/pmc_render_fwd.json', 'profiles/r3/pmc_render_fwd.json', 'profiles/r2/pmc_render_fwd.json', 'profiles/r1/pmc_render_fwd_derived.json')
 
 
 def cameras(n, radius, gen):
@@ -416,7 +416,7 @@ def extras(dev, ops):
 
 
 def load_pmc_profile(texels='fp32'):
-    for rel in (PMC_PROFILES if texels == 'fp32' else ('profiles/r4/pmc_render_fwd_%s.json' % texels, 'profiles/r3/pmc_render_fwd_%s.json' % texels)):
+    for rel in (PMC_PROFILES if texels == 'fp32' else ('profiles/r5/pmc_render_fwd_%s.json' % texels, 'profiles/r4/pmc_render_fwd_%s.json' % texels, 'profiles/r3/pmc_render_fwd_%s.json' % texels)):
         p = os.path.join(ROOT, rel)
         if os.path.exists(p):
             try:

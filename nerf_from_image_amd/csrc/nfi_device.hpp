@@ -679,7 +679,8 @@ __device__ __forceinline__ void tile_gather_two_rounds(const FieldParams& P, int
 // density / colour epilogue on the decoder outputs o (lane (g,j): rows 4g..4g+3 of point j; row 0 =
 // distance/density, rows 1.. = colour logits pre-scaled by log2e)
 // SEMP: where the softmax probabilities of a point go.  0: sem[n] is a global row [A] (the sampler closure's
-// 'semantics' output); > 0: sem[n] addresses the point's column of a per-wave LDS table [A][SEMP] (attribute-major, the
+// 'semantics' output); < 0: the same table with unorm16 entries, pitch -SEMP (tile_epilogue); > 0: sem[n] addresses the
+// point's column of a per-wave LDS table [A][SEMP] (attribute-major, the
 // fused renderer composites it after the merge; the pitch makes the four channel groups' stores conflict-free).
 template <bool ATT, int N, int SEMP = 0>
 __device__ __forceinline__ void tile_epilogue(const FieldParams& P, int lane, const f32x4 (&o)[N], const float (&outside)[N],
@@ -738,6 +739,12 @@ __device__ __forceinline__ void tile_epilogue(const FieldParams& P, int lane, co
             // explicit LDS address space: a ds_write, ordered with the wave's other LDS traffic (a flat store is not)
             auto* q = (__attribute__((address_space(3))) float*)sem[n];
             if (row >= 1 && row <= A) q[(row - 1) * SEMP] = e4[r] * inv;
+          } else if constexpr (SEMP < 0) {
+            // 16-bit table (the 128 + 128 kernel: half the LDS, two workgroups per CU): unorm16, p = q / 65535,
+            // |error| <= 7.7e-6 per sample - and the composited map is a convex combination of the samples
+            auto* q = (__attribute__((address_space(3))) unsigned short*)sem[n];
+            const float pq = fminf(__builtin_rintf(e4[r] * inv * 65535.0f), 65535.0f);
+            if (row >= 1 && row <= A) q[(row - 1) * (-SEMP)] = (unsigned short)(int)pq;
           } else {
             if (row >= 1 && row <= A) sem[n][row - 1] = e4[r] * inv;
           }
@@ -1172,10 +1179,13 @@ __device__ __forceinline__ SampleOut field_wave(const FieldParams& P, float scen
     __builtin_amdgcn_s_setprio(0);
     const float outs[2] = {(fa & 1) ? 1.0f : 0.0f, (fb & 1) ? 1.0f : 0.0f};
     // a point's semantics: row [A] of the global output, or its column of the wave's LDS table (SEMP > 0)
-    const size_t sem_pt = SEMP > 0 ? (size_t)1 : (size_t)P.n_attention;
-    float* const sems[2] = {
-        (sem_base && (fa & 2)) ? sem_base + (size_t)(16 * ta + j) * sem_pt : nullptr,
-        (sem_base && pair && (fb & 2)) ? sem_base + (size_t)(16 * tb + j) * sem_pt : nullptr};
+    // (SEMP < 0: a table of 16-bit entries - the pointer only carries the column's address to tile_epilogue)
+    const size_t sem_pt = SEMP != 0 ? (size_t)1 : (size_t)P.n_attention;
+    auto sem_col = [&](int t) -> float* {
+      if constexpr (SEMP < 0) return reinterpret_cast<float*>(reinterpret_cast<unsigned short*>(sem_base) + (16 * t + j));
+      else return sem_base + (size_t)(16 * t + j) * sem_pt;
+    };
+    float* const sems[2] = {(sem_base && (fa & 2)) ? sem_col(ta) : nullptr, (sem_base && pair && (fb & 2)) ? sem_col(tb) : nullptr};
     TileOut to[2];
     if constexpr (VD) {
       static_assert(PREC == 0 && !NRM, "the view-direction decoder exists in exact fp32 only, without the normal map");

@@ -1451,7 +1451,11 @@ struct RayQueue {
 //                 normalize(d sdf / d x) from the analytic derivative of the decoder (field_wave<..., NRM>), composited
 //                 with the merged weights in source order like the semantics
 constexpr int kRenderPlain = 0, kRenderTaps = 1, kRenderProf = 2, kRenderTerm = 3, kRenderExtra = 4, kRenderNormals = 5;
-constexpr int kSemPitch = 2 * 64 + 4, kSemPitchWide = 2 * 128 + 4;   // pitch = 4 (mod 64): conflict-free stores from the MFMA layout
+constexpr int kSemPitch = 2 * 64 + 4;                 // pitch = 4 (mod 64) dwords: conflict-free stores from the MFMA layout
+// the 128 + 128 kernel parks the probabilities as unorm16 (tile_epilogue<SEMP < 0>): 41.6 KB of fp32 tables left room for ONE
+// workgroup per CU next to the 47 KB of slabs and operands; 21 KB let two in (cfg5 + semantics 0.59 -> see DESIGN 4.2a).
+// Pitch in 16-bit entries: 4 rows = 528 dwords = 16 (mod 64), the four row groups' stores fall into different banks
+constexpr int kSemPitchWide = 2 * 128 + 8;
 // dynamic LDS of the kRenderExtra / kRenderNormals kernels: [normal operands: kNrmLdsFloats, kRenderNormals only]
 // [semantics tables: 4 waves x A x pitch floats, when asked for]
 extern __shared__ __attribute__((aligned(16))) float nfi_dyn_lds[];
@@ -1764,7 +1768,7 @@ template <int TEX, bool ATT, int MODE, int PREC, bool VD = false, int OCC = NFI_
 __global__ __launch_bounds__(256, OCC) void render_fwd_wide_kernel(RenderKernelParams k) {
   constexpr bool TAPS = MODE == kRenderTaps, TERM = MODE == kRenderTerm;
   constexpr bool EXTRA = MODE == kRenderExtra || MODE == kRenderNormals, NRM = MODE == kRenderNormals;
-  constexpr int SEMP = (EXTRA && ATT) ? kSemPitchWide : 0;
+  constexpr int SEMP = (EXTRA && ATT) ? -kSemPitchWide : 0;        // < 0: 16-bit table entries
   constexpr int kImg = VD ? kVdImageFloats : kLdsImageFloats;
   __shared__ __attribute__((aligned(16))) float lds[kImg];
   __shared__ __attribute__((aligned(16))) float vfs[4][64];
@@ -1801,14 +1805,20 @@ __global__ __launch_bounds__(256, OCC) void render_fwd_wide_kernel(RenderKernelP
   P.w1t = nfi_dyn_lds; P.w2r0 = nfi_dyn_lds + kW1TFloats;       // (kRenderNormals only)
   int cur_scene = -1;
   // kRenderExtra: this wave's semantics table [A][kSemPitchWide], column = sample: coarse [0,128), fine [128,256)
+  typedef __attribute__((address_space(3))) unsigned short lds_u16;
   float* semT = nullptr;
-  if constexpr (SEMP > 0) {
+  if constexpr (SEMP != 0) {
     if (k.semantics) {
-      semT = nfi_dyn_lds + (NRM ? kNrmLdsFloats : 0) + wave * (k.A * kSemPitchWide);
-      for (int i = lane; i < k.A * kSemPitchWide; i += 64) ((lds_float*)semT)[i] = 0.0f;
+      semT = reinterpret_cast<float*>(reinterpret_cast<unsigned short*>(nfi_dyn_lds + (NRM ? kNrmLdsFloats : 0)) +
+                                      wave * (k.A * kSemPitchWide));
+      for (int i = lane; i < k.A * kSemPitchWide / 2; i += 64) ((lds_float*)semT)[i] = 0.0f;
       wave_lds_fence();
     }
   }
+  // column `c` of the table (16-bit entries), as the pointer field_wave hands to tile_epilogue
+  auto sem_col = [&](int c) -> float* {
+    return semT ? reinterpret_cast<float*>(reinterpret_cast<unsigned short*>(semT) + c) : nullptr;
+  };
   RayQueue queue(k, lane);
   uint32_t cur = queue.fetch(), nxt = 0;
   while (cur < n_rays) {
@@ -1882,7 +1892,7 @@ __global__ __launch_bounds__(256, OCC) void render_fwd_wide_kernel(RenderKernelP
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
         SampleOut q = field_wave<TEX, ATT, true, PREC, VD, SEMP, NRM>(P, k.scene_range, lane, ox + dx * tc[j], oy + dy * tc[j],
-                                                                      oz + dz * tc[j], val[j], semT ? semT + j * 64 : nullptr, nullptr,
+                                                                      oz + dz * tc[j], val[j], sem_col(j * 64), nullptr,
                                                                       stage, nullptr, k.xray, (int)ray);
         sc[j] = q.sigma; rc[j] = q.r; gc[j] = q.g; bc[j] = q.b;
         if constexpr (NRM) { nrm[j][0] = q.nx; nrm[j][1] = q.ny; nrm[j][2] = q.nz; }
@@ -1934,7 +1944,7 @@ __global__ __launch_bounds__(256, OCC) void render_fwd_wide_kernel(RenderKernelP
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
           SampleOut q = field_wave<TEX, ATT, true, PREC, VD, SEMP, NRM>(P, k.scene_range, lane, ox + dx * tf[j], oy + dy * tf[j],
-                                                                        oz + dz * tf[j], vfine[j], semT ? semT + 128 + j * 64 : nullptr,
+                                                                        oz + dz * tf[j], vfine[j], sem_col(128 + j * 64),
                                                                         nullptr, stage, nullptr, k.xray, (int)ray);
           if (TERM && !vfine[j]) { q.sigma = 0.0f; q.r = 0.0f; q.g = 0.0f; q.b = 0.0f; }
           if constexpr (NRM) { nrm[2 + j][0] = q.nx; nrm[2 + j][1] = q.ny; nrm[2 + j][2] = q.nz; }
@@ -1971,7 +1981,7 @@ __global__ __launch_bounds__(256, OCC) void render_fwd_wide_kernel(RenderKernelP
       if constexpr (EXTRA) {
         if (k.coords) composite_coords<4>(slab, w, n, lane, ox, oy, oz, dx, dy, dz, k.coords + (size_t)ray * 3);
         float ws[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-        if ((SEMP > 0 && semT) || NRM) {
+        if ((SEMP != 0 && semT) || NRM) {
           // the merged weights back in source order (the cdf row is free after the merge)
           wave_lds_fence();
 #pragma unroll
@@ -1991,14 +2001,14 @@ __global__ __launch_bounds__(256, OCC) void render_fwd_wide_kernel(RenderKernelP
             m3[c] = wave_sum((ws[0] * nrm[0][c] + ws[1] * nrm[1][c]) + (ws[2] * nrm[2][c] + ws[3] * nrm[3][c])) + bgn;
           if (lane == 0) { float* q = k.normals + (size_t)ray * 3; q[0] = m3[0]; q[1] = m3[1]; q[2] = m3[2]; }
         }
-        if constexpr (SEMP > 0) {
+        if constexpr (SEMP != 0) {
           if (semT) {
-            const lds_float* sl = (const lds_float*)semT;
+            const lds_u16* sl = (const lds_u16*)semT;
             float mine = 0.0f;
             for (int a = 0; a < k.A; ++a) {
-              const lds_float* row = sl + a * kSemPitchWide + lane;
-              const float sa = wave_sum((ws[0] * row[0] + ws[1] * row[64]) + (ws[2] * row[128] + ws[3] * row[192]));
-              if (lane == a) mine = sa;
+              const lds_u16* row = sl + a * kSemPitchWide + lane;
+              const float sa = wave_sum((ws[0] * (float)row[0] + ws[1] * (float)row[64]) + (ws[2] * (float)row[128] + ws[3] * (float)row[192]));
+              if (lane == a) mine = sa * (1.0f / 65535.0f);
             }
             if (lane < k.A) k.semantics[(size_t)ray * k.A + lane] = mine;
           }
@@ -2346,10 +2356,10 @@ extern "C" int nfi_render_fwd(const nfi_render_args* a, nfi_stream_t stream) {
   //  tiles - was measured in round 4 and is slower: 1.387 vs 1.300 ms chairs-like, 2.249 vs 2.156 ms every ray hits, images
   //  identical (profiles/r4/wide_fp16_three_workgroups.log); unlike the 64 + 64 kernel, whose fp16 form gains 8 % from the
   //  third workgroup, a 256-sample ray's texel footprint makes 50 % more rays in flight cost more in the L2 than they hide)
-  const size_t sem_lds = (a->semantics ? (size_t)4 * a->n_attention * (wide ? kSemPitchWide : kSemPitch) * sizeof(float) : 0) +
+  const size_t sem_lds = (a->semantics ? (size_t)4 * a->n_attention * (wide ? kSemPitchWide * sizeof(unsigned short) : kSemPitch * sizeof(float)) : 0) +
                          (a->normals ? (size_t)kNrmLdsFloats * sizeof(float) : 0);
   constexpr size_t kSemLdsMax = ((size_t)4 * NFI_MAX_ATTENTION * kSemPitch + kNrmLdsFloats) * sizeof(float);
-  constexpr size_t kSemLdsMaxWide = ((size_t)4 * NFI_MAX_ATTENTION * kSemPitchWide + kNrmLdsFloats) * sizeof(float);
+  constexpr size_t kSemLdsMaxWide = (size_t)4 * NFI_MAX_ATTENTION * kSemPitchWide * sizeof(unsigned short) + kNrmLdsFloats * sizeof(float);
   if (a->event_start) (void)hipEventRecord((hipEvent_t)a->event_start, s);
 #define NFI_LAUNCH_RENDER(TEX, ATT)                                                                                   \
   do {                                                                                                                \

@@ -26,15 +26,18 @@ for w in $WHAT; do
       timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29541 \
         bench.py --gpus 1 --mode train --steps 30 --warmup 5 --force-dist > $O/train.json 2> $O/train.err; echo "train rc=$?" >> $O/env.txt; tail -c 1500 $O/train.json;;
     pmc)
-      timeout 1200 python tools/pmc_collect.py --kernel render_fwd_kernel --out $O/pmc_render_fwd.json --marched-from-bench -- \
+      timeout 1200 python tools/pmc_collect.py --workdir /tmp/pmc_fwd --kernel render_fwd_kernel --out $O/pmc_render_fwd.json --marched-from-bench -- \
         python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras --no-variants > $O/pmc.log 2>&1; echo "pmc rc=$?" >> $O/env.txt; tail -30 $O/pmc.log;;
+    pmc_bf16)
+      timeout 1200 python tools/pmc_collect.py --workdir /tmp/pmc_bf16 --kernel render_fwd_kernel --out $O/pmc_render_fwd_bf16.json --marched-from-bench -- \
+        python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras --no-variants --texels bf16 > $O/pmc_bf16.log 2>&1; echo "pmc_bf16 rc=$?" >> $O/env.txt; tail -12 $O/pmc_bf16.log;;
     pmc_bwd)
       # the field backward kernel inside the training step (4 images x 128x128 rays x (64 + 64) samples: ONE launch since the one-node render)
-      timeout 1200 python tools/pmc_collect.py --kernel field_query_bwd_kernel --out $O/pmc_backward.json --units 8388608 -- \
+      timeout 1200 python tools/pmc_collect.py --workdir /tmp/pmc_bwd --kernel field_query_bwd_kernel --out $O/pmc_backward.json --units 8388608 -- \
         python $R/bench.py --mode train --steps 4 --warmup 2 > $O/pmc_bwd.log 2>&1; echo "pmc_bwd rc=$?" >> $O/env.txt; tail -30 $O/pmc_bwd.log;;
     pmc_reduce)
       # the scatter's reduce kernel inside the training step: 4 scenes x 8.4 M points x 3 planes = 25.2 M entries per launch
-      timeout 1200 python tools/pmc_collect.py --kernel bin_reduce_kernel --out $O/pmc_bin_reduce.json --units 25165824 -- \
+      timeout 1200 python tools/pmc_collect.py --workdir /tmp/pmc_red --kernel bin_reduce_kernel --out $O/pmc_bin_reduce.json --units 25165824 -- \
         python $R/bench.py --mode train --steps 4 --warmup 2 > $O/pmc_reduce.log 2>&1; echo "pmc_reduce rc=$?" >> $O/env.txt; tail -25 $O/pmc_reduce.log;;
     train_fp16)
       timeout 600 python bench.py --mode train --steps 30 --warmup 5 --texels fp16 > $O/train_fp16.json 2> $O/train_fp16.err; tail -c 700 $O/train_fp16.json
