@@ -61,10 +61,15 @@ def test_bench_parity_figure(gpu_device):
     assert j['parity']['ok'] and max(j['parity'][k] for k in ('rgb', 'depth', 'mask')) <= 1e-4, j['parity']
     assert j['parity']['mask_mean'] > 0.05
     # the CPU baseline is the reference itself (run.py::render + the real Generator's sampler from the staged oracle/_ref)
-    assert j['cpu_baseline']['kind'] == 'reference' and j['cpu_baseline']['value'] > 0
-    p = j['parity']
-    assert p['oracle_equals_reference_cpu_bit_for_bit'], p
-    assert max(p['vs_reference_cpu'].values()) <= 1e-4 and p['ok_vs_reference_pytorch_rocm'], p
+    from oracle import reference
+    assert j['cpu_baseline']['value'] > 0
+    if reference.available():
+        assert j['cpu_baseline']['kind'] == 'reference'
+        p = j['parity']
+        assert p['oracle_equals_reference_cpu_bit_for_bit'], p
+        assert max(p['vs_reference_cpu'].values()) <= 1e-4 and p['ok_vs_reference_pytorch_rocm'], p
+    else:                                                # (a snapshot without the staged oracle/_ref: the oracle restatement)
+        assert j['cpu_baseline']['kind'] == 'port' and j['parity']['ok_vs_pytorch_rocm']
 
 
 def test_bench_train_mode_single_rank_rccl(gpu_device):
