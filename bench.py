@@ -444,9 +444,11 @@ def main():
 
     variants = {}
     if not args.no_variants:
-        legs = [('mlp_exact_fp32', {'d': d, 'tuning': 8}, pipelined), ('all_rays_hit', {'d': d_hit, 'tuning': 0}, pipelined),
+        legs = [('all_rays_hit', {'d': d_hit, 'tuning': 0}, pipelined),
                 ('pipelined' if not pipelined else 'serial', {'d': d, 'tuning': 0}, not pipelined)]
         if args.texels == 'fp32':
+            # (the exact-fp32 MLP is built for fp32 texels: with 16-bit storage the texels set the precision)
+            legs.insert(0, ('mlp_exact_fp32', {'d': d, 'tuning': 8}, pipelined))
             # BASELINE cfg2 names bf16: the same whole step with the triplanes handed over as bf16 texels (arithmetic fp32)
             legs.append(('bf16_texels', {'d': d, 'tuning': 0, 'tdt': ops.TEXEL_BF16}, pipelined))
         for name, v, pl in legs:
@@ -515,7 +517,8 @@ def main():
             cfg = res['config']
             cfg['value_serial' if not pipelined else 'value_pipelined'] = value
             cfg['value_' + other] = variants[other]['value']
-            cfg['value_mlp_exact_fp32'] = variants['mlp_exact_fp32']['value']
+            if 'mlp_exact_fp32' in variants:
+                cfg['value_mlp_exact_fp32'] = variants['mlp_exact_fp32']['value']
             cfg['value_all_rays_hit'] = variants['all_rays_hit']['value']
             if 'bf16_texels' in variants:
                 cfg['value_bf16_texels'] = variants['bf16_texels']['value']

@@ -52,6 +52,17 @@ def test_bench_single_process(gpu_device):
     assert lv['gather_stream_algorithmic']['x_hbm_peak'] > 0
 
 
+def test_bench_16_bit_texel_storage(gpu_device):
+    """--texels bf16 (the storage type BASELINE cfg2 names): the line comes out, the exact-fp32 leg (fp32 texels only) is left
+    out, and the run's own parity figure is taken against the ROUNDED planes."""
+    r = subprocess.run([sys.executable, 'bench.py', '--steps', '3', '--warmup', '1', '--no-extras', '--texels', 'bf16',
+                        '--images-per-gpu', '2'], cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    j = _last_json(r.stdout)
+    assert j['config']['texel_storage'].startswith('bf16') and 'value_mlp_exact_fp32' not in j['config']
+    assert j['config']['value_all_rays_hit'] > 1e6 and j['parity']['ok'], j['parity']
+
+
 def test_bench_parity_figure(gpu_device):
     """The bench line carries its own parity check: one image of the timed workload against the CPU oracle."""
     r = subprocess.run([sys.executable, 'bench.py', '--steps', '3', '--warmup', '1', '--no-extras'], cwd=ROOT,
