@@ -23,7 +23,7 @@ BUDGET = 1e-4
 def _require_reference():
     # The staged copy ships with the snapshot (git-ignored like the .so, not gpurun-ignored): on the GPU box these tests RUN
     # (0 skipped in profiles/r5/pytest_gpu.log).  A snapshot made without it - a bare clone, where build() found no
-    # /root/reference to stage from - is reported as a skip with the recipe's name rather than as 13 failures.
+    # /root/reference to stage from - is reported as a skip with the recipe's name rather than as a dozen failures.
     if not reference.available():
         pytest.skip('reference sources not staged: run oracle/make_ref.py (or __graft_entry__.build()) where /root/reference exists')
 
