@@ -35,7 +35,7 @@ def stress(name, fn, n, keys):
     return r
 
 
-def render_case(dev, n_img, radius, tdt, R=bench.R, S=bench.S, tuning=0):
+def render_case(dev, n_img, radius, tdt, R=bench.R, S=bench.S, tuning=0, **render_kw):
     dd = bench.synthetic_inputs(n_img, 4321, dev)
     g = torch.Generator().manual_seed(77)
     dd['cam'] = bench.cameras(n_img, radius, g).to(dev)
@@ -48,7 +48,7 @@ def render_case(dev, n_img, radius, tdt, R=bench.R, S=bench.S, tuning=0):
 
     def fn():
         out = ops.render_fwd(dd['cam'], dd['focal'], R, R, S, texels, image, bench.SCENE_RANGE, bench.A, dd['att'], True,
-                             dd['beta'], dd['alpha'], noise_coarse=nc, noise_fine=nf, workspace=state['ws'], tuning=tuning)
+                             dd['beta'], dd['alpha'], noise_coarse=nc, noise_fine=nf, workspace=state['ws'], tuning=tuning, **render_kw)
         state['ws'] = out['_workspace']
         return out
     return fn
@@ -94,6 +94,14 @@ def main():
     res['render_cfg5_fp16'] = stress('render 2 x 256^2 128+128 fp16 texels (cfg5)',
                                      render_case(dev, 2, bench.RADIUS, ops.TEXEL_F16, R=256, S=128), max(n // 2, 50),
                                      ('rgb', 'depth', 'mask'))
+    # round 5: the packed bf16 tile (three workgroups per CU) and the 128 + 128 kernel with its 16-bit semantics table
+    res['render_b8_chairs_bf16'] = stress('render 8 x 128^2 64+64 chairs-like, bf16 texels',
+                                          render_case(dev, 8, bench.RADIUS, ops.TEXEL_BF16), n, ('rgb', 'depth', 'mask'))
+    res['render_b8_all_hit_bf16'] = stress('render 8 x 128^2 64+64 every ray hits, bf16 texels',
+                                           render_case(dev, 8, 1.3, ops.TEXEL_BF16), max(n // 2, 50), ('rgb', 'depth', 'mask'))
+    res['render_cfg5_semantics'] = stress('render 2 x 256^2 128+128 + semantics map (cfg5)',
+                                          render_case(dev, 2, bench.RADIUS, ops.TEXEL_F32, R=256, S=128, want_semantics=True),
+                                          max(n // 4, 50), ('rgb', 'depth', 'mask', 'semantics'))
     res['field_query_exact'] = stress('field_query_kernel 2 x 1 Mi points, exact fp32', field_case(dev, 0), max(n // 2, 50),
                                       ('sigma', 'rgb', 'sdf'))
     res['field_query_split'] = stress('field_query_kernel 2 x 1 Mi points, split fp16', field_case(dev, 1), max(n // 2, 50),
