@@ -115,6 +115,47 @@ def test_inversion_steps_match_the_real_reference(gpu_device):
     assert abs(q1 - p1) <= 0.5 and abs(j1 - i1) <= 0.02, (r['reference'][-1], r['hip'][-1])
 
 
+def test_run_py_parallel_model_calls_the_drop_in_unchanged(gpu_device):
+    """INTEGRATION.md section 1 in action: run.py's own `ParallelModel` (560-617, AST-sliced - run.py cannot be imported)
+    with nothing changed but the module-level name `render` it calls, and the attach()ed Generator as its model: the
+    call run.py's training / eval / inversion loops make (use_ema, resolution / ray multipliers, compute_semantics, the
+    per-replica loss closure) returns what the untouched ParallelModel + reference render + reference Generator return."""
+    _require_reference()
+    import nerf_from_image_amd.render as nfi_render
+    sc = rc.build_scene('p3d', 2, gpu_device)
+    ref_render, _ = reference.load_render(sc.args, sc.dcfg, unscripted_stages=True)
+
+    def parallel_model(render_fn, model):
+        env = {'nn': torch.nn, 'torch': torch, 'render': render_fn, 'depth_samples_per_ray': 32}
+        reference.slice_functions('run.py', ['ParallelModel'], env)
+        return env['ParallelModel'](64, model=model, model_ema=model)
+    pm_ref = parallel_model(ref_render, sc.gen)
+    pm_hip = parallel_model(nfi_render.make_render(sc.args, sc.dcfg), sc.hip)
+    closure_seen = []
+
+    def closure(pm, rgb, alpha, semantics, extra_outputs, weight=1.0):
+        closure_seen.append(pm)
+        return weight * rgb.mean(dim=(1, 2, 3)) + alpha.mean(dim=(1, 2))
+    for kw in (dict(use_ema=True), dict(use_ema=True, ray_multiplier=2, compute_semantics=True),
+               dict(use_ema=False, closure=closure, closure_params={'weight': 0.5})):
+        res = 64 * int(kw.get('res_multiplier', 1))
+        samples = 32 * int(kw.get('ray_multiplier', 1))
+        noise = rc.draw_noise(sc, res, samples)
+        with torch.no_grad():
+            with rc.ReplayNoise(noise):
+                a = pm_hip(sc.cam, sc.focal, None, sc.bbox, sc.ws, **kw)
+            with rc.ReplayNoise(noise):
+                b = pm_ref(sc.cam, sc.focal, None, sc.bbox, sc.ws, **kw)
+        if 'closure' in kw:
+            assert a.shape == b.shape == (2,) and rc.max_err(a, b) <= BUDGET
+            continue
+        for k, x, y in zip(('rgb', 'depth', 'mask', 'normals', 'extra'), a[:5], b[:5]):
+            assert (x is None) == (y is None), k
+            if x is not None:
+                assert x.shape == y.shape and rc.max_err(x, y) <= BUDGET, (k, kw, rc.max_err(x, y))
+    assert closure_seen == [pm_hip, pm_ref]
+
+
 def test_same_seed_gives_the_reference_noise(gpu_device):
     """No interception: the SCRIPTED reference (as run.py runs it) and the drop-in after the same torch.manual_seed draw
     the same two noise tensors from PyTorch-ROCm's Philox stream (same shapes, same order: lib/nerf_utils.py:115, 202)."""
