@@ -356,3 +356,68 @@ def inversion(sc, res, samples, steps=8, lr=2e-3, seed=11):
         opt_hip.step()
         traj_hip.append((l_o,) + m_o)
     return {'along_reference_trajectory': along, 'reference': traj_ref, 'hip': traj_hip}
+
+
+REGULARISER_NAMES = ['sdf_eikonal_loss', 'sdf_distance_loss', 'total_variation_loss', 'entropy_loss']
+
+
+def regularisers(sc, seed=321, weights=(1.0, 0.7, 3.0, 0.01)):
+    """The G step's regulariser branch (generator.py:505-585) on the real Generator in training mode: the reference's own
+    forward against `attach(model, hip_regularisers=True)`, same seed (= the same two draws), losses and gradients w.r.t. the
+    latents (through the synthesis network), the decoder and beta.  Returns relative errors."""
+    import nerf_from_image_amd.generator as nfi_gen
+
+    def run(model):
+        model = model.train().requires_grad_(True)
+        ws = sc.ws.detach().clone().requires_grad_()
+        torch.manual_seed(seed)
+        out = model(None, ws, REGULARISER_NAMES)
+        assert set(out) == set(REGULARISER_NAMES)
+        loss = sum(w * out[n].sum() for w, n in zip(weights, REGULARISER_NAMES))
+        dec = model.decoder.net
+        grads = torch.autograd.grad(loss, [ws, dec[0].weight, dec[0].bias, dec[2].weight, model.beta])
+        return {n: out[n].detach() for n in REGULARISER_NAMES}, grads
+    ref_out, ref_g = run(copy.deepcopy(sc.gen))
+    hip_out, hip_g = run(nfi_gen.attach(copy.deepcopy(sc.gen), hip_regularisers=True))
+    rep = {'loss_rel': {n: max_err(hip_out[n], ref_out[n]) / float(ref_out[n].abs().max()) for n in REGULARISER_NAMES},
+           'loss_reference': {n: ref_out[n].tolist() for n in REGULARISER_NAMES},
+           'grad_rel_l2': {name: rel_err(a, b) for name, a, b in zip(['ws', 'w1', 'b1', 'w2', 'beta'], hip_g, ref_g)}}
+    return rep
+
+
+def training_step(sc, res, samples, seed=77, reg_weight=0.1):
+    """One generator-side training step in cfg4's shape on the REAL Generator (training mode, latents through the mapping
+    network): render + image / alpha loss (run.py:980-1010), regulariser forward (974-979, 1011-1028), one backward - the
+    reference's own render + forward against the drop-in render + `attach(..., hip_regularisers=True)`, same noise and
+    seed.  Compares the loss and the gradient of EVERY generator parameter.  Returns a dict."""
+    import nerf_from_image_amd.generator as nfi_gen
+    import nerf_from_image_amd.render as nfi_render
+    noise = draw_noise(sc, res, samples, seed=seed)
+    g = torch.Generator().manual_seed(seed)
+    t_rgb = (torch.rand(sc.batch, res, res, 3, generator=g) * 2 - 1).to(sc.dev)
+    t_mask = (torch.rand(sc.batch, res, res, generator=g) > 0.5).float().to(sc.dev)
+    ref_render, _ = reference.load_render(sc.args, sc.dcfg, unscripted_stages=True)
+    hip_render_fn = nfi_render.make_render(sc.args, sc.dcfg)
+
+    def run(model, render_fn):
+        model = model.train().requires_grad_(True)
+        for p_ in model.parameters():
+            p_.grad = None
+        with ReplayNoise(noise):
+            out = render_fn(model, res, res, sc.cam, sc.focal, None, sc.bbox, sc.z, samples)
+        loss = ((out[0] - t_rgb) ** 2).mean() + ((out[2] - t_mask) ** 2).mean()
+        torch.manual_seed(seed)
+        reg = model(None, sc.z, ['sdf_eikonal_loss', 'sdf_distance_loss'])
+        loss = loss + reg_weight * (reg['sdf_eikonal_loss'].mean() + reg['sdf_distance_loss'].mean())
+        loss.backward()
+        return float(loss.detach()), {n: p_.grad.detach().clone() for n, p_ in model.named_parameters() if p_.grad is not None}
+    l_r, g_r = run(copy.deepcopy(sc.gen), ref_render)
+    l_h, g_h = run(nfi_gen.attach(copy.deepcopy(sc.gen), hip_regularisers=True), hip_render_fn)
+    assert set(g_r) == set(g_h), set(g_r) ^ set(g_h)
+    num = sum(float((g_h[n].double() - g_r[n].double()).pow(2).sum()) for n in g_r)
+    den = sum(float(g_r[n].double().pow(2).sum()) for n in g_r)
+    per = {n: rel_err(g_h[n], g_r[n]) for n in g_r}
+    big = {n: e for n, e in per.items() if float(g_r[n].double().norm()) >= 1e-3 * den ** 0.5}
+    worst = max(big, key=big.get)
+    return {'loss_hip': l_h, 'loss_reference': l_r, 'n_parameter_tensors': len(g_r), 'grad_rel_l2_all_parameters': (num / den) ** 0.5,
+            'worst_tensor_among_the_significant': worst, 'worst_tensor_rel_l2': big[worst], 'significant_tensors': len(big)}

@@ -115,6 +115,32 @@ def test_inversion_steps_match_the_real_reference(gpu_device):
     assert abs(q1 - p1) <= 0.5 and abs(j1 - i1) <= 0.02, (r['reference'][-1], r['hip'][-1])
 
 
+def test_regulariser_branch_on_the_real_generator(gpu_device):
+    """The G step's regularisers (run.py:974-979, 1011-1028; generator.py:505-585) on the real Generator in training mode:
+    `attach(model, hip_regularisers=True)` serves eikonal / distance / total-variation / entropy from the HIP kernels
+    (`nfi_sdf_gradient_fwd/bwd`: the eikonal term's backward is the reference's DOUBLE backward through lib/ops.grid_sample2d)
+    - same seed, same two draws - against the reference's own forward: losses and gradients w.r.t. the latents (through the
+    StyleGAN2 synthesis network), the decoder and beta."""
+    _require_reference()
+    sc = rc.build_scene('cub', 2, gpu_device)
+    rep = rc.regularisers(sc)
+    assert max(rep['loss_rel'].values()) <= 2e-4, rep
+    assert max(rep['grad_rel_l2'].values()) <= 2e-3, rep
+
+
+def test_generator_training_step_on_the_real_generator(gpu_device):
+    """BASELINE cfg4's generator step on the real class (cub-like: orthographic, scene_range 2.0, black background, 4 images
+    x 128 x 128 x (64 + 64), model.train(), latents through the mapping network, image + alpha loss + eikonal / distance
+    regularisers, ONE backward): the gradient of EVERY generator parameter - mapping network, StyleGAN2 synthesis, texture
+    mapper, decoder, beta, alpha - against the reference's own render + forward."""
+    _require_reference()
+    sc = rc.build_scene('cub', 4, gpu_device)
+    rep = rc.training_step(sc, 128, 64)
+    assert abs(rep['loss_hip'] - rep['loss_reference']) <= 1e-5 * abs(rep['loss_reference']), rep
+    assert rep['n_parameter_tensors'] > 100 and rep['grad_rel_l2_all_parameters'] <= 2e-3, rep
+    assert rep['worst_tensor_rel_l2'] <= 2e-2, rep
+
+
 def test_run_py_parallel_model_calls_the_drop_in_unchanged(gpu_device):
     """INTEGRATION.md section 1 in action: run.py's own `ParallelModel` (560-617, AST-sliced - run.py cannot be imported)
     with nothing changed but the module-level name `render` it calls, and the attach()ed Generator as its model: the

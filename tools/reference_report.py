@@ -41,6 +41,8 @@ def main():
         rep['gradients']['%s_b2_128px_64+64' % geometry] = rc.gradients(sc, 128, 64)
         del sc
         torch.cuda.empty_cache()
+    rep['training_step_cub_b4_128px_64+64'] = rc.training_step(rc.build_scene('cub', 4, dev), 128, 64)
+    rep['regularisers_cub_b2'] = rc.regularisers(rc.build_scene('cub', 2, dev))
     sc = rc.build_scene('p3d', 4, dev)
     rep['inversion_p3d_b4_128px_64+64_8_steps'] = rc.inversion(sc, 128, 64, steps=8)
     print(json.dumps(rep, indent=1))
