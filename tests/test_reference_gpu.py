@@ -124,8 +124,8 @@ def test_regulariser_branch_on_the_real_generator(gpu_device):
     _require_reference()
     sc = rc.build_scene('cub', 2, gpu_device)
     rep = rc.regularisers(sc)
-    assert max(rep['loss_rel'].values()) <= 2e-4, rep
-    assert max(rep['grad_rel_l2'].values()) <= 2e-3, rep
+    assert max(rep['loss_rel'].values()) <= 1e-5, rep              # measured 6.3e-7
+    assert max(rep['grad_rel_l2'].values()) <= 1e-3, rep           # measured 1.6e-4 (latents), <= 3.2e-6 (decoder, beta)
 
 
 def test_generator_training_step_on_the_real_generator(gpu_device):
@@ -137,8 +137,9 @@ def test_generator_training_step_on_the_real_generator(gpu_device):
     sc = rc.build_scene('cub', 4, gpu_device)
     rep = rc.training_step(sc, 128, 64)
     assert abs(rep['loss_hip'] - rep['loss_reference']) <= 1e-5 * abs(rep['loss_reference']), rep
-    assert rep['n_parameter_tensors'] > 100 and rep['grad_rel_l2_all_parameters'] <= 2e-3, rep
-    assert rep['worst_tensor_rel_l2'] <= 2e-2, rep
+    # measured (profiles/r5/reference_parity.json): 1.5e-5 over all 116 tensors, worst significant tensor 6.6e-5
+    assert rep['n_parameter_tensors'] > 100 and rep['grad_rel_l2_all_parameters'] <= 2e-4, rep
+    assert rep['worst_tensor_rel_l2'] <= 1e-3, rep
 
 
 def test_run_py_parallel_model_calls_the_drop_in_unchanged(gpu_device):
