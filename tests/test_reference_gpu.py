@@ -84,14 +84,15 @@ def test_view_direction_decoder_matches_the_real_reference(gpu_device):
         _check(rep, ('rgb', 'depth', 'mask', 'extra'))
 
 
-@pytest.mark.parametrize('geometry', ['chairs', 'p3d', 'cub'])
+@pytest.mark.parametrize('geometry', ['chairs', 'p3d', 'cub', 'carla'])
 def test_gradients_match_the_real_reference(gpu_device, geometry):
     """Forward + backward through the real plane producer: d loss / d ws (through the StyleGAN2 synthesis network and
     the texture mapper), d loss / d camera matrix, d loss / d focal - the leaves the inversion loop optimises
     (run.py:2264-2299).  The reference's own backward scatters with fp32 atomics in arrival order."""
     _require_reference()
     sc = rc.build_scene(geometry, 2, gpu_device)
-    rep = rc.gradients(sc, 128, 64)
+    # (carla: --use_viewdir - the camera gradient also flows through the PyTorch ViewDirectionMapper's view directions)
+    rep = rc.gradients(sc, 128, 64) if geometry != 'carla' else rc.gradients(sc, 64, 32)
     assert abs(rep['loss_hip'] - rep['loss_reference']) <= 1e-4 * abs(rep['loss_reference']) + 1e-3, rep
     assert rep['g_ws'] <= 2e-3, rep
     assert rep['g_cam'] <= 1e-2, rep
