@@ -318,7 +318,7 @@ int nfi_raygen_bwd(const nfi_raygen_args* a, const float* g_ray_origins, const f
  * ------------------------------------------------------------------------------------------ */
 typedef struct nfi_field_bwd_args {
   int n_scenes;
-  int64_t points_per_scene;
+  int64_t points_per_scene;          /* <= 2^30 (<= 2^25 with scatter_mode 1): the kernels address a scene's points by 32-bit offsets */
   const float* points;
   const void* texels; int plane_res; int texel_dtype;   /* any storage type; g_texels is fp32 (view-direction decoder: fp32 texels only) */
   const float* decoder_image;                            /* forward operand image */
@@ -429,14 +429,15 @@ typedef struct nfi_render_args {
   void* event_start; void* event_stop;
   /* tuning knob, 0 = default.  bit 2: hand rays out in scanline order instead of 8x8 pixel tiles
    * (results identical).  bit 3: evaluate the decoder MLP with exact-fp32 MFMA instead of the
-   * split-fp16 (hi+lo, 22 significand bits) MFMA; both meet the 1e-4 parity budget.  bit 4: ONE device-wide work
+   * split-fp16 (hi+lo, 22 significand bits) MFMA; both meet the 1e-4 parity budget (fp32 texels only: with 16-bit texel
+   * storage the texels, not the MLP operands, set the precision - the call is refused).  bit 4: ONE device-wide work
    * counter instead of the per-XCD queues over square pixel blocks (results identical; the per-XCD queues take the
    * largest of 32 / 16 / 8 pixels that divides both image sides, two positions per atomic, and fall back to the single
    * counter when not even 8 does). */
   int tuning;
   /* optional uint64[12] device array: per-phase shader-cycle sums over all waves (profiling build of
    * the kernel; NULL = off): field tile {issue, wait+interp, mlp, count}, ray set-up, coarse field,
-   * resample, fine field, merge, composite, rays marched, wave lifetime */
+   * resample, fine field, merge, composite, rays marched, wave lifetime; fp32 texels only */
   void* profile_cycles;
   /* view-direction decoder: NULL, or [N, NFI_RAY_FEATURE_PITCH] (decoder_image from nfi_decoder_pack_viewdir;
    * the MLP then runs in exact fp32) */
@@ -482,12 +483,15 @@ typedef struct nfi_render_args {
    * output (models/generator.py:643) in the semantics slot of render_volume_density (compute_coords: run.py:234-235,
    * 337-338; the encoder-training loop asks for it every iteration, run.py:1639-1646).  Like `semantics` it comes out of
    * the SAME render launch (rgb / depth / mask bit-identical to a call without it); neither is available together with
-   * stage taps, the cycle profile, the view-direction decoder or the exact-fp32 MLP. */
+   * stage taps, the cycle profile or the exact-fp32 MLP; with the view-direction decoder (ray_features) both exist for fp32
+   * texels.  (The 128 + 128 kernel parks the probabilities of `semantics` as unorm16 between the passes: |error| <= 7.7e-6
+   * per sample under a convex combination.) */
   float* coords;
   /* [N,3] or NULL: the composited normal map, sum_k w_k normalize(d sdf / d x)_k over the merged samples, + (1 - mask)
    * on a white background (compute_normals: run.py:228-230, 241-245, 296-300; lib/nerf_utils.py:149-151, 159; the
    * sampler's 'normals' output, models/generator.py:599-618, here the analytic derivative of the decoder's distance
-   * instead of autograd).  use_sdf only; fp32 or fp16 texels; same launch, same restrictions as `coords`. */
+   * instead of autograd).  use_sdf only; fp32 or fp16 texels; same launch, same restrictions as `coords`; not with the
+   * view-direction decoder. */
   float* normals;
 } nfi_render_args;
 size_t nfi_render_workspace_bytes(int64_t n_rays);
