@@ -39,9 +39,9 @@ def main():
     for geometry in ('chairs', 'p3d', 'cub'):
         sc = rc.build_scene(geometry, 2, dev)
         rep['gradients']['%s_b2_128px_64+64' % geometry] = rc.gradients(sc, 128, 64)
-    rep['gradients']['carla_viewdir_b2_64px_32+32'] = rc.gradients(rc.build_scene('carla', 2, dev), 64, 32)
         del sc
         torch.cuda.empty_cache()
+    rep['gradients']['carla_viewdir_b2_64px_32+32'] = rc.gradients(rc.build_scene('carla', 2, dev), 64, 32)
     rep['training_step_cub_b4_128px_64+64'] = rc.training_step(rc.build_scene('cub', 4, dev), 128, 64)
     rep['regularisers_cub_b2'] = rc.regularisers(rc.build_scene('cub', 2, dev))
     sc = rc.build_scene('p3d', 4, dev)
