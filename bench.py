@@ -541,6 +541,22 @@ def main():
                 res['config']['pytorch_rocm_reference_rays_per_s'] = ref_gpu['value']
                 res['config']['pytorch_rocm_reference_kind'] = ref_gpu['kind']
                 res['config']['x_pytorch_rocm_reference'] = value / ref_gpu['value']
+            e2e = (res['extras'].get('end_to_end_real_generator') or {}).get('render_incl_synthesis', {}).get('b%d' % B)
+            if e2e:
+                # SURVEY.md 8(d) metric (ii): render() INCLUDING the real plane producer (StyleGAN2 synthesis, PyTorch-ROCm /
+                # MIOpen in both implementations), HIP drop-in vs the untouched reference, and the share of that
+                # end-to-end call this bench's whole render step (hand-off + pack + noise + set-up + kernel) accounts for
+                cfg = res['config']
+                cfg['end_to_end_rays_per_s'] = e2e['hip_fp32_texels_rays_per_s']
+                cfg['end_to_end_reference_rays_per_s'] = e2e['reference_rays_per_s']
+                cfg['x_reference_end_to_end'] = e2e['x_reference_fp32_texels']
+                cfg['renderer_share_of_end_to_end_render'] = res['ms_per_step'] / e2e['hip_fp32_texels_ms']
+            dev16 = res['extras'].get('texel_storage_vs_fp32_reference') or {}
+            for tx in ('bf16', 'fp16'):
+                r16 = dev16.get('cfg2_b8_128px_64+64_%s_texels' % tx)
+                if r16:
+                    res['config']['%s_vs_fp32_reference_rgb' % tx] = r16['max_abs']['rgb']
+                    res['config']['%s_vs_fp32_reference_rgb_mean' % tx] = r16['mean_abs']['rgb']
         if world == 1 and not args.no_cpu_baseline:
             res['cpu_baseline'], res['parity'] = cpu_baseline_and_parity(1234, dev, ops, args.texels)
         else:
@@ -573,7 +589,10 @@ def train_mode(args, dev, rank, world, use_dist):
             'metric': 'training rays/sec (cfg4-like generator step: render fwd + regularisers + bwd + gradient all-reduce + Adam)',
             'value': world * r['rays_per_step'] * args.steps / elapsed, 'unit': 'rays/s', 'n_gpus': world,
             'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': elapsed / args.steps * 1e3,
-            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'dtype': 'f32 (decoder MLP operands split-fp16 hi+lo, 22 bits, forward and backward recompute; gradients, plane-'
+                     'gradient image and optimiser fp32)',
+            'data': 'synthetic',
             'config': {'workload': 'cfg4-like: %d images/GPU, 128x128 orthographic rays, 64+64 samples, scene_range 2.0, '
                                    'black background, image + alpha loss, eikonal + distance regularisers, gradient '
                                    'all-reduce of a generator-sized fp32 set (%d parameters), fused Adam'

@@ -159,8 +159,9 @@ def raygen(height, width, focal, cam2world, bbox=None, center=None, normalize=Fa
 
 
 def near_far(ray_origins, ray_directions, scene_range, strict=True):
-    """Returns near, far (finished planes), hit (bool).  strict: raise when no ray hits, as the
-    reference does (costs a device->host read of one counter)."""
+    """Returns near, far (finished planes), hit (bool).  strict: True - raise when no ray hits, as the reference does
+    (costs a device->host read of one counter); 'deferred' - no synchronisation, the counter is looked at by the next
+    strict call on the device / flush_strict() (as in render_fwd); False - never raises."""
     ro, rd = _f32c(ray_origins, 'ray_origins'), _f32c(ray_directions, 'ray_directions')
     shape = ro.shape[:-1]
     n = ro.numel() // 3
@@ -174,9 +175,11 @@ def near_far(ray_origins, ray_directions, scene_range, strict=True):
         _lib.call_struct('nfi_near_far', 'nfi_near_far_args', _stream(ro), n_rays=n, ray_origins=ro,
                          ray_directions=rd, scene_range=float(scene_range), near_raw=near_raw, far_raw=far_raw,
                          hit=hit, reduce=red, near_plane=near, far_plane=far)
-    if strict and int(red[2].item()) == 0:
-        raise RuntimeError('compute_near_far_planes: no ray intersects the scene cube '
-                           '(the reference fails on min() of an empty selection here)')
+    if strict == 'deferred':
+        _raise_pending(dev)
+        _defer_hit_count(red[2:3], dev)
+    elif strict and int(red[2].item()) == 0:
+        raise RuntimeError(_NO_HIT)
     return near.view(shape), far.view(shape), (hit & 1).bool().view(shape)
 
 
@@ -396,11 +399,19 @@ def render_fwd(cam2world, focal, height, width, num_samples, texels, decoder_ima
     are untouched; |d rgb| <= ~eps, see include/nfi_hip.h).
     strict: True - raise when no ray of the batch meets the scene cube, as the reference does (lib/nerf_utils.py:258 fails
     on min() of an empty selection): the ray set-up runs as its own launch and its hit counter is read back before the
-    render kernel is launched (one host synchronisation, on the set-up only); 'deferred' - no synchronisation: the counter
-    is copied to pinned memory behind the render and checked by the next strict call / flush_strict().
+    render kernel is launched (one host synchronisation, on the set-up only - the reference synchronises at the same
+    place, its boolean indexing at nerf_utils.py:258; the device idles for that host round trip, and `events` /
+    `clock_probe` then bracket the render kernel WITHOUT the ray set-up); 'after' - one launch, the counter is read
+    back behind the render kernel (no gap between set-up and render; the host waits for the whole render);
+    'deferred' - no synchronisation: the counter is copied to pinned memory behind the render and checked by the next
+    strict call / flush_strict().
     want_semantics / want_coords: also return 'semantics' [B,H,W,A] (composited softmax probabilities, run.py:312-335)
     / 'coords' [B,H,W,3] (composited query points, run.py:337-338) / 'normals' [B,H,W,3] (composited unit normals of the
-    SDF, + 1 - mask on a white background, lib/nerf_utils.py:149-151, 159; fp32 / fp16 texels) from the SAME launch."""
+    SDF, + 1 - mask on a white background, lib/nerf_utils.py:149-151, 159; fp32 / fp16 texels) from the SAME launch.
+    Precision of 'semantics': with num_samples <= 64 the per-sample probabilities wait for the compositing in fp32; the
+    64 < num_samples <= 128 kernel parks them as unorm16 (|error| <= 2^-17 = 7.7e-6 per sample, values below that become
+    0), so its map is within 1e-5 of the reference's instead of 1e-6 (tests/test_hip_parity.py,
+    test_wide_kernel_semantics_table_precision)."""
     cam2world = _f32c(cam2world, 'tform_cam2world')
     B = cam2world.shape[0]
     dev = cam2world.device
@@ -449,6 +460,8 @@ def render_fwd(cam2world, focal, height, width, num_samples, texels, decoder_ima
     check_after = False
     if strict == 'deferred':
         _raise_pending(dev)                      # an EARLIER batch of this device that met no ray
+    elif strict == 'after':
+        check_after = True
     elif strict:
         if not rays_ready and not stash and not any(name in tap_t for name in ('ray_origins', 'ray_directions', 'hit')):
             # the ray set-up as its own launch, its hit count read back BEFORE the render kernel goes out: the host waits
@@ -515,21 +528,28 @@ def _raise_if_no_hit(workspace):
         raise RuntimeError(_NO_HIT)
 
 
-def _defer_hit_count(workspace, dev):
-    """strict='deferred': the hit count goes to pinned host memory behind the render (async copy + event), no wait."""
-    st = _PENDING.setdefault(dev.index, {'host': torch.zeros(64, dtype=torch.int32).pin_memory(), 'slot': 0, 'queue': []})
+def _dev_key(dev):
+    """The device's index; torch.device('cuda') (index None) is the current device - the key the tensors' own device has."""
+    return torch.cuda.current_device() if dev.index is None else dev.index
+
+
+def _defer_hit_count(source, dev):
+    """strict='deferred': the hit count goes to pinned host memory behind the render (async copy + event), no wait.
+    source: the render workspace (uint8; the count is its third int32) or the int32 [1] count itself."""
+    st = _PENDING.setdefault(_dev_key(dev), {'host': torch.zeros(64, dtype=torch.int32).pin_memory(), 'slot': 0, 'queue': []})
     if len(st['queue']) >= 64:
         _raise_pending(dev, wait=True)
     slot = st['slot']
     st['slot'] = (slot + 1) % 64
-    st['host'][slot:slot + 1].copy_(workspace[8:12].view(torch.int32), non_blocking=True)
+    count = source[8:12].view(torch.int32) if source.dtype == torch.uint8 else source
+    st['host'][slot:slot + 1].copy_(count, non_blocking=True)
     ev = torch.cuda.Event()
     ev.record(torch.cuda.current_stream(dev))
     st['queue'].append((ev, slot))
 
 
 def _raise_pending(dev, wait=False):
-    st = _PENDING.get(dev.index)
+    st = _PENDING.get(_dev_key(dev))
     while st and st['queue']:
         ev, slot = st['queue'][0]
         if not ev.query():

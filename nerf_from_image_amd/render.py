@@ -36,7 +36,9 @@ process-wide - the reference calls render from one thread per GPU):
                     cube (lib/nerf_utils.py:258 fails on min() of an empty selection; its boolean indexing synchronises
                     the host there too).  The fused paths read the hit counter of the ray set-up back BEFORE the render
                     kernel is launched: the host waits for the set-up kernels only, and a batch without a hit does not
-                    pay for a render.  'deferred': no synchronisation at all - the counter travels to pinned host memory
+                    pay for a render.  'after': the fused paths launch once and read the counter back behind the render
+                    (no device idle between set-up and render; the host waits for the render).  'deferred': no
+                    synchronisation at all, on any path - the counter travels to pinned host memory
                     behind the render and is looked at by the NEXT strict call on that device (or ops.flush_strict()),
                     which raises for the earlier batch; for serving / pipelined loops.  False: never raises, such a
                     batch renders as background.  With row_window the check is the whole image's: it runs only when
@@ -99,7 +101,7 @@ def render(target_model, height, width, tform_cam2world, focal_length, center, b
 
 def _strict(opts):
     v = opts.strict_near_far
-    return 'deferred' if v == 'deferred' else bool(v)
+    return v if v in ('deferred', 'after') else bool(v)
 
 
 def _needs_grad(*tensors):
@@ -266,8 +268,9 @@ def _render(cfg, dcfg, opts, target_model, height, width, tform_cam2world, focal
     ray_origins, ray_directions = rays if rays is not None else nerf_utils.get_ray_bundle_normalized(
         height, width, focal_length, tform_cam2world, bbox, center)
     with torch.no_grad():
+        # (the staged path has one place to look at the counter - behind the near / far launch: 'after' is True here)
         near, far = nerf_utils.compute_near_far_planes(ray_origins.detach(), ray_directions.detach(), scene_range,
-                                                       strict=opts.strict_near_far)
+                                                       strict=True if _strict(opts) == 'after' else _strict(opts))
     query_points, depth_values = nerf_utils.compute_query_points_from_rays(
         ray_origins, ray_directions, near, far, S, randomize=randomize, noise=noise_c)
     if force_no_cam_grad:

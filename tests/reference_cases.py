@@ -128,6 +128,52 @@ def draw_noise(sc, res, samples, seed=99):
             torch.rand((sc.batch * res * res, samples), device=sc.dev, generator=gn)]
 
 
+def as_double(sc):
+    """The reference side of the scene in float64 (module, latents, cameras): the ground truth the fp32 implementations
+    are measured against.  fp64 atomics sum 1e7 addends of either sign to ~1e-13 relative whatever their order, so this
+    side is deterministic at the scale of every bound in tests/test_reference_gpu.py - unlike the fp32 reference, whose
+    grid_sampler backward scatters with fp32 atomics in arrival order."""
+    twin = copy.copy(sc)
+    twin.gen = copy.deepcopy(sc.gen).double()
+    twin.hip = None
+    twin.z, twin.ws, twin.cam = sc.z.double(), sc.ws.double(), sc.cam.double()
+    twin.focal, twin.bbox = (None if sc.focal is None else sc.focal.double()), (None if sc.bbox is None else sc.bbox.double())
+    return twin
+
+
+@contextlib.contextmanager
+def default_dtype(dtype):
+    """torch's default dtype for the duration: the reference builds a few tensors without naming one (arange(S) / S as
+    the lerp weight, lib/nerf_utils.py:104-106, which torch.lerp refuses next to float64 planes)."""
+    keep = torch.get_default_dtype()
+    torch.set_default_dtype(dtype)
+    try:
+        yield
+    finally:
+        torch.set_default_dtype(keep)
+
+
+@contextlib.contextmanager
+def float32_draws_in_float64():
+    """Inside a float64 run of the reference's regulariser branch (generator.py:505-585): the stratified volume samples
+    (lib/ops.py sample_volume_stratified draws float32 whatever the module's dtype; grid_sample then refuses the mixed
+    dtypes) come out as the SAME float32 draws cast to float64, and randn_like of a float64 tensor (the total-variation
+    perturbation) draws in float32 and casts - same Philox stream, same values as the fp32 run."""
+    m = reference.modules()
+    gen_ops = m.generator.ops
+    orig_sample, orig_randn_like = gen_ops.sample_volume_stratified, torch.randn_like
+
+    def sample32(*a, **k):
+        with default_dtype(torch.float32):
+            return orig_sample(*a, **k).double()
+    gen_ops.sample_volume_stratified = sample32
+    torch.randn_like = lambda t, **kw: (orig_randn_like(t.float(), **kw).double() if t.dtype == torch.float64 else orig_randn_like(t, **kw))
+    try:
+        yield
+    finally:
+        gen_ops.sample_volume_stratified, torch.randn_like = orig_sample, orig_randn_like
+
+
 @contextlib.contextmanager
 def frozen_producer(gen, planes96):
     """The plane producer of `gen` returns `planes96` ([B,96,R,R]) instead of running: lets a CPU copy of the reference
@@ -150,7 +196,7 @@ def reference_render(sc, res, samples, noise, device=None, images=None, grad=Fal
     n = cam.shape[0]
     nz = None if noise is None else [noise[0][sl], noise[1].view(sc.batch, -1, samples)[sl].reshape(-1, samples)]
     ctx = contextlib.nullcontext()
-    extra_in = {}
+    extra_in = dict(render_kw.pop('extra_model_inputs', {}))
     if device is not None and torch.device(device) != cam.device:
         with torch.no_grad():
             planes = sc.gen.synthesis_network(ws[:, :14]).cpu()
@@ -159,7 +205,8 @@ def reference_render(sc, res, samples, noise, device=None, images=None, grad=Fal
         ws, cam, focal, bbox = ws.to(device), cam.to(device), pick_to(focal, device), pick_to(bbox, device)
         ctx = frozen_producer(gen, planes)
     with ctx, (ReplayNoise(nz) if nz is not None else contextlib.nullcontext()), \
-            (contextlib.nullcontext() if grad else torch.no_grad()):
+            (contextlib.nullcontext() if grad else torch.no_grad()), \
+            (default_dtype(torch.float64) if cam.dtype == torch.float64 else contextlib.nullcontext()):
         return ren(gen, res, res, cam, focal, None, bbox, ws, samples, extra_model_inputs=extra_in, **render_kw)
 
 
@@ -172,9 +219,18 @@ def _attention(gen, ws):
     return gen(None, ws, ['attention_values', 'sampler'])['attention_values']
 
 
-def hip_render(sc, res, samples, noise, grad=False, ws=None, cam=None, focal=None, **render_kw):
+def with_texels(sc, texel_dtype):
+    """The same scene with the HIP twin's planes stored as `texel_dtype` (ops.TEXEL_F32 / TEXEL_F16 / TEXEL_BF16): the
+    reference side (sc.gen) is untouched, so everything compared against it is compared against fp32 planes."""
+    import nerf_from_image_amd.generator as nfi_gen
+    twin = copy.copy(sc)
+    twin.hip = nfi_gen.attach(copy.deepcopy(sc.gen), texel_dtype=texel_dtype)
+    return twin
+
+
+def hip_render(sc, res, samples, noise, grad=False, ws=None, cam=None, focal=None, hip_options=None, **render_kw):
     import nerf_from_image_amd.render as nfi_render
-    ren = nfi_render.make_render(sc.args, sc.dcfg)
+    ren = nfi_render.make_render(sc.args, sc.dcfg, **(hip_options or {}))
     with (ReplayNoise(noise) if noise is not None else contextlib.nullcontext()), \
             (contextlib.nullcontext() if grad else torch.no_grad()):
         return ren(sc.hip, res, res, sc.cam if cam is None else cam, sc.focal if focal is None else focal, None, sc.bbox,
@@ -185,25 +241,31 @@ def max_err(a, b):
     return float((a.detach().float().cpu() - b.detach().float().cpu()).abs().max())
 
 
+def mean_err(a, b):
+    return float((a.detach().float().cpu() - b.detach().float().cpu()).abs().mean())
+
+
 def rel_err(a, b):
     a, b = a.detach().double().cpu(), b.detach().double().cpu()
     return float((a - b).norm() / b.norm().clamp_min(1e-30))
 
 
-def compare(sc, res, samples, cpu_images=2, **render_kw):
+def compare(sc, res, samples, cpu_images=2, hip_options=None, **render_kw):
     """HIP vs the reference on this GPU (whole batch) and vs the reference on the CPU (first `cpu_images` images, same
-    planes).  Returns a dict of max |error| per output and the CPU-vs-GPU gap of the reference itself."""
+    planes).  Returns a dict of max |error| (and mean |error|) per output and the CPU-vs-GPU gap of the reference itself.
+    hip_options: render options of the drop-in only (termination_eps ...); the reference always renders exactly, in fp32."""
     noise = draw_noise(sc, res, samples)
-    ours = hip_render(sc, res, samples, noise, **render_kw)
+    ours = hip_render(sc, res, samples, noise, hip_options=hip_options, **render_kw)
     ref_gpu = reference_render(sc, res, samples, noise, **render_kw)
     names = ['rgb', 'depth', 'mask', 'normals', 'extra']
     rep = {'mask_mean': float(ref_gpu[2].mean()), 'vs_reference_gpu': {}, 'vs_reference_cpu': {}, 'reference_cpu_vs_gpu_gap': {},
-           'pixels_over_1e-4_vs_reference_gpu': {}}
+           'pixels_over_1e-4_vs_reference_gpu': {}, 'mean_abs_vs_reference_gpu': {}, 'mean_abs_vs_reference_cpu': {}}
     for k, a, b in zip(names, ours[:5], ref_gpu[:5]):
         if a is None and b is None:
             continue
         assert a is not None and b is not None and a.shape == b.shape, (k, None if a is None else a.shape, None if b is None else b.shape)
         rep['vs_reference_gpu'][k] = max_err(a, b)
+        rep['mean_abs_vs_reference_gpu'][k] = mean_err(a, b)
         rep['pixels_over_1e-4_vs_reference_gpu'][k] = int(((a - b).abs() > 1e-4).sum())
     if cpu_images:
         sl = slice(0, min(cpu_images, sc.batch))
@@ -212,13 +274,58 @@ def compare(sc, res, samples, cpu_images=2, **render_kw):
             if a is None:
                 continue
             rep['vs_reference_cpu'][k] = max_err(a[sl], b)
+            rep['mean_abs_vs_reference_cpu'][k] = mean_err(a[sl], b)
             rep['reference_cpu_vs_gpu_gap'][k] = max_err(c[sl], b)
     return rep
 
 
-def gradients(sc, res, samples, seed=5):
+# The configurations BASELINE.json words with 16-bit storage or at cfg5's shape, each against the REAL reference in fp32
+# (run.py:176-350; res / ray multipliers run.py:598-605): name -> (geometry, images, rays per side, samples per pass,
+# texel storage of the HIP twin, termination_eps of the HIP twin).
+CONFIG_CASES = {
+    'cfg2_b8_128px_64+64_bf16_texels': ('chairs', 8, 128, 64, 'bf16', 0.0),
+    'cfg2_b8_128px_64+64_bf16_texels_term1e-5': ('chairs', 8, 128, 64, 'bf16', 1e-5),
+    'cfg2_b8_128px_64+64_fp16_texels': ('chairs', 8, 128, 64, 'fp16', 0.0),
+    'cfg2_b8_128px_64+64_fp32_texels_term1e-5': ('chairs', 8, 128, 64, 'fp32', 1e-5),
+    'cfg5_b2_256px_128+128_fp32_texels': ('chairs', 2, 256, 128, 'fp32', 0.0),
+    'cfg5_b2_256px_128+128_fp32_texels_term1e-5': ('chairs', 2, 256, 128, 'fp32', 1e-5),
+    'cfg5_b2_256px_128+128_fp16_texels': ('chairs', 2, 256, 128, 'fp16', 0.0),
+    'cfg5_b2_256px_128+128_fp16_texels_term1e-5': ('chairs', 2, 256, 128, 'fp16', 1e-5),
+}
+
+
+def texel_code(name):
+    from nerf_from_image_amd import ops
+    return {'fp32': ops.TEXEL_F32, 'fp16': ops.TEXEL_F16, 'bf16': ops.TEXEL_BF16}[name]
+
+
+def config_case(name, dev, cpu_images=1, scenes=None):
+    """compare() of one CONFIG_CASES entry.  scenes: a dict the built fp32 scenes are kept in between cases (the
+    producer's weights and the cameras are the same for every storage type)."""
+    geometry, batch, res, samples, texels, eps = CONFIG_CASES[name]
+    key = (geometry, batch)
+    sc = (scenes or {}).get(key) or build_scene(geometry, batch, dev)
+    if scenes is not None:
+        scenes[key] = sc
+    twin = sc if texels == 'fp32' else with_texels(sc, texel_code(texels))
+    rep = compare(twin, res, samples, cpu_images=cpu_images, hip_options={'termination_eps': eps} if eps else None)
+    rep['texels'], rep['termination_eps'] = texels, eps
+    return rep
+
+
+def parallel_model(render_fn, model, resolution, samples):
+    """run.py's own ParallelModel (560-617), AST-sliced, with the module-level names it reads: `render` and
+    `depth_samples_per_ray`."""
+    env = {'nn': torch.nn, 'torch': torch, 'render': render_fn, 'depth_samples_per_ray': samples}
+    reference.slice_functions('run.py', ['ParallelModel'], env)
+    return env['ParallelModel'](resolution, model=model, model_ema=model)
+
+
+def gradients(sc, res, samples, seed=5, float64=True):
     """Forward + backward of  sum(rgb * w_rgb) + sum(mask * w_mask)  w.r.t. the latents ws, the camera matrix and the
-    focal length, in both implementations (same noise).  Returns relative L2 errors of the gradients."""
+    focal length, in both implementations (same noise).  Returns relative L2 errors of the gradients: HIP against the
+    fp32 reference, and (float64=True) HIP and the fp32 reference each against the reference run in FLOAT64 on the same
+    device (`as_double`) - the comparator that does not move from run to run."""
     noise = draw_noise(sc, res, samples)
     gw = torch.Generator(device=sc.dev).manual_seed(seed)
     w_rgb = torch.randn((sc.batch, res, res, 3), device=sc.dev, generator=gw)
@@ -232,18 +339,61 @@ def gradients(sc, res, samples, seed=5):
 
     def run(which):
         ws, cam, focal = leaves()
+        kept = {}
+
+        def keep_planes(mod, inp, out):         # d loss / d planes: what the renderer hands the producer's backward
+            if out.requires_grad:
+                out.retain_grad()
+                kept['planes'] = out
         if which == 'hip':
+            h = sc.hip.synthesis_network.register_forward_hook(keep_planes)
             out = hip_render(sc, res, samples, noise, grad=True, ws=ws, cam=cam, focal=focal)
-        else:
+            loss = (out[0] * w_rgb).sum() + (out[2] * w_mask).sum()
+        elif which == 'ref':
             keep = sc.ws, sc.cam, sc.focal
             sc.ws, sc.cam, sc.focal = ws, cam, focal
+            h = sc.gen.synthesis_network.register_forward_hook(keep_planes)
             try:
                 out = reference_render(sc, res, samples, noise, grad=True)
             finally:
                 sc.ws, sc.cam, sc.focal = keep
-        loss = (out[0] * w_rgb).sum() + (out[2] * w_mask).sum()
+            loss = (out[0] * w_rgb).sum() + (out[2] * w_mask).sum()
+        else:                              # the reference in float64: the deterministic ground truth
+            sc64 = as_double(sc)
+            sc64.gen.requires_grad_(False)
+            ws, cam = ws.detach().double().requires_grad_(), cam.detach().double().requires_grad_()
+            focal = None if focal is None else focal.detach().double().requires_grad_()
+            sc64.ws, sc64.cam, sc64.focal = ws, cam, focal
+            h = sc64.gen.synthesis_network.register_forward_hook(keep_planes)
+            out = reference_render(sc64, res, samples, [n.double() for n in noise], grad=True)
+            loss = (out[0] * w_rgb.double()).sum() + (out[2] * w_mask.double()).sum()
+        h.remove()
         loss.backward()
+        g_planes.append(kept['planes'].grad.detach().clone())
+        if which == 'ref':
+            planes32.append(kept['planes'].detach())
         return float(loss.detach()), ws.grad, cam.grad, None if focal is None else focal.grad
+
+    def run_renderer_only_float64():
+        """The float64 reference on the SAME planes and colour table the fp32 implementations rendered (the producer's own
+        fp32 rounding - MIOpen's, 1e-6 relative, amplified ~1e3 by the texel differences every coordinate gradient is made
+        of - is then common to all three and drops out): d loss / d planes, camera, focal of the RENDERER alone."""
+        sc64 = as_double(sc)
+        sc64.gen.requires_grad_(False)
+        planes = planes32[0].double().requires_grad_()
+        cam = sc.cam.detach().double().requires_grad_()
+        focal = None if sc.focal is None else sc.focal.detach().double().requires_grad_()
+        sc64.cam, sc64.focal = cam, focal
+        extra = {}
+        if sc.gen.attention_values > 0:
+            with torch.no_grad():
+                extra = {'attention_values': _attention(sc.gen, sc.ws).double()}
+        with frozen_producer(sc64.gen, planes):
+            out = reference_render(sc64, res, samples, [n.double() for n in noise], grad=True, extra_model_inputs=extra)
+        loss = (out[0] * w_rgb.double()).sum() + (out[2] * w_mask.double()).sum()
+        loss.backward()
+        return planes.grad, cam.grad, None if focal is None else focal.grad
+    g_planes, planes32 = [], []
     for mod in (sc.gen, sc.hip):
         mod.requires_grad_(False)
     l_h, gws_h, gcam_h, gf_h = run('hip')
@@ -251,6 +401,23 @@ def gradients(sc, res, samples, seed=5):
     rep = {'loss_hip': l_h, 'loss_reference': l_r, 'g_ws': rel_err(gws_h, gws_r), 'g_cam': rel_err(gcam_h[:, :3], gcam_r[:, :3])}
     if gf_h is not None:
         rep['g_focal'] = rel_err(gf_h, gf_r)
+    rep['g_planes'] = rel_err(g_planes[0], g_planes[1])
+    if float64:
+        l_d, gws_d, gcam_d, gf_d = run('ref64')
+        rep['loss_reference_float64'] = l_d
+        rep['hip_vs_float64'] = {'g_ws': rel_err(gws_h, gws_d), 'g_cam': rel_err(gcam_h[:, :3], gcam_d[:, :3]),
+                                 'g_planes': rel_err(g_planes[0], g_planes[2])}
+        rep['reference_vs_float64'] = {'g_ws': rel_err(gws_r, gws_d), 'g_cam': rel_err(gcam_r[:, :3], gcam_d[:, :3]),
+                                       'g_planes': rel_err(g_planes[1], g_planes[2])}
+        if gf_h is not None:
+            rep['hip_vs_float64']['g_focal'] = rel_err(gf_h, gf_d)
+            rep['reference_vs_float64']['g_focal'] = rel_err(gf_r, gf_d)
+        gp_f, gcam_f, gf_f = run_renderer_only_float64()
+        rep['renderer_only_hip_vs_float64'] = {'g_planes': rel_err(g_planes[0], gp_f), 'g_cam': rel_err(gcam_h[:, :3], gcam_f[:, :3])}
+        rep['renderer_only_reference_vs_float64'] = {'g_planes': rel_err(g_planes[1], gp_f), 'g_cam': rel_err(gcam_r[:, :3], gcam_f[:, :3])}
+        if gf_h is not None:
+            rep['renderer_only_hip_vs_float64']['g_focal'] = rel_err(gf_h, gf_f)
+            rep['renderer_only_reference_vs_float64']['g_focal'] = rel_err(gf_r, gf_f)
     return rep
 
 
@@ -361,31 +528,49 @@ def inversion(sc, res, samples, steps=8, lr=2e-3, seed=11):
 REGULARISER_NAMES = ['sdf_eikonal_loss', 'sdf_distance_loss', 'total_variation_loss', 'entropy_loss']
 
 
-def regularisers(sc, seed=321, weights=(1.0, 0.7, 3.0, 0.01)):
+def regularisers(sc, seed=321, weights=(1.0, 0.7, 3.0, 0.01), float64=True):
     """The G step's regulariser branch (generator.py:505-585) on the real Generator in training mode: the reference's own
     forward against `attach(model, hip_regularisers=True)`, same seed (= the same two draws), losses and gradients w.r.t. the
     latents (through the synthesis network), the decoder and beta.  Returns relative errors."""
     import nerf_from_image_amd.generator as nfi_gen
 
-    def run(model):
+    def run(model, double=False):
         model = model.train().requires_grad_(True)
-        ws = sc.ws.detach().clone().requires_grad_()
+        ws = sc.ws.detach().clone().requires_grad_() if not double else sc.ws.detach().double().requires_grad_()
         torch.manual_seed(seed)
-        out = model(None, ws, REGULARISER_NAMES)
-        assert set(out) == set(REGULARISER_NAMES)
-        loss = sum(w * out[n].sum() for w, n in zip(weights, REGULARISER_NAMES))
-        dec = model.decoder.net
-        grads = torch.autograd.grad(loss, [ws, dec[0].weight, dec[0].bias, dec[2].weight, model.beta])
+        with (float32_draws_in_float64() if double else contextlib.nullcontext()):
+            out = model(None, ws, REGULARISER_NAMES)
+            assert set(out) == set(REGULARISER_NAMES)
+            loss = sum(w * out[n].sum() for w, n in zip(weights, REGULARISER_NAMES))
+            dec = model.decoder.net
+            grads = torch.autograd.grad(loss, [ws, dec[0].weight, dec[0].bias, dec[2].weight, model.beta])
         return {n: out[n].detach() for n in REGULARISER_NAMES}, grads
+    names = ['ws', 'w1', 'b1', 'w2', 'beta']
     ref_out, ref_g = run(copy.deepcopy(sc.gen))
     hip_out, hip_g = run(nfi_gen.attach(copy.deepcopy(sc.gen), hip_regularisers=True))
     rep = {'loss_rel': {n: max_err(hip_out[n], ref_out[n]) / float(ref_out[n].abs().max()) for n in REGULARISER_NAMES},
            'loss_reference': {n: ref_out[n].tolist() for n in REGULARISER_NAMES},
-           'grad_rel_l2': {name: rel_err(a, b) for name, a, b in zip(['ws', 'w1', 'b1', 'w2', 'beta'], hip_g, ref_g)}}
+           'grad_rel_l2': {name: rel_err(a, b) for name, a, b in zip(names, hip_g, ref_g)}}
+    if float64:
+        d_out, d_g = run(copy.deepcopy(sc.gen).double(), double=True)
+        rep['hip_vs_float64'] = {name: rel_err(a, b) for name, a, b in zip(names, hip_g, d_g)}
+        rep['reference_vs_float64'] = {name: rel_err(a, b) for name, a, b in zip(names, ref_g, d_g)}
+        rep['loss_rel_hip_vs_float64'] = {n: max_err(hip_out[n], d_out[n]) / float(d_out[n].abs().max()) for n in REGULARISER_NAMES}
     return rep
 
 
-def training_step(sc, res, samples, seed=77, reg_weight=0.1):
+def _summary(g_a, g_b):
+    """Relative L2 error over ALL tensors of g_a against g_b, and the worst tensor among those that carry at least 1e-3 of
+    the whole gradient's norm."""
+    num = sum(float((g_a[n].double() - g_b[n].double()).pow(2).sum()) for n in g_b)
+    den = sum(float(g_b[n].double().pow(2).sum()) for n in g_b)
+    per = {n: rel_err(g_a[n], g_b[n]) for n in g_b}
+    big = {n: e for n, e in per.items() if float(g_b[n].double().norm()) >= 1e-3 * den ** 0.5}
+    worst = max(big, key=big.get)
+    return {'all_parameters': (num / den) ** 0.5, 'worst_tensor': worst, 'worst_tensor_rel_l2': big[worst], 'significant_tensors': len(big)}
+
+
+def training_step(sc, res, samples, seed=77, reg_weight=0.1, float64=True):
     """One generator-side training step in cfg4's shape on the REAL Generator (training mode, latents through the mapping
     network): render + image / alpha loss (run.py:980-1010), regulariser forward (974-979, 1011-1028), one backward - the
     reference's own render + forward against the drop-in render + `attach(..., hip_regularisers=True)`, same noise and
@@ -399,25 +584,31 @@ def training_step(sc, res, samples, seed=77, reg_weight=0.1):
     ref_render, _ = reference.load_render(sc.args, sc.dcfg, unscripted_stages=True)
     hip_render_fn = nfi_render.make_render(sc.args, sc.dcfg)
 
-    def run(model, render_fn):
+    def run(model, render_fn, double=False):
         model = model.train().requires_grad_(True)
         for p_ in model.parameters():
             p_.grad = None
-        with ReplayNoise(noise):
-            out = render_fn(model, res, res, sc.cam, sc.focal, None, sc.bbox, sc.z, samples)
-        loss = ((out[0] - t_rgb) ** 2).mean() + ((out[2] - t_mask) ** 2).mean()
+        cast = (lambda t: None if t is None else t.double()) if double else (lambda t: t)
+        with ReplayNoise([cast(n) for n in noise]), (default_dtype(torch.float64) if double else contextlib.nullcontext()):
+            out = render_fn(model, res, res, cast(sc.cam), cast(sc.focal), None, cast(sc.bbox), cast(sc.z), samples)
+        loss = ((out[0] - cast(t_rgb)) ** 2).mean() + ((out[2] - cast(t_mask)) ** 2).mean()
         torch.manual_seed(seed)
-        reg = model(None, sc.z, ['sdf_eikonal_loss', 'sdf_distance_loss'])
-        loss = loss + reg_weight * (reg['sdf_eikonal_loss'].mean() + reg['sdf_distance_loss'].mean())
-        loss.backward()
+        with (float32_draws_in_float64() if double else contextlib.nullcontext()):
+            reg = model(None, cast(sc.z), ['sdf_eikonal_loss', 'sdf_distance_loss'])
+            loss = loss + reg_weight * (reg['sdf_eikonal_loss'].mean() + reg['sdf_distance_loss'].mean())
+            loss.backward()
         return float(loss.detach()), {n: p_.grad.detach().clone() for n, p_ in model.named_parameters() if p_.grad is not None}
     l_r, g_r = run(copy.deepcopy(sc.gen), ref_render)
     l_h, g_h = run(nfi_gen.attach(copy.deepcopy(sc.gen), hip_regularisers=True), hip_render_fn)
     assert set(g_r) == set(g_h), set(g_r) ^ set(g_h)
-    num = sum(float((g_h[n].double() - g_r[n].double()).pow(2).sum()) for n in g_r)
-    den = sum(float(g_r[n].double().pow(2).sum()) for n in g_r)
-    per = {n: rel_err(g_h[n], g_r[n]) for n in g_r}
-    big = {n: e for n, e in per.items() if float(g_r[n].double().norm()) >= 1e-3 * den ** 0.5}
-    worst = max(big, key=big.get)
-    return {'loss_hip': l_h, 'loss_reference': l_r, 'n_parameter_tensors': len(g_r), 'grad_rel_l2_all_parameters': (num / den) ** 0.5,
-            'worst_tensor_among_the_significant': worst, 'worst_tensor_rel_l2': big[worst], 'significant_tensors': len(big)}
+    s_ = _summary(g_h, g_r)
+    rep = {'loss_hip': l_h, 'loss_reference': l_r, 'n_parameter_tensors': len(g_r), 'grad_rel_l2_all_parameters': s_['all_parameters'],
+           'worst_tensor_among_the_significant': s_['worst_tensor'], 'worst_tensor_rel_l2': s_['worst_tensor_rel_l2'],
+           'significant_tensors': s_['significant_tensors']}
+    if float64:
+        l_d, g_d = run(copy.deepcopy(sc.gen).double(), ref_render, double=True)
+        assert set(g_d) == set(g_h)
+        rep['loss_reference_float64'] = l_d
+        rep['hip_vs_float64'] = _summary(g_h, g_d)
+        rep['reference_vs_float64'] = _summary(g_r, g_d)
+    return rep

@@ -291,6 +291,28 @@ def test_fused_render(case):
         exact(r2[k], r[k], 'skip_missed_rays ' + k)
 
 
+@pytest.mark.parametrize('name', ['persp_s96_black_fine_det', 'persp_s128_fine_rand'])
+def test_wide_kernel_semantics_table_precision(gpu_device, name):
+    """The 128 + 128 kernel (64 < S <= 128: render_fwd_wide_kernel) parks the per-sample softmax probabilities as unorm16
+    (tile_epilogue<SEMP < 0>: round to nearest, |error| <= 2^-17 = 7.7e-6 per sample, probabilities under 7.6e-6 become 0)
+    where the 64 + 64 kernel keeps fp32 - the composited map is a convex combination of them (weights sum to the mask <= 1),
+    so its error is bounded by the same 7.7e-6 plus the fp32 kernel's own ~1e-6.  Explicit bound for the wide kernel: 1e-5
+    against the oracle AND the committed reference output, every pixel's map sums to the mask within 2e-5 (A = 10 roundings
+    of either sign), and rgb / depth / mask are untouched by the table's format."""
+    meta, t = load_golden(name)
+    assert meta['S'] > 64 and meta['A'] > 0
+    o = oracle_render(meta, t, 'cpu')
+    plain = hip_render(meta, t, gpu_device, skip_missed_rays=True)
+    r = hip_render(meta, t, gpu_device, skip_missed_rays=True, want_semantics=True)
+    for k in ('rgb', 'depth', 'mask'):
+        exact(r[k], plain[k], 'semantics launch (wide kernel), %s' % k)
+    e = err(r['semantics'], o['semantics'])
+    assert e['nonfinite'] == 0 and e['max'] <= 1e-5, ('semantic map, wide kernel (unorm16 table)', e)     # measured <= 4e-6
+    close(r['semantics'], t['ref_semantics'], 1e-5, 'semantic map vs committed reference output')
+    close(r['semantics'].sum(-1), r['mask'], 2e-5, 'sum of the semantic map = mask')
+    assert float(r['semantics'].min()) >= 0.0
+
+
 def test_fused_render_extra_maps(case):
     """compute_semantics / compute_coords inside the fused kernel (run.py:312-338, lib/nerf_utils.py:147-159): the maps
     come out of the SAME launch, rgb / depth / mask stay bit-identical to the plain render, the maps match the oracle

@@ -1,7 +1,7 @@
 """The legs of bench.py that are NOT the timed headline: the CPU baseline and parity figure (the reference itself, from the
 staged oracle/_ref; the oracle restatement where that is missing), the reference renderer on this GPU under PyTorch-ROCm (the
->= 10 x target's denominator), and the `extras` block (render-only rates per storage type / workload, fine-pass termination,
-the composited extra maps, the staged-path comparison, synthetic inversion and training steps).
+>= 10 x target's denominator), and the `extras` block (render-only rates per storage type / workload, the composited extra maps, the
+staged-path comparison, the end-to-end legs on the real Generator, the 16-bit storage deviation).
 
 TEST / MEASUREMENT INFRASTRUCTURE: this is the only place outside tests/ where bench.py reaches oracle/ - after the timed
 region, as the checker and the baseline, never as the thing measured (see oracle/nfi_oracle.py header)."""
@@ -218,18 +218,6 @@ def extras(dev, ops):
     exact_out = {}
     for name, (n_img, radius, tdt, kw) in cases.items():
         ex['render_only'][name], exact_out[name] = time_render(ops, dev, n_img, radius, tdt, **kw)
-    # ray termination in the FINE pass at eps = 1e-5 (coarse pass, pdf and sample indices untouched; inside the 1e-4 parity
-    # budget: tests/test_hip_full_size.py) - BASELINE cfg5's "early termination + sample compaction"
-    term = {}
-    for name in ('b8_chairs_fp32_texels', 'b8_all_rays_hit_fp32_texels', 'b2_cfg5_256px_128+128_fp16_texels'):
-        n_img, radius, tdt, kw = cases[name]
-        for eps in (1e-5, 1e-3):
-            r, out = time_render(ops, dev, n_img, radius, tdt, termination_eps=eps, **kw)
-            r['max_abs_drgb_vs_exact'] = float((out['rgb'] - exact_out[name]['rgb']).abs().max())
-            r['max_abs_dmask_vs_exact'] = float((out['mask'] - exact_out[name]['mask']).abs().max())
-            r['speedup_vs_exact'] = r['rays_per_s'] / ex['render_only'][name]['rays_per_s']
-            term['%s_eps%g' % (name, eps)] = r
-    ex['fine_pass_termination'] = term
     # the composited extra maps of run.py:312-338 from the SAME fused launch (compute_coords: every encoder-training
     # iteration, run.py:1639-1646; compute_semantics: every inversion eval batch, run.py:2036-2051), with the staged path
     # (one launch per stage, every per-sample tensor through HBM: what these calls cost before round 4) beside them
@@ -251,31 +239,32 @@ def extras(dev, ops):
     ex['pytorch_rocm_reference_path'] = pytorch_rocm_reference(dev)
     sys.path.insert(0, os.path.join(ROOT, 'tools'))
     sys.path.insert(0, os.path.join(ROOT, 'tests'))
-    # BASELINE config 3 stand-in (no p3d_car data / checkpoint exists offline): synthetic inversion, 30 Adam steps on
-    # latent + pose, HIP renderer (forward + HIP backward kernels) vs the oracle under PyTorch-ROCm autograd, same noise
-    try:
-        import inversion_synthetic
-        h_hip, h_ref, t_hip, t_ref = inversion_synthetic.run(dev, res=128, samples=64, batch=4, steps=30, plane_res=256)
-        ex['inversion_synthetic'] = {
-            'psnr_start': h_hip[0][0], 'psnr_hip': h_hip[-1][0], 'psnr_reference_path': h_ref[-1][0],
-            'iou_hip': h_hip[-1][1], 'iou_reference_path': h_ref[-1][1],
-            'ms_per_step_hip': t_hip * 1e3, 'ms_per_step_reference_path': t_ref * 1e3,
-            'sample': '4 images 128x128, 64+64 samples, 30 Adam steps (lr 2e-3, betas 0.9/0.95) on latent + pose, '
-                      'stand-in plane producer; reference path = oracle ops under PyTorch-ROCm autograd; median step'}
-    except Exception as e:      # reported, never fatal for the headline line
-        ex['inversion_synthetic'] = {'error': repr(e)}
-    # BASELINE config 4 stand-in: one generator-side training step in cub geometry (ortho camera, scene_range 2.0,
-    # image + alpha loss, eikonal + distance regularisers), HIP path vs the oracle's op sequence under autograd
-    try:
-        import train_step_synthetic
-        ts = train_step_synthetic.run(dev, batch=4, res=128, samples=64, steps=6, verbose=False)
-        ex['train_step_synthetic'] = {
-            'ms_per_step_hip': ts['hip']['ms_per_step'], 'ms_per_step_reference_path': ts['reference_path']['ms_per_step'],
-            'loss_hip': ts['hip']['loss'], 'loss_reference_path': ts['reference_path']['loss'],
-            'sample': '4 images 128x128 ortho, 64+64 samples, render fwd + regulariser branch + bwd into plane producer, '
-                      'decoder, beta, alpha; stand-in plane producer; median of 6 steps; different noise draws per path'}
-    except Exception as e:
-        ex['train_step_synthetic'] = {'error': repr(e)}
+    # END TO END on the real reference classes, plane producer included (SURVEY.md 8(d) metric (ii)): render() incl.
+    # Generator.forward at cfg2 B = 1 / 4 / 8, one --run_inversion step (cfg3 shape), one generator-side GAN step (cfg4
+    # shape) - the HIP drop-in against the untouched reference on this GPU, same weights (tools/end_to_end.py; the kernel
+    # split of the same legs: profiles/r6/e2e/)
+    from oracle import reference
+    if reference.available():
+        try:
+            import end_to_end
+            ex['end_to_end_real_generator'] = end_to_end.summary(dev, quick=True)
+        except Exception as e:      # reported, never fatal for the headline line
+            ex['end_to_end_real_generator'] = {'error': repr(e)}
+        # what 16-bit plane STORAGE costs against the fp32 reference (BASELINE words cfg2 with bf16, cfg5 with fp16)
+        try:
+            import reference_cases as rc
+            dev_ = {}
+            scenes = {}
+            for name in ('cfg2_b8_128px_64+64_bf16_texels', 'cfg2_b8_128px_64+64_fp16_texels'):
+                r = rc.config_case(name, dev, cpu_images=0, scenes=scenes)
+                dev_[name] = {'max_abs': r['vs_reference_gpu'], 'mean_abs': r['mean_abs_vs_reference_gpu'],
+                              'against': 'run.py::render + the real Generator on fp32 planes, PyTorch-ROCm, same noise'}
+            ex['texel_storage_vs_fp32_reference'] = dev_
+        except Exception as e:
+            ex['texel_storage_vs_fp32_reference'] = {'error': repr(e)}
+        torch.cuda.empty_cache()
+    else:
+        ex['end_to_end_real_generator'] = {'error': 'reference sources not staged (oracle/make_ref.py)'}
     return ex
 
 

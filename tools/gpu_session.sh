@@ -1,6 +1,6 @@
 #!/bin/bash
 # One GPU-box session: tests, parity report, bench (render + train), rocprofv3 stats + PMC of the render kernel.
-# usage (via gpurun): bash tools/gpu_session.sh <tag> [what...]   what: tests report refreport bench train pmc pmc_bwd bwd handoff prof_inv prof_train prof_bench regulariser train_bwd stress   (default: tests report bench train pmc)
+# usage (via gpurun): bash tools/gpu_session.sh <tag> [what...]   what: tests report refreport e2e e2e_prof bench train pmc pmc_bwd bwd handoff prof_inv prof_train prof_bench regulariser train_bwd stress   (default: tests report bench train pmc)
 TAG=${1:-s}
 shift
 WHAT=${@:-tests report bench train pmc}
@@ -16,10 +16,14 @@ for w in $WHAT; do
   case $w in
     tests)
       timeout 1500 python -m pytest tests -m gpu -q --durations=15 > $O/pytest.log 2>&1; echo "pytest rc=$?" >> $O/env.txt; tail -5 $O/pytest.log;;
+    gradspread)
+      timeout 900 python tools/gradient_spread.py 3 > $O/gradient_spread.json 2> $O/gradient_spread.err; echo "gradspread rc=$?" >> $O/env.txt; tail -3 $O/gradient_spread.err;;
+    reftests)
+      timeout 1500 python -m pytest tests/test_reference_gpu.py -m gpu -q --durations=10 > $O/pytest_reference.log 2>&1; echo "reftests rc=$?" >> $O/env.txt; tail -8 $O/pytest_reference.log;;
     report)
       timeout 600 python tools/parity_report.py > $O/parity_report.json 2> $O/parity_report.err; echo "report rc=$?" >> $O/env.txt;;
     refreport)
-      timeout 600 python tools/reference_report.py > $O/reference_parity.json 2> $O/reference_parity.err; echo "refreport rc=$?" >> $O/env.txt;;
+      timeout 1500 python tools/reference_report.py $REFREPORT_SECTIONS > $O/reference_parity.json 2> $O/reference_parity.err; echo "refreport rc=$?" >> $O/env.txt;;
     bench)
       timeout 900 python bench.py > $O/bench.json 2> $O/bench.err; echo "bench rc=$?" >> $O/env.txt; tail -c 600 $O/bench.json;;
     train)
@@ -74,6 +78,41 @@ PY
     prof_bench)
       (cd /tmp && export TMPDIR=/tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_bench -o b -- python $R/bench.py --steps 100 --warmup 20 --no-extras --no-cpu-baseline --no-variants > $O/prof_bench.log 2>&1); tail -c 300 $O/prof_bench.log
       python tools/kstats.py $O/prof_bench 8;;
+    e2e)
+      # end to end on the REAL reference classes (plane producer included), both implementations: tools/end_to_end.py
+      timeout 1500 python tools/end_to_end.py > $O/end_to_end.json 2> $O/end_to_end.err; echo "e2e rc=$?" >> $O/env.txt; tail -c 1500 $O/end_to_end.json;;
+    e2e_prof)
+      # rocprofv3 kernel traces of the end-to-end legs with phase markers, cut into renderer / producer / other
+      mkdir -p $O/e2e
+      run_leg() {   # name, end_to_end.py arguments...
+        n=$1; shift
+        (cd /tmp && export TMPDIR=/tmp && timeout 420 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/e2e_$n -o t -- \
+           python $R/tools/end_to_end.py --markers --sidecar /tmp/e2e_$n.json "$@" > $O/e2e/$n.log 2>&1)
+        python tools/phase_split.py /tmp/e2e_$n /tmp/e2e_$n.json > $O/e2e/split_$n.json 2>> $O/e2e/$n.log
+        f=$(find /tmp/e2e_$n -name '*kernel_stats.csv' | head -1); [ -n "$f" ] && cp "$f" $O/e2e/kernel_stats_$n.csv
+        python - <<PY
+import json
+try:
+    d = json.load(open("$O/e2e/split_$n.json"))
+    print("$n", 'step %.2f ms' % d['step_ms_events_median'], {k: round(v, 3) for k, v in d['group_ms_per_step'].items()})
+except Exception as e:
+    print("$n", 'FAILED', e)
+PY
+      }
+      run_leg render_b8_hip --leg render --impl hip --batch 8 --iters 20
+      run_leg render_b8_hip_bf16 --leg render --impl hip --batch 8 --iters 20 --texels bf16
+      run_leg render_b8_reference --leg render --impl reference --batch 8 --iters 10
+      run_leg render_b1_hip --leg render --impl hip --batch 1 --iters 20
+      run_leg render_b8_hip_channels_last --leg render --impl hip --batch 8 --iters 20 --channels-last
+      run_leg render_b8_reference_channels_last --leg render --impl reference --batch 8 --iters 10 --channels-last
+      run_leg inversion_hip --leg inversion --impl hip
+      run_leg inversion_reference --leg inversion --impl reference
+      run_leg gstep_hip --leg gstep --impl hip
+      run_leg gstep_hip_fused_handoff --leg gstep --impl hip --fused-handoff
+      run_leg gstep_hip_path_length --leg gstep --impl hip --path-length
+      run_leg gstep_reference --leg gstep --impl reference
+      run_leg gstep_reference_path_length --leg gstep --impl reference --path-length
+      ;;
     regulariser)
       timeout 300 python tools/bench_regulariser.py > $O/bench_regulariser.log 2>&1; tail -2 $O/bench_regulariser.log;;
     train_bwd)
