@@ -287,10 +287,10 @@ def main():
     ap.add_argument('--texels', choices=('fp32', 'fp16', 'bf16'), default='fp32',
                     help='storage type of the texels the kernels gather from (arithmetic stays fp32)')
     ap.add_argument('--pipelined', action='store_true',
-                    help='render mode: `value` under the two-stream schedule instead of the serial one (DESIGN.md 4.3)')
+                    help='render mode: `value` under the two-stream schedule instead of the serial one (HISTORY.md 4.3)')
     ap.add_argument('--prewarm-ms', type=float, default=300.0,
                     help='render mode: untimed steps for this long before the W warm-up steps (allocator and shader clock '
-                         'in steady state, DESIGN.md 4.3); 0 switches it off')
+                         'in steady state, HISTORY.md 4.3); 0 switches it off')
     ap.add_argument('--no-variants', action='store_true',
                     help='render mode: skip the value_mlp_exact_fp32 / value_all_rays_hit / value_pipelined legs')
     ap.add_argument('--prefetch-depth', type=int, default=2,

@@ -141,6 +141,15 @@ def as_double(sc):
     return twin
 
 
+def deterministic_producer():
+    """The producer's convolutions restricted to MIOpen's deterministic solvers (torch.backends.cudnn.deterministic).  Left
+    to itself MIOpen picks split-K weight-gradient kernels that sum with fp32 atomics in arrival order, and d loss / d
+    latents then moves by 1e-5 ... 2e-3 (relative L2) from one run to the next IN BOTH IMPLEMENTATIONS - the renderer's share of
+    a comparison drowns in it.  With the flag every gradient comparison of this file repeats to all printed digits
+    (profiles/r6/gradient_spread.json: three runs each way)."""
+    return torch.backends.cudnn.flags(enabled=True, deterministic=True, benchmark=False)
+
+
 @contextlib.contextmanager
 def default_dtype(dtype):
     """torch's default dtype for the duration: the reference builds a few tensors without naming one (arange(S) / S as
@@ -570,7 +579,7 @@ def _summary(g_a, g_b):
     return {'all_parameters': (num / den) ** 0.5, 'worst_tensor': worst, 'worst_tensor_rel_l2': big[worst], 'significant_tensors': len(big)}
 
 
-def training_step(sc, res, samples, seed=77, reg_weight=0.1, float64=True):
+def training_step(sc, res, samples, seed=77, reg_weight=0.1, float64=True, fused_handoff=False):
     """One generator-side training step in cfg4's shape on the REAL Generator (training mode, latents through the mapping
     network): render + image / alpha loss (run.py:980-1010), regulariser forward (974-979, 1011-1028), one backward - the
     reference's own render + forward against the drop-in render + `attach(..., hip_regularisers=True)`, same noise and
@@ -599,7 +608,7 @@ def training_step(sc, res, samples, seed=77, reg_weight=0.1, float64=True):
             loss.backward()
         return float(loss.detach()), {n: p_.grad.detach().clone() for n, p_ in model.named_parameters() if p_.grad is not None}
     l_r, g_r = run(copy.deepcopy(sc.gen), ref_render)
-    l_h, g_h = run(nfi_gen.attach(copy.deepcopy(sc.gen), hip_regularisers=True), hip_render_fn)
+    l_h, g_h = run(nfi_gen.attach(copy.deepcopy(sc.gen), hip_regularisers=True, fused_handoff=fused_handoff), hip_render_fn)
     assert set(g_r) == set(g_h), set(g_r) ^ set(g_h)
     s_ = _summary(g_h, g_r)
     rep = {'loss_hip': l_h, 'loss_reference': l_r, 'n_parameter_tensors': len(g_r), 'grad_rel_l2_all_parameters': s_['all_parameters'],

@@ -159,38 +159,66 @@ def test_view_direction_decoder_matches_the_real_reference(gpu_device):
         _check(rep, ('rgb', 'depth', 'mask', 'extra'))
 
 
+# Gradients with the producer's convolutions on MIOpen's deterministic solvers (rc.deterministic_producer): every figure
+# below repeats to all printed digits from run to run (profiles/r6/gradient_spread.json, three runs; without the flag d loss /
+# d latents moves by 1e-5 ... 2e-3 between runs in BOTH implementations - the producer's atomic split-K weight gradients).
+# Relative L2 of the HIP gradient against the fp32 reference's, as MEASURED; asserted at 3 x.
+GRADIENT_MEASURED = {
+    #          d/d latents  d/d planes  d/d camera  d/d focal
+    'chairs': dict(g_ws=7.8e-6, g_planes=4.9e-5, g_cam=4.5e-5, g_focal=8.1e-5),
+    'p3d': dict(g_ws=7.5e-6, g_planes=5.2e-5, g_cam=4.9e-4, g_focal=3.5e-4),
+    # (orthographic: the reference's own fp32 sum of the camera gradient is 6e-4 off float64, ours 4e-5 - below)
+    'cub': dict(g_ws=5.4e-6, g_planes=5.2e-5, g_cam=6.3e-4),
+    'carla': dict(g_ws=3.8e-6, g_planes=2.8e-5, g_cam=2.0e-5, g_focal=1.3e-6),
+}
+
+
 @pytest.mark.parametrize('geometry', ['chairs', 'p3d', 'cub', 'carla'])
 def test_gradients_match_the_real_reference(gpu_device, geometry):
     """Forward + backward through the real plane producer: d loss / d ws (through the StyleGAN2 synthesis network and
-    the texture mapper), d loss / d camera matrix, d loss / d focal - the leaves the inversion loop optimises
-    (run.py:2264-2299).  The reference's own backward scatters with fp32 atomics in arrival order."""
+    the texture mapper), d loss / d planes (what the renderer hands the producer's backward), d loss / d camera matrix,
+    d loss / d focal - the leaves the inversion loop optimises (run.py:2264-2299).
+
+    Two comparators.  (1) The fp32 reference, at 3 x the measured figure.  (2) The reference in FLOAT64 on the same device
+    (rc.as_double) as ground truth for the RENDERER: the float64 run renders the very planes the fp32 runs rendered, so the
+    producer's own rounding is common to all three; the HIP gradient may be at most 2.5 x as far from it as the fp32
+    reference is (measured: planes 1.0 - 2.0 x, camera 0.07 - 1.0 x, focal 1.0 - 2.2 x; the planes' figure is the
+    backward's per-tile power-of-two operand scaling, 2^-22 of a tile's largest entry, against the reference's fp32
+    atomics)."""
     _require_reference()
-    sc = rc.build_scene(geometry, 2, gpu_device)
-    # (carla: --use_viewdir - the camera gradient also flows through the PyTorch ViewDirectionMapper's view directions)
-    rep = rc.gradients(sc, 128, 64) if geometry != 'carla' else rc.gradients(sc, 64, 32)
-    assert abs(rep['loss_hip'] - rep['loss_reference']) <= 1e-4 * abs(rep['loss_reference']) + 1e-3, rep
-    # (measured over the round's runs: g_ws 1.1e-5 ... 6.4e-4 - the spread is the reference's own atomic scatter order -,
-    #  g_cam <= 5.1e-4, g_focal <= 3.6e-4)
-    assert rep['g_ws'] <= 5e-3, rep
-    assert rep['g_cam'] <= 1e-2, rep
-    if 'g_focal' in rep:
-        assert rep['g_focal'] <= 1e-2, rep
+    with rc.deterministic_producer():
+        sc = rc.build_scene(geometry, 2, gpu_device)
+        # (carla: --use_viewdir - the camera gradient also flows through the PyTorch ViewDirectionMapper's view directions)
+        rep = rc.gradients(sc, 128, 64) if geometry != 'carla' else rc.gradients(sc, 64, 32)
+    assert abs(rep['loss_hip'] - rep['loss_reference']) <= 1e-5 * abs(rep['loss_reference']), rep
+    for k, measured in GRADIENT_MEASURED[geometry].items():
+        assert rep[k] <= 3.0 * measured + 1e-6, (k, rep[k], 'measured', measured, rep)
+    ours, theirs = rep['renderer_only_hip_vs_float64'], rep['renderer_only_reference_vs_float64']
+    for k in ours:
+        assert ours[k] <= 2.5 * theirs[k] + 1e-5, (k, 'vs float64: HIP', ours[k], 'fp32 reference', theirs[k], rep)
+    # the whole graph in float64 (producer included): both fp32 implementations carry the producer's rounding
+    for k in ('g_ws', 'g_planes'):
+        assert rep['hip_vs_float64'][k] <= 2.5 * rep['reference_vs_float64'][k] + 1e-5, (k, rep)
 
 
 def test_inversion_steps_match_the_real_reference(gpu_device):
-    """BASELINE cfg3's loop on the real Generator at size (p3d_car-like geometry, 4 images x 128 x 128 x (64 + 64), Adam on
-    latents + camera + focal, run.py:2232-2299) with a synthetic target (no p3d_car data / checkpoint exists offline): at
-    every point of the REFERENCE's trajectory the HIP path gives the same loss and gradients, and its own trajectory
-    reaches the same PSNR / IoU."""
+    """BASELINE cfg3's loop on the real Generator at size and length (p3d_car-like geometry, 4 images x 128 x 128 x (64 + 64),
+    30 steps of Adam on latents + camera + focal, run.py:2232-2299, --inv_steps 30) with a synthetic target (no p3d_car
+    data / checkpoint exists offline): at every point of the REFERENCE's trajectory the HIP path gives the same loss and
+    gradients, and its own trajectory reaches the same PSNR / IoU.  Producer on deterministic MIOpen solvers: the figures
+    repeat (measured, profiles/r6/reference_parity.json: loss <= 2.1e-5, d/d latents <= 1.2e-4, camera <= 3.1e-5, focal <=
+    1.0e-4 - the spikes are single samples that the two fp32 forwards place on different sides of a texel edge)."""
     _require_reference()
-    sc = rc.build_scene('p3d', 4, gpu_device)
-    r = rc.inversion(sc, 128, 64, steps=8)
+    with rc.deterministic_producer():
+        sc = rc.build_scene('p3d', 4, gpu_device)
+        r = rc.inversion(sc, 128, 64, steps=30)
     for a in r['along_reference_trajectory']:
-        assert a['loss_rel'] <= 1e-4 and a['g_ws'] <= 5e-3 and a['g_cam'] <= 1e-2 and a.get('g_focal', 0.0) <= 1e-2, a
+        assert a['loss_rel'] <= 6.5e-5 and a['g_ws'] <= 3.6e-4 and a['g_cam'] <= 1e-4 and a.get('g_focal', 0.0) <= 3e-4, a
     (l0, p0, i0), (l1, p1, i1) = r['reference'][0], r['reference'][-1]
     (h0, q0, j0), (h1, q1, j1) = r['hip'][0], r['hip'][-1]
-    assert l1 < l0 and h1 < h0, (r['reference'], r['hip'])                 # both descend
-    assert abs(q1 - p1) <= 0.5 and abs(j1 - i1) <= 0.02, (r['reference'][-1], r['hip'][-1])
+    assert l1 < l0 and h1 < h0 and p1 > p0 + 1.0, (r['reference'], r['hip'])                 # both descend
+    # free-running trajectories (each its own Adam): measured 1e-5 dB apart after 8 steps
+    assert abs(q1 - p1) <= 0.05 and abs(j1 - i1) <= 0.002, (r['reference'][-1], r['hip'][-1])
 
 
 def test_regulariser_branch_on_the_real_generator(gpu_device):
@@ -198,30 +226,37 @@ def test_regulariser_branch_on_the_real_generator(gpu_device):
     `attach(model, hip_regularisers=True)` serves eikonal / distance / total-variation / entropy from the HIP kernels
     (`nfi_sdf_gradient_fwd/bwd`: the eikonal term's backward is the reference's DOUBLE backward through lib/ops.grid_sample2d)
     - same seed, same two draws - against the reference's own forward: losses and gradients w.r.t. the latents (through the
-    StyleGAN2 synthesis network), the decoder and beta."""
+    StyleGAN2 synthesis network), the decoder and beta.  Producer on deterministic MIOpen solvers; bounds = 3 x measured
+    (losses 5.2e-7; latents 1.9e-6 - 1.0e-3 without the flag -, W1 3.0e-6, b1 9.0e-7, W2 8.9e-7, beta 1.7e-6)."""
     _require_reference()
-    sc = rc.build_scene('cub', 2, gpu_device)
-    rep = rc.regularisers(sc)
-    assert max(rep['loss_rel'].values()) <= 1e-5, rep              # measured 6.3e-7
-    # measured: decoder / beta <= 3.4e-6; the latents' gradient - through the synthesis network, fed by two fp32 atomic
-    # scatters whose summation order differs from run to run - 1.6e-4 ... 1.1e-3 over the round's runs
-    assert max(v for k_, v in rep['grad_rel_l2'].items() if k_ != 'ws') <= 1e-4, rep
-    assert rep['grad_rel_l2']['ws'] <= 5e-3, rep
+    with rc.deterministic_producer():
+        sc = rc.build_scene('cub', 2, gpu_device)
+        rep = rc.regularisers(sc)
+    assert max(rep['loss_rel'].values()) <= 2e-6, rep
+    for k, bound in (('ws', 6e-6), ('w1', 9e-6), ('b1', 3e-6), ('w2', 3e-6), ('beta', 5e-6)):
+        assert rep['grad_rel_l2'][k] <= bound, (k, rep)
+    # against the reference in float64: the latents' gradient of BOTH fp32 implementations is 1.08e-3 from it (the producer)
+    assert rep['hip_vs_float64']['ws'] <= 1.5 * rep['reference_vs_float64']['ws'] + 1e-6, rep
 
 
-def test_generator_training_step_on_the_real_generator(gpu_device):
+@pytest.mark.parametrize('fused_handoff', [False, True])
+def test_generator_training_step_on_the_real_generator(gpu_device, fused_handoff):
     """BASELINE cfg4's generator step on the real class (cub-like: orthographic, scene_range 2.0, black background, 4 images
     x 128 x 128 x (64 + 64), model.train(), latents through the mapping network, image + alpha loss + eikonal / distance
     regularisers, ONE backward): the gradient of EVERY generator parameter - mapping network, StyleGAN2 synthesis, texture
-    mapper, decoder, beta, alpha - against the reference's own render + forward."""
+    mapper, decoder, beta, alpha - against the reference's own render + forward; with `fused_handoff=True` the last
+    synthesis block's tail (upsample + torgb + add, stylegan.py:424-443) runs in nfi_torgb_texels_fwd / _bwd as well.
+    Producer on deterministic MIOpen solvers; measured: loss 3.1e-7, all 116 tensors 8.0e-6, worst significant tensor
+    6.6e-5 (decoder.net.0.weight); both fp32 implementations 9.5e-5 from the float64 reference."""
     _require_reference()
-    sc = rc.build_scene('cub', 4, gpu_device)
-    rep = rc.training_step(sc, 128, 64)
-    assert abs(rep['loss_hip'] - rep['loss_reference']) <= 1e-5 * abs(rep['loss_reference']), rep
-    # measured (profiles/r5/reference_parity.json): 1.5e-5 over all 116 tensors, worst significant tensor 6.6e-5; the bounds
-    # leave room for the run-to-run spread of the two fp32 atomic scatters (the reference's and ours) behind the latents' path
-    assert rep['n_parameter_tensors'] > 100 and rep['grad_rel_l2_all_parameters'] <= 1e-3, rep
-    assert rep['worst_tensor_rel_l2'] <= 1e-2, rep
+    with rc.deterministic_producer():
+        sc = rc.build_scene('cub', 4, gpu_device)
+        rep = rc.training_step(sc, 128, 64, fused_handoff=fused_handoff)
+    assert abs(rep['loss_hip'] - rep['loss_reference']) <= 1e-6 * abs(rep['loss_reference']), rep
+    assert rep['n_parameter_tensors'] > 100 and rep['grad_rel_l2_all_parameters'] <= 2.5e-5, rep
+    assert rep['worst_tensor_rel_l2'] <= 2e-4, rep
+    h, r = rep['hip_vs_float64'], rep['reference_vs_float64']
+    assert h['all_parameters'] <= 1.5 * r['all_parameters'] and h['worst_tensor_rel_l2'] <= 1.5 * r['worst_tensor_rel_l2'] + 1e-5, rep
 
 
 def test_run_py_parallel_model_calls_the_drop_in_unchanged(gpu_device):

@@ -1,4 +1,4 @@
-"""CPU test of tools/vgpr_liveness.py (the register-liveness reader used for the occupancy work): a
+"""CPU test of tools/vgpr_liveness.py (the register-liveness reader used for the occupancy work, HISTORY.md section 7): a
 hand-written listing with a loop, a loop-carried value, a value held across a load cluster and a dead definition."""
 import os
 import subprocess

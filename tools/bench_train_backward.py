@@ -56,27 +56,31 @@ def main():
     if os.environ.get('NFI_NO_RAY_ORDER'):
         k = {n: v for n, v in k.items() if n != 'ray_order'}
     print('ray_order hint:', k.get('ray_order'))
-    out = fn(*a, **k)
-    torch.cuda.synchronize()
-    ev = [torch.cuda.Event(enable_timing=True) for _ in range(n + 1)]
-    for i in range(n):
-        ev[i].record()
-        out = fn(*a, **k)
-    ev[n].record()
-    torch.cuda.synchronize()
-    ms = sorted(ev[i].elapsed_time(ev[i + 1]) for i in range(n))
-    # the plane gradient against the per-point atomic scatter (scatter_mode 0: fp32 rows never leave the registers)
     exact = fn(*a, **dict(k, scatter_mode=0))['g_texels'].double()
-    got = out['g_texels'].double()
-    err_max = float((got - exact).abs().max() / exact.abs().max())
-    err_l2 = float((got - exact).norm() / exact.norm())
-    pts = a[0].shape[0] * a[0].shape[1]
-    gs = a[11]
-    print('%s: %.1f M points (%.1f %% with a non-zero sigma gradient): field backward + scatter %.3f ms median (min %.3f)  '
-          '|g_texels| %.9e  sum %.9e  |g_w1| %.9e  vs atomic scatter: max %.2e of max, l2 %.2e' % (
-              os.path.basename(_lib.LIBRARY), pts / 1e6, 100.0 * float((gs != 0).float().mean()), ms[n // 2], ms[0],
-              float(out['g_texels'].double().norm()), float(out['g_texels'].double().sum()), float(out['g_w1'].double().norm()),
-              err_max, err_l2))
+    modes = [int(m) for m in os.environ.get('NFI_SCATTER_MODES', '1').split(',')]
+    for rnd in range(2 if len(modes) > 1 else 1):          # (two alternating rounds when modes are compared)
+        for mode in modes:
+            km = dict(k, scatter_mode=mode)
+            out = fn(*a, **km)
+            torch.cuda.synchronize()
+            ev = [torch.cuda.Event(enable_timing=True) for _ in range(n + 1)]
+            for i in range(n):
+                ev[i].record()
+                out = fn(*a, **km)
+            ev[n].record()
+            torch.cuda.synchronize()
+            ms = sorted(ev[i].elapsed_time(ev[i + 1]) for i in range(n))
+            # the plane gradient against the per-point atomic scatter (scatter_mode 0: fp32 rows never leave the registers)
+            got = out['g_texels'].double()
+            err_max = float((got - exact).abs().max() / exact.abs().max())
+            err_l2 = float((got - exact).norm() / exact.norm())
+            pts = a[0].shape[0] * a[0].shape[1]
+            gs = a[11]
+            print('%s scatter_mode %d: %.1f M points (%.1f %% with a non-zero sigma gradient): field backward + scatter %.3f ms median '
+                  '(min %.3f)  |g_texels| %.9e  sum %.9e  |g_w1| %.9e  vs atomic scatter: max %.2e of max, l2 %.2e' % (
+                      os.path.basename(_lib.LIBRARY), mode, pts / 1e6, 100.0 * float((gs != 0).float().mean()), ms[n // 2], ms[0],
+                      float(out['g_texels'].double().norm()), float(out['g_texels'].double().sum()),
+                      float(out['g_w1'].double().norm()), err_max, err_l2))
 
 
 if __name__ == '__main__':

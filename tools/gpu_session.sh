@@ -25,7 +25,7 @@ for w in $WHAT; do
     refreport)
       timeout 1500 python tools/reference_report.py $REFREPORT_SECTIONS > $O/reference_parity.json 2> $O/reference_parity.err; echo "refreport rc=$?" >> $O/env.txt;;
     bench)
-      timeout 900 python bench.py > $O/bench.json 2> $O/bench.err; echo "bench rc=$?" >> $O/env.txt; tail -c 600 $O/bench.json;;
+      t0=$(date +%s); timeout 900 python bench.py > $O/bench.json 2> $O/bench.err; echo "bench rc=$? seconds=$(( $(date +%s) - t0 ))" >> $O/env.txt; tail -c 600 $O/bench.json;;
     train)
       timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29541 \
         bench.py --gpus 1 --mode train --steps 30 --warmup 5 --force-dist > $O/train.json 2> $O/train.err; echo "train rc=$?" >> $O/env.txt; tail -c 1500 $O/train.json;;
@@ -116,7 +116,13 @@ PY
     regulariser)
       timeout 300 python tools/bench_regulariser.py > $O/bench_regulariser.log 2>&1; tail -2 $O/bench_regulariser.log;;
     train_bwd)
-      timeout 300 python tools/bench_train_backward.py 30 > $O/bench_train_backward.log 2>&1; tail -2 $O/bench_train_backward.log;;
+      timeout 300 python tools/bench_train_backward.py 30 > $O/bench_train_backward.log 2>&1; tail -4 $O/bench_train_backward.log;;
+    scatter_ab)
+      # fp32 rows (scatter_mode 1) against fp16 rows (2): the real inputs of a training step, two alternating rounds; then
+      # the per-kernel durations of both from one rocprofv3 kernel trace
+      NFI_SCATTER_MODES=1,2 timeout 300 python tools/bench_train_backward.py 30 > $O/scatter_ab.log 2>&1; tail -5 $O/scatter_ab.log
+      (cd /tmp && export TMPDIR=/tmp && NFI_SCATTER_MODES=1,2 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/scatter_ab -o t -- python $R/tools/bench_train_backward.py 20 > $O/scatter_ab_prof.log 2>&1)
+      f=$(find /tmp/scatter_ab -name '*kernel_stats.csv' | head -1); [ -n "$f" ] && cp "$f" $O/kernel_stats_scatter_ab.csv && head -12 "$f" | cut -c1-150;;
     mall)
       timeout 300 python tools/probes/mall_probe.py > $O/mall_probe.log 2>&1; cat $O/mall_probe.log;;
     stress)

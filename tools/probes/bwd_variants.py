@@ -1,4 +1,4 @@
-"""Variant builds of the field backward kernel for the packed-fp32 wrong-product hunt (DESIGN.md "Determinism").
+"""Variant builds of the field backward kernel for the packed-fp32 wrong-product hunt (HISTORY.md "Determinism").
 
     python tools/probes/bwd_variants.py build        # here (no GPU): build/variants/libnfi_<name>.so
     python tools/probes/bwd_variants.py run [N]      # on the GPU box: N launches per variant, events in g_points

@@ -1,6 +1,6 @@
 // probe: timing-dependent wrong results around packed fp32 (v_pk_*_f32), DPP and cross-half op_sel on gfx950.
 //
-// Background (DESIGN.md "Determinism"): field_query_bwd_kernel, when its coordinate-gradient arithmetic is compiled by
+// Background (HISTORY.md "Determinism"): field_query_bwd_kernel, when its coordinate-gradient arithmetic is compiled by
 // the SLP vectoriser to v_pk_mul_f32 / v_pk_add_f32 with op_sel, produced a wrong g_points component in lanes 48..63 once
 // in ~1e5 tiles.  This probe runs instruction sequences TWICE per iteration from the same inputs - once exactly as the
 // compiler scheduled them ("tight") and once with s_nop 7 between all instructions ("padded") - and compares the

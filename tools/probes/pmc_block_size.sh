@@ -1,7 +1,7 @@
 # FETCH_SIZE / L2 hit rate / time of render_fwd_kernel for the three pixel-block sizes of the per-XCD work queues
 # (tuning bits 5-6: 0 = default (32 px at 128^2), 96 = 16 px, 32 = 8 px).  bash tools/probes/pmc_block_size.sh  (GPU box)
 # ROUND-3 PROBE: the tuning bits 5-8 were measurement knobs and left the product in round 4 (the default - the largest
-# block that divides the image - had the least traffic: DESIGN.md section 7); to re-run this, put a library built from
+# block that divides the image - had the least traffic: HISTORY.md section 7); to re-run this, put a library built from
 # commit 4d6d769 in place (tools/probes/render_variants.py build base).
 R=$PWD; O=$R/gpurun_out/r3blk; mkdir -p $O; cd /tmp; export TMPDIR=/tmp
 for t in 0 96 32; do

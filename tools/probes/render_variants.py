@@ -1,4 +1,4 @@
-"""Variant builds of the fused render kernels for A/B timing on the GPU box - the NEGATIVE RESULTS of round 3 (DESIGN.md
+"""Variant builds of the fused render kernels for A/B timing on the GPU box - the NEGATIVE RESULTS of round 3 (HISTORY.md
 section 7).  The build-time knobs these variants switch (NFI_PLANEWISE, NFI_TILE_PAIR, NFI_SCALAR_RAY, NFI_LEAN_RAY,
 NFI_SPLIT_MIX, NFI_MERGE_HIST, the tuning bits 5-8 of the work queues) were removed from the product sources in round 4;
 they live in the tree of commit FROZEN below, which `build` extracts with `git show` (needs the repository's history,

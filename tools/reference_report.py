@@ -41,12 +41,19 @@ def main():
     for name in rc.CONFIG_CASES:
         section('configs_vs_fp32_reference', name, lambda: rc.config_case(name, dev, cpu_images=1, scenes=scenes))
     scenes.clear()
-    # gradients: HIP vs the fp32 reference, and both against the reference in float64 (the deterministic comparator)
+    # gradients: HIP vs the fp32 reference, and both against the reference in float64; the producer's convolutions on
+    # MIOpen's deterministic solvers (rc.deterministic_producer: without it d loss / d latents moves by up to 2e-3 from run to
+    # run in both implementations, profiles/r6/gradient_spread.json)
+    def det(fn):
+        def run():
+            with rc.deterministic_producer():
+                return fn()
+        return run
     for geometry in ('chairs', 'p3d', 'cub'):
-        section('gradients', '%s_b2_128px_64+64' % geometry, lambda: rc.gradients(rc.build_scene(geometry, 2, dev), 128, 64))
-    section('gradients', 'carla_viewdir_b2_64px_32+32', lambda: rc.gradients(rc.build_scene('carla', 2, dev), 64, 32))
-    section('training_step_cub_b4_128px_64+64', None, lambda: rc.training_step(rc.build_scene('cub', 4, dev), 128, 64))
-    section('regularisers_cub_b2', None, lambda: rc.regularisers(rc.build_scene('cub', 2, dev)))
+        section('gradients', '%s_b2_128px_64+64' % geometry, det(lambda: rc.gradients(rc.build_scene(geometry, 2, dev), 128, 64)))
+    section('gradients', 'carla_viewdir_b2_64px_32+32', det(lambda: rc.gradients(rc.build_scene('carla', 2, dev), 64, 32)))
+    section('training_step_cub_b4_128px_64+64', None, det(lambda: rc.training_step(rc.build_scene('cub', 4, dev), 128, 64)))
+    section('regularisers_cub_b2', None, det(lambda: rc.regularisers(rc.build_scene('cub', 2, dev))))
     for geometry, batch in (('chairs', 1), ('chairs', 8), ('p3d', 16), ('cub', 4)):
         section('forward', '%s_b%d_128px_64+64' % (geometry, batch), lambda: rc.compare(rc.build_scene(geometry, batch, dev), 128, 64, cpu_images=2))
     if not only or 'forward' in only:
@@ -60,7 +67,10 @@ def main():
         sc = rc.build_scene('chairs', 2, dev)
         section('forward', 'chairs_b2_normals_64px_32+32', lambda: rc.compare(sc, 64, 32, cpu_images=2, grad=True, compute_normals=True))
         del sc
-    section('inversion_p3d_b4_128px_64+64_8_steps', None, lambda: rc.inversion(rc.build_scene('p3d', 4, dev), 128, 64, steps=8))
+    def inv():
+        with rc.deterministic_producer():
+            return rc.inversion(rc.build_scene('p3d', 4, dev), 128, 64, steps=30)
+    section('inversion_p3d_b4_128px_64+64_30_steps', None, inv)
     print(json.dumps(rep, indent=1))
 
 

@@ -4,7 +4,7 @@
 
 Each workload is launched `launches` times with identical inputs; every output is compared bit for bit with the
 majority (element-wise median) of the first five launches.  Nothing here uses atomics on floats, so ANY difference is
-a wrong result of the kind DESIGN.md "Determinism" describes.  Prints one line per workload and a JSON summary.
+a wrong result of the kind HISTORY.md "Determinism" describes.  Prints one line per workload and a JSON summary.
 """
 import json
 import os

@@ -6,7 +6,7 @@ Builds the control-flow graph from labels and branches, runs the usual backward 
 counted), prints the pressure profile (maximum, the line where it is reached, pressure at every buffer_load cluster and
 at every MFMA block) and, for the point of maximum pressure (or --at LINE), the live registers grouped by the line that
 defined them - which, with the source comments hipcc leaves in the listing, says WHAT is being held across the gather.
-A reading aid for the "what keeps the render kernel from a third wave per SIMD" question; not part
+A reading aid for the "what keeps the render kernel from a third wave per SIMD" question (HISTORY.md section 8); not part
 of the build.
 """
 import re
