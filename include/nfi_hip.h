@@ -345,10 +345,7 @@ typedef struct nfi_field_bwd_args {
    * 1: binned - the kernel writes the per-point feature gradient (128 B) to the workspace, the points are counting-
    * sorted by texel cell per plane (by 16x16-texel tile through global memory, by cell inside LDS), and the sorted
    * entries are reduced in registers with one set of line-coalesced atomics per run of a cell; needs
-   * nfi_field_bwd_workspace_bytes(a) of workspace (177 B per point).  Same result up to fp32 summation order.
-   * 2: as 1 with the per-point rows stored as 32 x fp16 (64 B) under a power-of-two scale per row (largest entry in
-   * [2^14, 2^15), exponent in the flag byte / the sorted entry; rows under 2^-62 count as zero): half the bytes of every
-   * row read of the reduction; 2^-11 relative rounding per row element (measured on the plane gradient: DESIGN.md). */
+   * nfi_field_bwd_workspace_bytes(a) of workspace (177 B per point).  Same result up to fp32 summation order. */
   int scatter_mode;
   int texel_layout;              /* of texels AND g_texels */
   /* Order hint (0: none): the points are [rays][samples_per_ray] with the rays in row-major order of an image

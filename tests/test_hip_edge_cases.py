@@ -166,6 +166,27 @@ def test_no_ray_meets_the_cube(gpu_device):
     with pytest.raises(RuntimeError, match='an earlier batch'):
         ops.flush_strict(dev)
     ops.flush_strict(dev)                                                        # the queue was cleared by the raise
+    # 'after': ONE launch (no split), the counter is read back behind the render kernel - raises for THIS batch
+    with pytest.raises(RuntimeError, match='no ray intersects the scene cube'):
+        ops.render_fwd(cam, focal, 8, 8, 16, *args, strict='after')
+    two = ops.render_fwd(good, focal, 8, 8, 16, *args, strict='after')
+    assert all(torch.equal(two[k], one[k]) for k in ('rgb', 'depth', 'mask'))
+    # a device named without an index (torch.device('cuda')) is the current device: the same queue as the tensors' own
+    # 'cuda:N' (flush_strict(torch.device('cuda')) used to look up a key of its own and never raise)
+    ops.render_fwd(cam, focal, 8, 8, 16, *args, strict='deferred')
+    with torch.cuda.device(dev), pytest.raises(RuntimeError, match='an earlier batch'):
+        ops.flush_strict(torch.device('cuda'))
+    # the STAGED path (nerf_utils.compute_near_far_planes -> ops.near_far): 'deferred' defers there too instead of taking
+    # the synchronous branch because the string is truthy
+    ro, rd = ops.raygen(8, 8, focal, cam, normalize=True)
+    ops.near_far(ro, rd, 0.55, strict='deferred')                                # no hit, no exception, no host read
+    with pytest.raises(RuntimeError, match='an earlier batch'):
+        ops.flush_strict(dev)
+    with pytest.raises(RuntimeError, match='no ray intersects the scene cube'):
+        ops.near_far(ro, rd, 0.55, strict=True)
+    ro, rd = ops.raygen(8, 8, focal, good, normalize=True)
+    ops.near_far(ro, rd, 0.55, strict='deferred')
+    ops.flush_strict(dev)
 
 
 def test_a_band_of_background_rows_is_not_an_error(gpu_device):

@@ -52,7 +52,7 @@ def test_loader_falls_back_to_the_staged_copy():
 def test_render_strictness_option_values():
     import types
     import nerf_from_image_amd.render as nfi_render
-    for v, want in ((True, True), (False, False), ('deferred', 'deferred'), (1, True)):
+    for v, want in ((True, True), (False, False), ('deferred', 'deferred'), ('after', 'after'), (1, True)):
         assert nfi_render._strict(types.SimpleNamespace(strict_near_far=v)) == want
     with pytest.raises(TypeError):
         nfi_render.make_render(None, None, no_such_option=1)
