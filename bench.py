@@ -69,7 +69,7 @@ MFMA_F32_PEAK_TFLOPS = 157.3
 MFMA_F16_PEAK_TFLOPS = 2500.0
 MLP_FLOP_PER_RAY = 704512
 N_SIMD = 1024
-PMC_PROFILES = ('profiles/r5/pmc_render_fwd.json', 'profiles/r4/pmc_render_fwd.json', 'profiles/r3/pmc_render_fwd.json', 'profiles/r2/pmc_render_fwd.json', 'profiles/r1/pmc_render_fwd_derived.json')
+PMC_PROFILES = ('profiles/r6/pmc_render_fwd.json', 'profiles/r5/pmc_render_fwd.json', 'profiles/r4/pmc_render_fwd.json', 'profiles/r3/pmc_render_fwd.json', 'profiles/r2/pmc_render_fwd.json', 'profiles/r1/pmc_render_fwd_derived.json')
 
 
 def cameras(n, radius, gen):

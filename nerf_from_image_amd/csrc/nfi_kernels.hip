@@ -2322,7 +2322,6 @@ extern "C" int nfi_render_fwd(const nfi_render_args* a, nfi_stream_t stream) {
   const bool term = a->termination_eps > 0.0f;
   const bool extra = a->semantics || a->coords || a->normals;
   REQUIRE(!a->normals || a->use_sdf, "render: the normals map needs the SDF decoder (use_sdf)");
-  REQUIRE(!a->normals || a->texel_dtype != NFI_TEXEL_BF16, "render: the normals map exists for fp32 and fp16 texels");
   REQUIRE(a->termination_eps >= 0.0f && a->termination_eps < 1.0f, "render: termination_eps must be in [0,1)");
   REQUIRE(!term || a->fine_sampling, "render: termination_eps acts on the fine pass (fine_sampling)");
   REQUIRE(!term || !(any_tap || extra || a->profile_cycles || a->ray_features || strict),
@@ -2364,9 +2363,8 @@ extern "C" int nfi_render_fwd(const nfi_render_args* a, nfi_stream_t stream) {
 #define NFI_LAUNCH_RENDER(TEX, ATT)                                                                                   \
   do {                                                                                                                \
     if (a->normals) {                                                                                                 \
-      constexpr int TN = TEX == 1 ? 0 : TEX;       /* (bf16 is refused above) */                                       \
-      NFI_ENSURE_DYNAMIC_LDS((render_fwd_kernel<TN, ATT, NFI_RENDER_OCC, kRenderNormals, 1>), kSemLdsMax, "render");   \
-      hipLaunchKernelGGL((render_fwd_kernel<TN, ATT, NFI_RENDER_OCC, kRenderNormals, 1>), grid, dim3(256), sem_lds, s, k); \
+      NFI_ENSURE_DYNAMIC_LDS((render_fwd_kernel<TEX, ATT, NFI_RENDER_OCC, kRenderNormals, 1>), kSemLdsMax, "render");  \
+      hipLaunchKernelGGL((render_fwd_kernel<TEX, ATT, NFI_RENDER_OCC, kRenderNormals, 1>), grid, dim3(256), sem_lds, s, k); \
     } else if (extra) {                                                                                               \
       NFI_ENSURE_DYNAMIC_LDS((render_fwd_kernel<TEX, ATT, NFI_RENDER_OCC, kRenderExtra, 1>), kSemLdsMax, "render");    \
       hipLaunchKernelGGL((render_fwd_kernel<TEX, ATT, NFI_RENDER_OCC, kRenderExtra, 1>), grid, dim3(256), sem_lds, s, k); \
@@ -2381,9 +2379,8 @@ extern "C" int nfi_render_fwd(const nfi_render_args* a, nfi_stream_t stream) {
 #define NFI_LAUNCH_RENDER_WIDE(TEX, ATT)                                                                             \
   do {                                                                                                                \
     if (a->normals) {                                                                                                 \
-      constexpr int TN = TEX == 1 ? 0 : TEX;                                                                          \
-      NFI_ENSURE_DYNAMIC_LDS((render_fwd_wide_kernel<TN, ATT, kRenderNormals, 1>), kSemLdsMaxWide, "render");          \
-      hipLaunchKernelGGL((render_fwd_wide_kernel<TN, ATT, kRenderNormals, 1>), grid, dim3(256), sem_lds, s, k);        \
+      NFI_ENSURE_DYNAMIC_LDS((render_fwd_wide_kernel<TEX, ATT, kRenderNormals, 1>), kSemLdsMaxWide, "render");         \
+      hipLaunchKernelGGL((render_fwd_wide_kernel<TEX, ATT, kRenderNormals, 1>), grid, dim3(256), sem_lds, s, k);       \
     } else if (extra) {                                                                                               \
       NFI_ENSURE_DYNAMIC_LDS((render_fwd_wide_kernel<TEX, ATT, kRenderExtra, 1>), kSemLdsMaxWide, "render");           \
       hipLaunchKernelGGL((render_fwd_wide_kernel<TEX, ATT, kRenderExtra, 1>), grid, dim3(256), sem_lds, s, k);         \

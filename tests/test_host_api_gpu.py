@@ -107,6 +107,44 @@ def test_render_dropin_fused(setup, fine, randomize, white):
     close(rgb, o['rgb'], 1e-4, 'rgb'); close(depth, o['depth'], 1e-4, 'depth'); close(mask, o['mask'], 1e-4, 'mask')
 
 
+def test_graphed_render_replays_the_eager_call(setup):
+    """nerf_from_image_amd.graphs.GraphedRender: the whole render() call - plane producer, hand-off, noise, set-up, fused
+    kernel - captured in a HIP graph.  Deterministic sampling (randomize=False): bit-identical to the eager call, also for
+    NEW cameras and latents copied into the captured buffers; random sampling: every replay draws fresh noise."""
+    from nerf_from_image_amd.graphs import GraphedRender
+    model, cam, focal, z = setup
+    cfg = types.SimpleNamespace(use_viewdir=False, use_sdf=True, attention_values=10, fine_sampling=True)
+    dcfg = {'scene_range': 0.55, 'white_background': True}
+    render = nfi_render.make_render(cfg, dcfg, strict_near_far=False)
+    H = W = 24
+    S = 32
+    graphed = GraphedRender(render, model, H, W, cam, focal, None, None, z, S, randomize=False, compute_semantics=True)
+    with torch.no_grad():
+        eager = render(model, H, W, cam, focal, None, None, z, S, randomize=False, compute_semantics=True)
+    out = graphed(cam, focal, None, None, z)
+    for k in (0, 1, 2, 4):
+        assert torch.equal(out[k], eager[k]), k
+    g = torch.Generator().manual_seed(3)
+    cam2 = cam.clone()
+    cam2[:, :3, 3] += 0.05 * torch.randn(2, 3, generator=g).to(cam.device)
+    z2 = torch.randn(z.shape, generator=g).to(z.device)
+    with torch.no_grad():
+        eager2 = render(model, H, W, cam2, focal, None, None, z2, S, randomize=False, compute_semantics=True)
+    out2 = graphed(cam2, focal, None, None, z2)
+    for k in (0, 1, 2, 4):
+        assert torch.equal(out2[k], eager2[k]) and not torch.equal(eager2[k], eager[k]), k
+    with pytest.raises(ValueError):
+        graphed(cam2[:1], focal[:1], None, None, z2[:1])                  # shapes are the graph's
+    # random sampling: consecutive replays are consecutive draws
+    noisy = GraphedRender(render, model, H, W, cam, focal, None, None, z, S)
+    a = noisy(cam, focal, None, None, z)[0].clone()
+    b = noisy(cam, focal, None, None, z)[0].clone()
+    assert not torch.equal(a, b) and float((a - b).abs().mean()) < 0.05
+    # the default (strict) render function reads the hit count back on the host: it cannot be captured, and says so
+    with pytest.raises(ValueError, match='strict_near_far=False'):
+        GraphedRender(nfi_render.make_render(cfg, dcfg), model, H, W, cam, focal, None, None, z, S)
+
+
 class OneRenderLaunch:
     """The extra maps must come out of ONE fused render launch: counts ops.render_fwd calls and makes the stage ops of
     the staged path (field query, resampling, compositing) fail."""

@@ -22,7 +22,7 @@ BUDGET = 1e-4
 
 def _require_reference():
     # The staged copy ships with the snapshot (git-ignored like the .so, not gpurun-ignored): on the GPU box these tests RUN
-    # (0 skipped in profiles/r5/pytest_gpu.log).  A snapshot made without it - a bare clone, where build() found no
+    # (0 skipped in profiles/r6/pytest_gpu_run1.log).  A snapshot made without it - a bare clone, where build() found no
     # /root/reference to stage from - is reported as a skip with the recipe's name rather than as a dozen failures.
     if not reference.available():
         pytest.skip('reference sources not staged: run oracle/make_ref.py (or __graft_entry__.build()) where /root/reference exists')
@@ -159,18 +159,27 @@ def test_view_direction_decoder_matches_the_real_reference(gpu_device):
         _check(rep, ('rgb', 'depth', 'mask', 'extra'))
 
 
-# Gradients with the producer's convolutions on MIOpen's deterministic solvers (rc.deterministic_producer): every figure
-# below repeats to all printed digits from run to run (profiles/r6/gradient_spread.json, three runs; without the flag d loss /
+# Gradients with the producer's convolutions on MIOpen's deterministic solvers (rc.deterministic_producer): inside one
+# process every figure repeats to all printed digits (profiles/r6/gradient_spread.json, three runs; without the flag d loss /
 # d latents moves by 1e-5 ... 2e-3 between runs in BOTH implementations - the producer's atomic split-K weight gradients).
-# Relative L2 of the HIP gradient against the fp32 reference's, as MEASURED; asserted at 3 x.
+# From one process to the next MIOpen may still pick another (deterministic) solver, the planes then differ in the last bits
+# and a few samples flip sides of a texel edge: the camera / focal figures - sums over the image that cancel ~1000 : 1 - move
+# by a factor 2-4.  Relative L2 of the HIP gradient against the fp32 reference's: the MAXIMUM over the round's eight
+# sessions (profiles/r6/); asserted at 3 x.
 GRADIENT_MEASURED = {
     #          d/d latents  d/d planes  d/d camera  d/d focal
-    'chairs': dict(g_ws=7.8e-6, g_planes=4.9e-5, g_cam=4.5e-5, g_focal=8.1e-5),
-    'p3d': dict(g_ws=7.5e-6, g_planes=5.2e-5, g_cam=4.9e-4, g_focal=3.5e-4),
+    'chairs': dict(g_ws=7.8e-6, g_planes=4.9e-5, g_cam=7.7e-5, g_focal=3.5e-4),
+    'p3d': dict(g_ws=7.7e-6, g_planes=5.4e-5, g_cam=5.3e-4, g_focal=4.0e-4),
     # (orthographic: the reference's own fp32 sum of the camera gradient is 6e-4 off float64, ours 4e-5 - below)
-    'cub': dict(g_ws=5.4e-6, g_planes=5.2e-5, g_cam=6.3e-4),
-    'carla': dict(g_ws=3.8e-6, g_planes=2.8e-5, g_cam=2.0e-5, g_focal=1.3e-6),
+    'cub': dict(g_ws=5.4e-6, g_planes=5.5e-5, g_cam=6.3e-4),
+    'carla': dict(g_ws=3.8e-6, g_planes=3.5e-5, g_cam=3.6e-5, g_focal=1.6e-5),
 }
+# HIP's distance from the float64 reference over the fp32 reference's distance from it, at most (renderer only, same planes):
+# planes 1.0 - 2.0 measured (the backward's split-fp16 operands are scaled per tile: an entry is resolved to 2^-22 of its
+# tile's largest), camera 0.07 - 1.0, focal 1.0 - 4.2 (22 significand bits against fp32's 24 in the coordinate gradients of
+# every sample, summed over an image under a crop box with ~1000 : 1 cancellation; absolute: 2.8e-4 ... 6.6e-4 of the
+# gradient's norm, the fp32 reference 7e-5 ... 3e-4)
+FLOAT64_RATIO = dict(g_planes=2.5, g_cam=2.5, g_focal=6.0)
 
 
 @pytest.mark.parametrize('geometry', ['chairs', 'p3d', 'cub', 'carla'])
@@ -181,10 +190,8 @@ def test_gradients_match_the_real_reference(gpu_device, geometry):
 
     Two comparators.  (1) The fp32 reference, at 3 x the measured figure.  (2) The reference in FLOAT64 on the same device
     (rc.as_double) as ground truth for the RENDERER: the float64 run renders the very planes the fp32 runs rendered, so the
-    producer's own rounding is common to all three; the HIP gradient may be at most 2.5 x as far from it as the fp32
-    reference is (measured: planes 1.0 - 2.0 x, camera 0.07 - 1.0 x, focal 1.0 - 2.2 x; the planes' figure is the
-    backward's per-tile power-of-two operand scaling, 2^-22 of a tile's largest entry, against the reference's fp32
-    atomics)."""
+    producer's own rounding is common to all three; the HIP gradient may be at most FLOAT64_RATIO times as far from it as
+    the fp32 reference is."""
     _require_reference()
     with rc.deterministic_producer():
         sc = rc.build_scene(geometry, 2, gpu_device)
@@ -195,7 +202,7 @@ def test_gradients_match_the_real_reference(gpu_device, geometry):
         assert rep[k] <= 3.0 * measured + 1e-6, (k, rep[k], 'measured', measured, rep)
     ours, theirs = rep['renderer_only_hip_vs_float64'], rep['renderer_only_reference_vs_float64']
     for k in ours:
-        assert ours[k] <= 2.5 * theirs[k] + 1e-5, (k, 'vs float64: HIP', ours[k], 'fp32 reference', theirs[k], rep)
+        assert ours[k] <= FLOAT64_RATIO[k] * theirs[k] + 1e-5, (k, 'vs float64: HIP', ours[k], 'fp32 reference', theirs[k], rep)
     # the whole graph in float64 (producer included): both fp32 implementations carry the producer's rounding
     for k in ('g_ws', 'g_planes'):
         assert rep['hip_vs_float64'][k] <= 2.5 * rep['reference_vs_float64'][k] + 1e-5, (k, rep)
@@ -206,19 +213,20 @@ def test_inversion_steps_match_the_real_reference(gpu_device):
     30 steps of Adam on latents + camera + focal, run.py:2232-2299, --inv_steps 30) with a synthetic target (no p3d_car
     data / checkpoint exists offline): at every point of the REFERENCE's trajectory the HIP path gives the same loss and
     gradients, and its own trajectory reaches the same PSNR / IoU.  Producer on deterministic MIOpen solvers: the figures
-    repeat (measured, profiles/r6/reference_parity.json: loss <= 2.1e-5, d/d latents <= 1.2e-4, camera <= 3.1e-5, focal <=
-    1.0e-4 - the spikes are single samples that the two fp32 forwards place on different sides of a texel edge)."""
+    repeat (measured over the 30 steps, profiles/r6/reference_parity.json: loss <= 2.1e-5, d/d latents <= 2.3e-4, camera <=
+    1.1e-4, focal <= 5.5e-4 - the spikes are single samples that the two fp32 forwards place on different sides of a texel
+    edge; PSNR 33.98 -> 45.77 dB: reference 45.77057 dB / IoU 0.97519, HIP 45.77055 / 0.97519)."""
     _require_reference()
     with rc.deterministic_producer():
         sc = rc.build_scene('p3d', 4, gpu_device)
         r = rc.inversion(sc, 128, 64, steps=30)
     for a in r['along_reference_trajectory']:
-        assert a['loss_rel'] <= 6.5e-5 and a['g_ws'] <= 3.6e-4 and a['g_cam'] <= 1e-4 and a.get('g_focal', 0.0) <= 3e-4, a
+        assert a['loss_rel'] <= 6.5e-5 and a['g_ws'] <= 7e-4 and a['g_cam'] <= 3.3e-4 and a.get('g_focal', 0.0) <= 1.7e-3, a
     (l0, p0, i0), (l1, p1, i1) = r['reference'][0], r['reference'][-1]
     (h0, q0, j0), (h1, q1, j1) = r['hip'][0], r['hip'][-1]
-    assert l1 < l0 and h1 < h0 and p1 > p0 + 1.0, (r['reference'], r['hip'])                 # both descend
-    # free-running trajectories (each its own Adam): measured 1e-5 dB apart after 8 steps
-    assert abs(q1 - p1) <= 0.05 and abs(j1 - i1) <= 0.002, (r['reference'][-1], r['hip'][-1])
+    assert l1 < l0 and h1 < h0 and p1 > p0 + 5.0, (r['reference'], r['hip'])                 # both descend (+ 11.8 dB)
+    # free-running trajectories (each its own Adam; chaotic): measured 1.5e-5 ... 2.8e-3 dB apart after the 30 steps, IoU identical
+    assert abs(q1 - p1) <= 1e-2 and abs(j1 - i1) <= 1e-4, (r['reference'][-1], r['hip'][-1])
 
 
 def test_regulariser_branch_on_the_real_generator(gpu_device):
@@ -226,14 +234,15 @@ def test_regulariser_branch_on_the_real_generator(gpu_device):
     `attach(model, hip_regularisers=True)` serves eikonal / distance / total-variation / entropy from the HIP kernels
     (`nfi_sdf_gradient_fwd/bwd`: the eikonal term's backward is the reference's DOUBLE backward through lib/ops.grid_sample2d)
     - same seed, same two draws - against the reference's own forward: losses and gradients w.r.t. the latents (through the
-    StyleGAN2 synthesis network), the decoder and beta.  Producer on deterministic MIOpen solvers; bounds = 3 x measured
-    (losses 5.2e-7; latents 1.9e-6 - 1.0e-3 without the flag -, W1 3.0e-6, b1 9.0e-7, W2 8.9e-7, beta 1.7e-6)."""
+    StyleGAN2 synthesis network), the decoder and beta.  Producer on deterministic MIOpen solvers; bounds = 3 x the maximum
+    measured over the round's sessions (losses 5.2e-7; latents 1.9e-6 ... 6.7e-6 - 1.0e-3 without the flag -, W1 3.7e-6,
+    b1 9.8e-7, W2 8.9e-7, beta 1.7e-6)."""
     _require_reference()
     with rc.deterministic_producer():
         sc = rc.build_scene('cub', 2, gpu_device)
         rep = rc.regularisers(sc)
     assert max(rep['loss_rel'].values()) <= 2e-6, rep
-    for k, bound in (('ws', 6e-6), ('w1', 9e-6), ('b1', 3e-6), ('w2', 3e-6), ('beta', 5e-6)):
+    for k, bound in (('ws', 2e-5), ('w1', 1.1e-5), ('b1', 3e-6), ('w2', 3e-6), ('beta', 5e-6)):
         assert rep['grad_rel_l2'][k] <= bound, (k, rep)
     # against the reference in float64: the latents' gradient of BOTH fp32 implementations is 1.08e-3 from it (the producer)
     assert rep['hip_vs_float64']['ws'] <= 1.5 * rep['reference_vs_float64']['ws'] + 1e-6, rep

@@ -115,12 +115,25 @@ def _scene(geometry, batch, dev, impl, texels, fused_handoff=False, hip_regulari
     return sc, model, ren
 
 
-def leg_render(dev, impl, batch=8, texels='fp32', iters=20, warmup=3, markers=False, res=128, samples=64, channels_last=False):
+def leg_render(dev, impl, batch=8, texels='fp32', iters=20, warmup=3, markers=False, res=128, samples=64, channels_last=False,
+               graph=False):
     sc, model, ren = _scene('chairs', batch, dev, impl, texels, channels_last=channels_last)
     mk = Markers(dev, markers)
     mk.instrument(model)
+    graphed = None
+    if graph:
+        # the whole call as ONE HIP graph (nerf_from_image_amd/graphs.py; drop-in only: the reference's render reads the hit
+        # mask back on the host, lib/nerf_utils.py:258, which cannot be captured)
+        assert impl == 'hip' and not markers
+        import nerf_from_image_amd.render as nfi_render
+        from nerf_from_image_amd.graphs import GraphedRender
+        graphed = GraphedRender(nfi_render.make_render(sc.args, sc.dcfg, strict_near_far=False), model, res, res, sc.cam, sc.focal,
+                                None, None, sc.ws, samples)
 
     def step():
+        if graphed is not None:
+            graphed(sc.cam, sc.focal, None, None, sc.ws)
+            return
         mk.emit('step_begin')
         with torch.no_grad():
             ren(model, res, res, sc.cam, sc.focal, None, None, sc.ws, samples)
@@ -214,6 +227,13 @@ def summary(dev, quick=False):
             row['hip_%s_texels_rays_per_s' % tx] = h['rays_per_s']
             row['hip_%s_texels_ms' % tx] = h['ms_median']
             row['x_reference_%s_texels' % tx] = h['rays_per_s'] / ref['rays_per_s']
+        try:
+            h = leg_render(dev, 'hip', batch=b, graph=True, **it)
+            row['hip_fp32_texels_hip_graph_rays_per_s'] = h['rays_per_s']
+            row['hip_fp32_texels_hip_graph_ms'] = h['ms_median']
+            row['x_reference_hip_graph'] = h['rays_per_s'] / ref['rays_per_s']
+        except Exception as e:       # noqa: BLE001 (a producer that cannot be captured is reported, not fatal)
+            row['hip_graph_error'] = repr(e)[:300]
         out['render_incl_synthesis']['b%d' % b] = row
         torch.cuda.empty_cache()
     ref = leg_inversion(dev, 'reference', **it)
@@ -248,6 +268,7 @@ def main():
     ap.add_argument('--sidecar', help='JSON written for tools/phase_split.py (marker table, steps, warm-up)')
     ap.add_argument('--quick', action='store_true')
     ap.add_argument('--channels-last', action='store_true', help='render leg: the synthesis network in NHWC memory format (experiment)')
+    ap.add_argument('--graph', action='store_true', help='render leg, hip: the whole call captured in a HIP graph (GraphedRender)')
     a = ap.parse_args()
     dev = torch.device('cuda:0')
     if a.leg is None:
@@ -257,7 +278,7 @@ def main():
     if a.batch:
         kw['batch'] = a.batch
     if a.leg == 'render':
-        kw.update(channels_last=a.channels_last)
+        kw.update(channels_last=a.channels_last, graph=a.graph)
     if a.leg == 'gstep':
         kw.update(fused_handoff=a.fused_handoff, path_length=a.path_length, hip_regularisers=not a.reference_regularisers)
     r = LEGS[a.leg](dev, a.impl, **kw)
