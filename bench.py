@@ -56,6 +56,11 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# (only the extras' end-to-end legs and --mode train run convolutions: MIOpen starts from an empty user database - a fresh
+#  box's state - whatever ran on this box before; the timed render step contains no MIOpen kernel)
+if 'MIOPEN_USER_DB_PATH' not in os.environ:
+    import tempfile
+    os.environ['MIOPEN_USER_DB_PATH'] = tempfile.mkdtemp(prefix='nfi_miopen_db_')
 
 import torch  # noqa: E402
 

@@ -10,7 +10,8 @@ ray set-up, the fused render kernel - as one submission:
     graphed = GraphedRender(render, model, 128, 128, cam, focal, None, bbox, ws, 64)     # warm-up + capture
     rgb, depth, mask, normals, extra, _ = graphed(cam2, focal2, None, bbox2, ws2)       # copy-in + replay
 
-Inference only (no gradient).  The outputs are the graph's own tensors: they are overwritten by the next call, clone what
+Inference only (no gradient).  The model's parameters are read where they live: in-place updates (an optimiser step, the EMA
+of run.py:365-377) are seen by the next replay, re-assigned parameter tensors are not.  The outputs are the graph's own tensors: they are overwritten by the next call, clone what
 has to outlive it.  Every replay draws fresh noise (PyTorch registers its Philox state with the graph), exactly like
 consecutive eager calls.  ``strict_near_far`` has to be False: the reference's failure for a batch without a hit is a host
 read-back (lib/nerf_utils.py:258), and a captured stream cannot be waited on; such a batch renders as background.

@@ -1,6 +1,12 @@
 import json
 import os
 import sys
+import tempfile
+
+# A private MIOpen user database for the test process (and the processes it starts): the gradient tests run the plane
+# producer on MIOpen's deterministic solvers, and what MIOpen records while they run must not follow a LATER process - the
+# end-to-end legs of bench.py - around through ~/.config/miopen.  (Set before the first convolution initialises MIOpen.)
+os.environ.setdefault('MIOPEN_USER_DB_PATH', tempfile.mkdtemp(prefix='nfi_miopen_db_'))
 
 import numpy as np
 import pytest

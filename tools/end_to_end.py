@@ -26,6 +26,10 @@ import argparse
 import json
 import os
 import sys
+import tempfile
+
+# the producer's timings are MIOpen's: start from an empty user database (a fresh box's state) whatever ran on this box before
+os.environ.setdefault('MIOPEN_USER_DB_PATH', tempfile.mkdtemp(prefix='nfi_miopen_db_'))
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
