@@ -375,22 +375,37 @@ struct FieldParams {
   float neg_log2e_over_beta;      // -log2(e)/beta: exp(-|d|/beta) = exp2(|d| * this)
   const float* lds;              // LDS: decoder operand image (shared by the block)
   const float* vf;               // LDS: this scene's attention values in accumulator layout [16 rows][4]
-  // normal maps (field_wave<..., NRM>): W1' transposed as the A operand of the contraction over the hidden units,
-  // [2 channel tiles][4 n-tiles][64 lanes][4 regs], and row 0 of W2' in accumulator layout [4 groups][4 n-tiles][4 regs]
+  // normal maps (field_wave<..., NRM>): W1' transposed as the fp16 hi / lo A operands of the contraction over the hidden
+  // units (v_mfma_f32_16x16x32_f16), [2 channel tiles][2 k-steps][hi | lo][64 lanes] x 8 halves, and row 0 of W2' in
+  // accumulator layout [4 groups][4 n-tiles][4 regs]
   const float* w1t;
   const float* w2r0;
 };
-constexpr int kW1TFloats = 2 * 4 * 64 * 4, kNrmLdsFloats = kW1TFloats + 64;
+constexpr int kW1TFloats = 2 * 2 * 2 * 64 * 4, kNrmLdsFloats = kW1TFloats + 64;
+
+__device__ __forceinline__ void split_f16x8(const float (&x)[8], f16x8& hi, f16x8& lo);
 
 // The two tables above from the fp32 section of the decoder operand image (global), by the threads of a block:
 //   W1F[s][(g', m')][nt] = W1'[unit 16 nt + m'][channel c(s, g')], c(s, g') = s < 4 ? 4 g' + s : 16 + 4 g' + (s - 4)
-//   -> w1t[(ct, nt)][(g, m)][r] = W1'[unit 16 nt + 4 g + r][channel 16 ct + m] = W1F[4 ct + (m & 3)][(m >> 2, 4 g + r)][nt]
+//   A operand of G^T[16 channels x 16 points] += W1'^T[channels x 32 units] GH[32 units x points], lane (i = lane & 15,
+//   kg = lane >> 4), element e: W1'[unit 32 kk + 16 (e >> 2) + 4 kg + (e & 3)][channel 16 ct + i] - the k-slot order in which
+//   the accumulator layout of layer 1 (rows 4 g + r of n-tiles 2 kk, 2 kk + 1) is the B operand (as in layer 2)
 //   W2F[nt][(g, m)][r] = W2'[row m][unit 16 nt + 4 g + r]  ->  w2r0[g][nt][r] = W2F[nt][(g, 0)][r]
 __device__ __forceinline__ void stage_normal_operands(float* dst, const float* image) {
-  for (int i = threadIdx.x; i < kW1TFloats; i += blockDim.x) {
-    const int r = i & 3, ln = (i >> 2) & 63, nt = (i >> 8) & 3, ct = i >> 10;
-    const int g = ln >> 4, m = ln & 15;
-    dst[i] = image[kW1F + (((4 * ct + (m & 3)) * 64 + (16 * (m >> 2) + 4 * g + r)) << 2) + nt];
+  for (int idx = threadIdx.x; idx < 256; idx += blockDim.x) {
+    const int l = idx & 63, kk = (idx >> 6) & 1, ct = idx >> 7;
+    const int kg = l >> 4, c = 16 * ct + (l & 15);
+    const int gq = (c & 15) >> 2, sq = (c < 16 ? 0 : 4) + (c & 3);
+    float x[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int u = 32 * kk + 16 * (e >> 2) + 4 * kg + (e & 3);
+      x[e] = image[kW1F + (((sq * 64 + (16 * gq + (u & 15))) << 2) + (u >> 4))];
+    }
+    f16x8 hi, lo;
+    split_f16x8(x, hi, lo);
+    reinterpret_cast<u32x4*>(dst)[((ct * 2 + kk) * 2 + 0) * 64 + l] = __builtin_bit_cast(u32x4, hi);
+    reinterpret_cast<u32x4*>(dst)[((ct * 2 + kk) * 2 + 1) * 64 + l] = __builtin_bit_cast(u32x4, lo);
   }
   for (int i = threadIdx.x; i < 64; i += blockDim.x) {
     const int r = i & 3, nt = (i >> 2) & 3, g = i >> 4;
@@ -1205,20 +1220,39 @@ __device__ __forceinline__ SampleOut field_wave(const FieldParams& P, float scen
       for (int n = 0; n < 2; ++n) {
         if (n == 1 && !pair) break;
         const int t = n ? tb : ta;
-        // G^T[32 channels x 16 points] = W1'^T[32 x 64] * GH[64 x 16]: rows 16 ct + 4 g + r, the channel ownership of `feat`
+        // G^T[32 channels x 16 points] = W1'^T[32 x 64] * GH[64 x 16]: rows 16 ct + 4 g + r, the channel ownership of `feat`.
+        // Split fp16 like the decoder itself (round 6; 12 K = 32 MFMAs instead of 32 exact-fp32 ones, which run at the
+        // fp32 VECTOR rate on gfx950): GH scaled per point by a power of two - a gradient has no natural scale and the
+        // hi + lo split resolves 2^-24 absolute -, the accumulator scaled back exactly.
+        static_assert(PREC == 1, "the normal map's contraction is built for the split-fp16 decoder");
         f32x4 G[2] = {f32x4{0.0f, 0.0f, 0.0f, 0.0f}, f32x4{0.0f, 0.0f, 0.0f, 0.0f}};
-        const f32x4* w1t = reinterpret_cast<const f32x4*>(P.w1t);
+        {
+          const u32x4* w1t = reinterpret_cast<const u32x4*>(P.w1t);
+          float am = 0.0f;
 #pragma unroll
-        for (int nt = 0; nt < 4; ++nt)
+          for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
-          for (int ct = 0; ct < 2; ++ct) {
-            const f32x4 w = w1t[(ct * 4 + nt) * 64 + lane];
-            const f32x4 b = n ? gh[1][nt] : gh[0][nt];
-            G[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(w.x, b.x, G[ct], 0, 0, 0);
-            G[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(w.y, b.y, G[ct], 0, 0, 0);
-            G[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(w.z, b.z, G[ct], 0, 0, 0);
-            G[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(w.w, b.w, G[ct], 0, 0, 0);
+            for (int r = 0; r < 4; ++r) am = fmaxf(am, fabsf(n ? gh[1][nt][r] : gh[0][nt][r]));
+          am = max_xor32(max_xor16(am));                       // over the four hidden groups of point j
+          float ssc, s_inv;
+          pow2_normaliser(am, ssc, s_inv);
+#pragma unroll
+          for (int kk = 0; kk < 2; ++kk) {
+            const f32x4 ga = n ? gh[1][2 * kk] : gh[0][2 * kk], gb = n ? gh[1][2 * kk + 1] : gh[0][2 * kk + 1];
+            const float xs[8] = {ga.x * ssc, ga.y * ssc, ga.z * ssc, ga.w * ssc, gb.x * ssc, gb.y * ssc, gb.z * ssc, gb.w * ssc};
+            f16x8 sh, sl;
+            split_f16x8(xs, sh, sl);
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct) {
+              const f16x8 ah = __builtin_bit_cast(f16x8, w1t[((ct * 2 + kk) * 2 + 0) * 64 + lane]);
+              const f16x8 al = __builtin_bit_cast(f16x8, w1t[((ct * 2 + kk) * 2 + 1) * 64 + lane]);
+              G[ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, sh, G[ct], 0, 0, 0);
+              G[ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, sl, G[ct], 0, 0, 0);
+              G[ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, sh, G[ct], 0, 0, 0);
+            }
           }
+          G[0] = G[0] * s_inv; G[1] = G[1] * s_inv;
+        }
         // M -> L layout through the stage tile (the mirror image of gather_tile's transpose)
         f32x4* wr = reinterpret_cast<f32x4*>(stage + j * 36 + g * 4);
         wr[0] = G[0]; wr[4] = G[1];
@@ -1237,6 +1271,8 @@ __device__ __forceinline__ SampleOut field_wave(const FieldParams& P, float scen
         const int flL = __shfl(flags, srcL, 64);
         float gcoord[3] = {0.0f, 0.0f, 0.0f};
         const uint32_t x0 = cxi & 1023u, y0 = (cxi >> 10) & 1023u, z0 = (cxi >> 20) & 1023u;
+        // (round 6, measured: issuing a plane's loads one plane ahead - plane 0 in front of the contraction - costs more in
+        //  spilled registers than the hidden latency returns: 0.54 -> 0.49 x the plain rate)
 #pragma unroll
         for (int pl = 0; pl < 3; ++pl) {
           const uint32_t a0 = (pl == 2) ? y0 : x0, b0 = (pl == 0) ? y0 : z0;
