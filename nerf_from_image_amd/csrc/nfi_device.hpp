@@ -862,12 +862,12 @@ __device__ __forceinline__ uint32_t ratio_f16x2(int es, float inv_pt) {
 //         fp32's 2^-24, an order of magnitude below the 1e-4 parity budget, at 1/5 of the matrix-pipe time.
 //         On gfx950 the f32-input MFMA runs at the f32 VECTOR rate and does not overlap with VALU work of
 //         other waves (tools/probes/mfma_valu_overlap.hip), so this time comes straight off the kernel.
-// NRM: gh[n][nt] receives d(distance) / d(h2) of the lane's hidden units = sigmoid(h) * W2'[0][unit] (accumulator layout),
-// the operand of the normal map's contraction with W1' (field_wave).
+// NRM: Gout[n][ct] receives G = W1'^T (sigmoid(h) * W2'[0]) of tile n - d(distance) / d(feature) up to the positive factors
+// the normalisation drops -, rows 16 ct + 4 g + r of point j: the operand of the normal map (field_wave).
 template <bool ATT, int N, int PREC, int SEMP = 0, bool NRM = false>
 __device__ __forceinline__ void tile_mlp(const FieldParams& P, int lane, const float (&feat)[N][8],
                                          const float (&outside)[N], float* const (&sem)[N], TileOut (&res)[N],
-                                         f32x4 (&gh)[N][4]) {
+                                         f32x4 (&Gout)[N][2]) {
   const int g = lane >> 4;
   const f32x4* ldsv = reinterpret_cast<const f32x4*>(P.lds);
   f32x4 o[N];
@@ -890,7 +890,8 @@ __device__ __forceinline__ void tile_mlp(const FieldParams& P, int lane, const f
       for (int n = 0; n < N; ++n) acc1[n][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl, fh[n], acc1[n][nt], 0, 0, 0);
     }
 #pragma unroll
-    for (int n = 0; n < N; ++n)
+    for (int n = 0; n < N; ++n) {
+      f32x4 gh[4];      // NRM: d(distance) / d(h2) of the lane's hidden units = sigmoid(h) * W2'[0][unit] (accumulator layout)
 #pragma unroll
       for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
@@ -903,9 +904,45 @@ __device__ __forceinline__ void tile_mlp(const FieldParams& P, int lane, const f
           acc1[n][nt][r] = __builtin_amdgcn_fmed3f(sp, h, 128.0f);
           if constexpr (NRM) {
             const float sg = (h > kSoftplusThr2) ? 1.0f : e * __builtin_amdgcn_rcpf(1.0f + e);     // d softplus2 / d h2
-            gh[n][nt][r] = sg * reinterpret_cast<const f32x4*>(P.w2r0)[g * 4 + nt][r];
+            gh[nt][r] = sg * reinterpret_cast<const f32x4*>(P.w2r0)[g * 4 + nt][r];
           }
         }
+      if constexpr (NRM) {
+        // G^T[32 channels x 16 points] = W1'^T[32 x 64] * GH[64 x 16] (rows 16 ct + 4 g + r: the channel ownership of
+        // `feat`), the operand of the normal map (field_wave).  Split fp16 like the layers themselves (round 6: 12 K = 32
+        // MFMAs instead of 32 exact-fp32 ones, which run at the fp32 VECTOR rate on gfx950), right behind this tile's
+        // softplus so that GH never outlives it: a gradient has no natural scale and the hi + lo split resolves 2^-24
+        // absolute, so GH is scaled per point by a power of two and the accumulator scaled back exactly.
+        const u32x4* w1t = reinterpret_cast<const u32x4*>(P.w1t);
+        float am = 0.0f;
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) am = fmaxf(am, fabsf(gh[nt][r]));
+        am = max_xor32(max_xor16(am));                       // over the four hidden groups of point j
+        float ssc, s_inv;
+        pow2_normaliser(am, ssc, s_inv);
+        f32x4 G0 = {0.0f, 0.0f, 0.0f, 0.0f}, G1 = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+          const f32x4 ga = gh[2 * kk], gb = gh[2 * kk + 1];
+          const float xs[8] = {ga.x * ssc, ga.y * ssc, ga.z * ssc, ga.w * ssc, gb.x * ssc, gb.y * ssc, gb.z * ssc, gb.w * ssc};
+          f16x8 sh, sl;
+          split_f16x8(xs, sh, sl);
+          const f16x8 ah = __builtin_bit_cast(f16x8, w1t[((0 * 2 + kk) * 2 + 0) * 64 + lane]);
+          const f16x8 al = __builtin_bit_cast(f16x8, w1t[((0 * 2 + kk) * 2 + 1) * 64 + lane]);
+          const f16x8 bh = __builtin_bit_cast(f16x8, w1t[((1 * 2 + kk) * 2 + 0) * 64 + lane]);
+          const f16x8 bl = __builtin_bit_cast(f16x8, w1t[((1 * 2 + kk) * 2 + 1) * 64 + lane]);
+          G0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, sh, G0, 0, 0, 0);
+          G1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh, sh, G1, 0, 0, 0);
+          G0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, sl, G0, 0, 0, 0);
+          G1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh, sl, G1, 0, 0, 0);
+          G0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, sh, G0, 0, 0, 0);
+          G1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(bl, sh, G1, 0, 0, 0);
+        }
+        Gout[n][0] = G0 * s_inv; Gout[n][1] = G1 * s_inv;
+      }
+    }
     const f32x4 b2 = ldsv[(kB2F >> 2) + g];
 #pragma unroll
     for (int n = 0; n < N; ++n) o[n] = b2;
@@ -958,11 +995,8 @@ __device__ __forceinline__ void tile_mlp(const FieldParams& P, int lane, const f
           float e = __builtin_amdgcn_exp2f(h);
           float sp = __builtin_amdgcn_logf(1.0f + e);
           acc1[n][nt][r] = (h > kSoftplusThr2) ? h : sp;
-          if constexpr (NRM) {
-            const float sg = (h > kSoftplusThr2) ? 1.0f : e * __builtin_amdgcn_rcpf(1.0f + e);
-            gh[n][nt][r] = sg * reinterpret_cast<const f32x4*>(P.w2r0)[g * 4 + nt][r];
-          }
         }
+    static_assert(!NRM, "the normal map's contraction is built for the split-fp16 decoder (PREC 1)");
     // ---- layer 2: O^T[16 x 16] = W2'[16 x 64] * SP^T[64 x 16]; two accumulators per tile ----
     f32x4 o0[N], o1[N];
     const f32x4 b2 = ldsv[(kB2F >> 2) + g];
@@ -988,7 +1022,7 @@ __device__ __forceinline__ void tile_mlp(const FieldParams& P, int lane, const f
 template <bool ATT, int N, int PREC, int SEMP = 0>
 __device__ __forceinline__ void tile_mlp(const FieldParams& P, int lane, const float (&feat)[N][8],
                                          const float (&outside)[N], float* const (&sem)[N], TileOut (&res)[N]) {
-  f32x4 unused[N][4];
+  f32x4 unused[N][2];
   tile_mlp<ATT, N, PREC, SEMP, false>(P, lane, feat, outside, sem, res, unused);
 }
 
@@ -1213,46 +1247,14 @@ __device__ __forceinline__ SampleOut field_wave(const FieldParams& P, float scen
       }
       tile_mlp_vd<ATT, 2, SEMP>(P, lane, feat, xr, outs, sems, to);
     } else if constexpr (NRM) {
-      f32x4 gh[2][4];
-      tile_mlp<ATT, 2, PREC, SEMP, true>(P, lane, feat, outs, sems, to, gh);
+      f32x4 Gp[2][2];
+      tile_mlp<ATT, 2, PREC, SEMP, true>(P, lane, feat, outs, sems, to, Gp);
       // ---- normals of the pair's points, one tile at a time ----
 #pragma unroll 1
       for (int n = 0; n < 2; ++n) {
         if (n == 1 && !pair) break;
         const int t = n ? tb : ta;
-        // G^T[32 channels x 16 points] = W1'^T[32 x 64] * GH[64 x 16]: rows 16 ct + 4 g + r, the channel ownership of `feat`.
-        // Split fp16 like the decoder itself (round 6; 12 K = 32 MFMAs instead of 32 exact-fp32 ones, which run at the
-        // fp32 VECTOR rate on gfx950): GH scaled per point by a power of two - a gradient has no natural scale and the
-        // hi + lo split resolves 2^-24 absolute -, the accumulator scaled back exactly.
-        static_assert(PREC == 1, "the normal map's contraction is built for the split-fp16 decoder");
-        f32x4 G[2] = {f32x4{0.0f, 0.0f, 0.0f, 0.0f}, f32x4{0.0f, 0.0f, 0.0f, 0.0f}};
-        {
-          const u32x4* w1t = reinterpret_cast<const u32x4*>(P.w1t);
-          float am = 0.0f;
-#pragma unroll
-          for (int nt = 0; nt < 4; ++nt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) am = fmaxf(am, fabsf(n ? gh[1][nt][r] : gh[0][nt][r]));
-          am = max_xor32(max_xor16(am));                       // over the four hidden groups of point j
-          float ssc, s_inv;
-          pow2_normaliser(am, ssc, s_inv);
-#pragma unroll
-          for (int kk = 0; kk < 2; ++kk) {
-            const f32x4 ga = n ? gh[1][2 * kk] : gh[0][2 * kk], gb = n ? gh[1][2 * kk + 1] : gh[0][2 * kk + 1];
-            const float xs[8] = {ga.x * ssc, ga.y * ssc, ga.z * ssc, ga.w * ssc, gb.x * ssc, gb.y * ssc, gb.z * ssc, gb.w * ssc};
-            f16x8 sh, sl;
-            split_f16x8(xs, sh, sl);
-#pragma unroll
-            for (int ct = 0; ct < 2; ++ct) {
-              const f16x8 ah = __builtin_bit_cast(f16x8, w1t[((ct * 2 + kk) * 2 + 0) * 64 + lane]);
-              const f16x8 al = __builtin_bit_cast(f16x8, w1t[((ct * 2 + kk) * 2 + 1) * 64 + lane]);
-              G[ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, sh, G[ct], 0, 0, 0);
-              G[ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, sl, G[ct], 0, 0, 0);
-              G[ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, sh, G[ct], 0, 0, 0);
-            }
-          }
-          G[0] = G[0] * s_inv; G[1] = G[1] * s_inv;
-        }
+        const f32x4 G[2] = {n ? Gp[1][0] : Gp[0][0], n ? Gp[1][1] : Gp[0][1]};
         // M -> L layout through the stage tile (the mirror image of gather_tile's transpose)
         f32x4* wr = reinterpret_cast<f32x4*>(stage + j * 36 + g * 4);
         wr[0] = G[0]; wr[4] = G[1];
@@ -1284,21 +1286,26 @@ __device__ __forceinline__ SampleOut field_wave(const FieldParams& P, float scen
           load_texel8<TEX>(P, voff, P.row_pix_bytes, 0, tv[3]);
           const float fa = (pl == 2) ? cfy : cfx, fb = (pl == 0) ? cfy : cfz;
           const float ga = 1.0f - fa, gb = 1.0f - fb;
-          float dcorner[4];
+          float dcorner[4];                                     // this lane's 8 channels of the four corner products
 #pragma unroll
           for (int c = 0; c < 4; ++c) {
             float acc = 0.0f;
 #pragma unroll
             for (int s8 = 0; s8 < 8; ++s8) acc = fmaf(gfL[s8], tv[c][s8], acc);
-            acc += dpp_f32<kDppQuadXor1>(0.0f, acc);          // sum over the 4 lanes (channel chunks) of the point
-            acc += dpp_f32<kDppQuadXor2>(0.0f, acc);
             dcorner[c] = acc;
           }
+          // (the bilinear derivative is linear in the corner products and fa, fb are the point's - the same in its four
+          //  lanes -, so the sum over the lanes is taken ONCE per axis behind the planes: 6 cross-lane adds per tile, not 24)
           const float g_fa = gb * (dcorner[1] - dcorner[0]) + fb * (dcorner[3] - dcorner[2]);
           const float g_fb = ga * (dcorner[2] - dcorner[0]) + fa * (dcorner[3] - dcorner[1]);
           gcoord[(pl == 2) ? 1 : 0] += g_fa;                    // plane 0: (x,y)  plane 1: (x,z)  plane 2: (y,z)
           gcoord[(pl == 0) ? 1 : 2] += g_fb;
           __builtin_amdgcn_sched_barrier(0);                    // one plane's 32 texel registers at a time
+        }
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {                           // sum over the 4 lanes (channel chunks) of the point
+          gcoord[a] += dpp_f32<kDppQuadXor1>(0.0f, gcoord[a]);
+          gcoord[a] += dpp_f32<kDppQuadXor2>(0.0f, gcoord[a]);
         }
         float gx = ((flL >> 2) & 1) ? gcoord[0] : 0.0f, gy = ((flL >> 3) & 1) ? gcoord[1] : 0.0f,
               gz = ((flL >> 4) & 1) ? gcoord[2] : 0.0f;
@@ -1306,8 +1313,9 @@ __device__ __forceinline__ SampleOut field_wave(const FieldParams& P, float scen
         // sees the reference's magnitude
         const float sc = (P.res_m1 * 0.5f) / scene_range;
         gx *= sc; gy *= sc; gz *= sc;
-        const float nrm = fmaxf(norm3(gx, gy, gz), 1e-12f);
-        gx /= nrm; gy /= nrm; gz /= nrm;
+        // (x * (1 / n) for F.normalize's x / n: one reciprocal instead of three IEEE divisions, an ulp inside the map's 3e-5)
+        const float rn = 1.0f / fmaxf(norm3(gx, gy, gz), 1e-12f);
+        gx *= rn; gy *= rn; gz *= rn;
         // the point's lanes 4 p .. 4 p + 3 all hold the result; sample lane 16 t + p takes it from lane 4 p
         const float sx = __shfl(gx, 4 * j, 64), sy = __shfl(gy, 4 * j, 64), sz = __shfl(gz, 4 * j, 64);
         if (g == t) { so.nx = sx; so.ny = sy; so.nz = sz; }
