@@ -21,6 +21,9 @@ GEOMETRY = {
     'cub': dict(scene_range=2.0, white=False, radius=3.0, focal=None, bbox=False),
     # carla (--use_viewdir): perspective, white background, the view-direction decoder
     'carla': dict(scene_range=1.0, white=True, radius=2.2, focal=1.2, bbox=False, viewdir=True),
+    # the generator's OTHER branches on the chairs cameras: NeRF density softplus(d - 1) instead of the SDF
+    # (models/generator.py:637-641) and the direct colour head wide_sigmoid_rescaled(features), A = 0 (665-666)
+    'density': dict(scene_range=0.55, white=True, radius=2.0, focal=1.0254, bbox=False, use_sdf=False, attention_values=0),
 }
 
 
@@ -56,13 +59,15 @@ def build_scene(geometry, batch, dev, seed=1234, alpha=0.05, beta=0.1):
     g = GEOMETRY[geometry]
     m = reference.modules()
     vd = bool(g.get('viewdir'))
+    use_sdf, n_att = bool(g.get('use_sdf', True)), int(g.get('attention_values', 10))
     torch.manual_seed(seed)
-    gen = m.generator.Generator(512, g['scene_range'], attention_values=10, use_viewdir=vd, use_sdf=True,
+    gen = m.generator.Generator(512, g['scene_range'], attention_values=n_att, use_viewdir=vd, use_sdf=use_sdf,
                                 disable_stylegan_noise=True)
     cpu = torch.Generator().manual_seed(seed + 1)
     with torch.no_grad():
-        gen.alpha.fill_(alpha)
-        gen.beta.fill_(beta)
+        if use_sdf:
+            gen.alpha.fill_(alpha)
+            gen.beta.fill_(beta)
         if vd:
             # the mapper's output layer is zero-initialised (generator.py:217-219): give it weights, or every colour
             # would be the same constant in both implementations
@@ -80,13 +85,20 @@ def build_scene(geometry, batch, dev, seed=1234, alpha=0.05, beta=0.1):
             sdf = out['sampler'](pts.view(batch, 1, 1, -1, 3), ['sdf_distance'])['sdf_distance']
         else:
             sdf = gen(None, ws, ['sampler'])['sampler'](pts, ['sdf_distance'])['sdf_distance']
-        gen.decoder.net[2].bias[0] -= sdf.flatten().quantile(0.25)
+        if use_sdf:
+            gen.decoder.net[2].bias[0] -= sdf.flatten().quantile(0.25)
+        else:
+            # density branch, sigma = softplus(d - 1): half of the volume well above 1, the rest well below
+            # (d' = k (d - median) + 1: the output row's weight times k, its bias moved accordingly)
+            k, q75 = 20.0, sdf.flatten().quantile(0.5)
+            gen.decoder.net[2].weight[0] *= k
+            gen.decoder.net[2].bias[0] = k * (gen.decoder.net[2].bias[0] - q75) + 1.0
     hip = nfi_gen.attach(copy.deepcopy(gen))
     ortho = g['focal'] is None
     cam = cameras(batch, g['radius'], cpu, ortho).to(dev)
     focal = None if ortho else torch.full((batch,), g['focal']).to(dev)
     bbox = crop_boxes(batch, cpu).to(dev) if g['bbox'] else None
-    args = reference.render_args(fine_sampling=True, use_sdf=True, attention_values=10, use_viewdir=vd)
+    args = reference.render_args(fine_sampling=True, use_sdf=use_sdf, attention_values=n_att, use_viewdir=vd)
     dcfg = {'scene_range': g['scene_range'], 'white_background': g['white']}
     return types.SimpleNamespace(geometry=geometry, g=g, gen=gen, hip=hip, z=z, ws=ws, cam=cam, focal=focal, bbox=bbox,
                                  args=args, dcfg=dcfg, batch=batch, dev=dev)
@@ -209,7 +221,8 @@ def reference_render(sc, res, samples, noise, device=None, images=None, grad=Fal
     if device is not None and torch.device(device) != cam.device:
         with torch.no_grad():
             planes = sc.gen.synthesis_network(ws[:, :14]).cpu()
-            extra_in = {'attention_values': _attention(sc.gen, ws).cpu()}
+            if sc.gen.attention_values > 0:
+                extra_in = dict(extra_in, attention_values=_attention(sc.gen, ws).cpu())
         gen = copy.deepcopy(sc.gen).to(device)
         ws, cam, focal, bbox = ws.to(device), cam.to(device), pick_to(focal, device), pick_to(bbox, device)
         ctx = frozen_producer(gen, planes)

@@ -35,10 +35,12 @@ def _check(rep, maps=('rgb', 'depth', 'mask')):
     assert rep['mask_mean'] > 0.1, rep          # the scene renders surfaces
 
 
-@pytest.mark.parametrize('geometry,batch', [('chairs', 1), ('chairs', 8), ('p3d', 16), ('cub', 4)])
+@pytest.mark.parametrize('geometry,batch', [('chairs', 1), ('chairs', 8), ('p3d', 16), ('cub', 4), ('density', 4)])
 def test_render_matches_the_real_reference(gpu_device, geometry, batch):
-    """cfg2 (B = 1 and 8), a p3d_car-like cfg3 batch (scene_range 1.4, black background, crop bbox, B = 16) and an
-    orthographic cub-like cfg4 batch, all 128 x 128 rays, 64 + 64 samples."""
+    """cfg2 (B = 1 and 8), a p3d_car-like cfg3 batch (scene_range 1.4, black background, crop bbox, B = 16), an
+    orthographic cub-like cfg4 batch, and the Generator's other branches (`use_sdf=False`: sigma = softplus(d - 1),
+    `attention_values=0`: rgb = wide_sigmoid_rescaled(features); models/generator.py:637-641, 665-666) on the chairs
+    cameras - all 128 x 128 rays, 64 + 64 samples."""
     _require_reference()
     sc = rc.build_scene(geometry, batch, gpu_device)
     rep = rc.compare(sc, 128, 64, cpu_images=2)
@@ -173,6 +175,9 @@ GRADIENT_MEASURED = {
     # (orthographic: the reference's own fp32 sum of the camera gradient is 6e-4 off float64, ours 4e-5 - below)
     'cub': dict(g_ws=5.4e-6, g_planes=5.5e-5, g_cam=6.3e-4),
     'carla': dict(g_ws=3.8e-6, g_planes=3.5e-5, g_cam=3.6e-5, g_focal=1.6e-5),
+    # density branch + direct colour head (one session: 3.7e-6 / 6.1e-5 / 2.7e-5 / 7.6e-5; the cameras are 'chairs', whose
+    # camera / focal spread over the sessions is taken over)
+    'density': dict(g_ws=3.8e-6, g_planes=6.1e-5, g_cam=7.7e-5, g_focal=3.5e-4),
 }
 # HIP's distance from the float64 reference over the fp32 reference's distance from it, at most (renderer only, same planes):
 # planes 1.0 - 2.0 measured (the backward's split-fp16 operands are scaled per tile: an entry is resolved to 2^-22 of its
@@ -182,7 +187,7 @@ GRADIENT_MEASURED = {
 FLOAT64_RATIO = dict(g_planes=2.5, g_cam=2.5, g_focal=6.0)
 
 
-@pytest.mark.parametrize('geometry', ['chairs', 'p3d', 'cub', 'carla'])
+@pytest.mark.parametrize('geometry', ['chairs', 'p3d', 'cub', 'carla', 'density'])
 def test_gradients_match_the_real_reference(gpu_device, geometry):
     """Forward + backward through the real plane producer: d loss / d ws (through the StyleGAN2 synthesis network and
     the texture mapper), d loss / d planes (what the renderer hands the producer's backward), d loss / d camera matrix,

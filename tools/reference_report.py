@@ -49,12 +49,12 @@ def main():
             with rc.deterministic_producer():
                 return fn()
         return run
-    for geometry in ('chairs', 'p3d', 'cub'):
+    for geometry in ('chairs', 'p3d', 'cub', 'density'):
         section('gradients', '%s_b2_128px_64+64' % geometry, det(lambda: rc.gradients(rc.build_scene(geometry, 2, dev), 128, 64)))
     section('gradients', 'carla_viewdir_b2_64px_32+32', det(lambda: rc.gradients(rc.build_scene('carla', 2, dev), 64, 32)))
     section('training_step_cub_b4_128px_64+64', None, det(lambda: rc.training_step(rc.build_scene('cub', 4, dev), 128, 64)))
     section('regularisers_cub_b2', None, det(lambda: rc.regularisers(rc.build_scene('cub', 2, dev))))
-    for geometry, batch in (('chairs', 1), ('chairs', 8), ('p3d', 16), ('cub', 4)):
+    for geometry, batch in (('chairs', 1), ('chairs', 8), ('p3d', 16), ('cub', 4), ('density', 4)):
         section('forward', '%s_b%d_128px_64+64' % (geometry, batch), lambda: rc.compare(rc.build_scene(geometry, batch, dev), 128, 64, cpu_images=2))
     if not only or 'forward' in only:
         sc = rc.build_scene('p3d', 4, dev)
