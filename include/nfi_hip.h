@@ -490,8 +490,8 @@ typedef struct nfi_render_args {
   /* [N,3] or NULL: the composited normal map, sum_k w_k normalize(d sdf / d x)_k over the merged samples, + (1 - mask)
    * on a white background (compute_normals: run.py:228-230, 241-245, 296-300; lib/nerf_utils.py:149-151, 159; the
    * sampler's 'normals' output, models/generator.py:599-618, here the analytic derivative of the decoder's distance
-   * instead of autograd).  use_sdf only; fp32 or fp16 texels; same launch, same restrictions as `coords`; not with the
-   * view-direction decoder. */
+   * instead of autograd).  use_sdf only; any texel storage; same launch, same restrictions as `coords` (with the
+   * view-direction decoder: fp32 texels - the distance is row 0 of its second layer). */
   float* normals;
 } nfi_render_args;
 size_t nfi_render_workspace_bytes(int64_t n_rays);

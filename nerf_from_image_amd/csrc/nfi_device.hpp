@@ -391,7 +391,9 @@ __device__ __forceinline__ void split_f16x8(const float (&x)[8], f16x8& hi, f16x
 //   kg = lane >> 4), element e: W1'[unit 32 kk + 16 (e >> 2) + 4 kg + (e & 3)][channel 16 ct + i] - the k-slot order in which
 //   the accumulator layout of layer 1 (rows 4 g + r of n-tiles 2 kk, 2 kk + 1) is the B operand (as in layer 2)
 //   W2F[nt][(g, m)][r] = W2'[row m][unit 16 nt + 4 g + r]  ->  w2r0[g][nt][r] = W2F[nt][(g, 0)][r]
-__device__ __forceinline__ void stage_normal_operands(float* dst, const float* image) {
+// (w1f / w2f: float offsets of the W1 fragments and of the second layer's fragments in `image` - kW1F / kW2F of the plain
+//  decoder image, kVdW1F / kVdW2 of the view-direction one, whose tile 0 holds the distance row)
+__device__ __forceinline__ void stage_normal_operands(float* dst, const float* image, int w1f = kW1F, int w2f = kW2F) {
   for (int idx = threadIdx.x; idx < 256; idx += blockDim.x) {
     const int l = idx & 63, kk = (idx >> 6) & 1, ct = idx >> 7;
     const int kg = l >> 4, c = 16 * ct + (l & 15);
@@ -400,7 +402,7 @@ __device__ __forceinline__ void stage_normal_operands(float* dst, const float* i
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       const int u = 32 * kk + 16 * (e >> 2) + 4 * kg + (e & 3);
-      x[e] = image[kW1F + (((sq * 64 + (16 * gq + (u & 15))) << 2) + (u >> 4))];
+      x[e] = image[w1f + (((sq * 64 + (16 * gq + (u & 15))) << 2) + (u >> 4))];
     }
     f16x8 hi, lo;
     split_f16x8(x, hi, lo);
@@ -409,7 +411,7 @@ __device__ __forceinline__ void stage_normal_operands(float* dst, const float* i
   }
   for (int i = threadIdx.x; i < 64; i += blockDim.x) {
     const int r = i & 3, nt = (i >> 2) & 3, g = i >> 4;
-    dst[kW1TFloats + i] = image[kW2F + ((nt * 64 + 16 * g) << 2) + r];
+    dst[kW1TFloats + i] = image[w2f + ((nt * 64 + 16 * g) << 2) + r];
   }
 }
 
@@ -856,6 +858,42 @@ __device__ __forceinline__ uint32_t ratio_f16x2(int es, float inv_pt) {
   return hb | (hb << 16);
 }
 
+// G^T[32 channels x 16 points] = W1'^T[32 x 64] * GH[64 x 16] (rows 16 ct + 4 g + r: the channel ownership of `feat`), the
+// operand of the normal map (field_wave).  gh: d(distance) / d(h2) of the lane's hidden units = sigmoid(h) * W2'[0][unit] in
+// accumulator layout.  Split fp16 like the layers themselves (round 6: 12 K = 32 MFMAs instead of 32 exact-fp32 ones, which
+// run at the fp32 VECTOR rate on gfx950): a gradient has no natural scale and the hi + lo split resolves 2^-24 absolute,
+// so GH is scaled per point by a power of two and the accumulator scaled back exactly.
+__device__ __forceinline__ void normal_contraction(const FieldParams& P, int lane, const f32x4 (&gh)[4], f32x4& Gout0, f32x4& Gout1) {
+  const u32x4* w1t = reinterpret_cast<const u32x4*>(P.w1t);
+  float am = 0.0f;
+#pragma unroll
+  for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) am = fmaxf(am, fabsf(gh[nt][r]));
+  am = max_xor32(max_xor16(am));                       // over the four hidden groups of point j
+  float ssc, s_inv;
+  pow2_normaliser(am, ssc, s_inv);
+  f32x4 G0 = {0.0f, 0.0f, 0.0f, 0.0f}, G1 = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+  for (int kk = 0; kk < 2; ++kk) {
+    const f32x4 ga = gh[2 * kk], gb = gh[2 * kk + 1];
+    const float xs[8] = {ga.x * ssc, ga.y * ssc, ga.z * ssc, ga.w * ssc, gb.x * ssc, gb.y * ssc, gb.z * ssc, gb.w * ssc};
+    f16x8 sh, sl;
+    split_f16x8(xs, sh, sl);
+    const f16x8 ah = __builtin_bit_cast(f16x8, w1t[((0 * 2 + kk) * 2 + 0) * 64 + lane]);
+    const f16x8 al = __builtin_bit_cast(f16x8, w1t[((0 * 2 + kk) * 2 + 1) * 64 + lane]);
+    const f16x8 bh = __builtin_bit_cast(f16x8, w1t[((1 * 2 + kk) * 2 + 0) * 64 + lane]);
+    const f16x8 bl = __builtin_bit_cast(f16x8, w1t[((1 * 2 + kk) * 2 + 1) * 64 + lane]);
+    G0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, sh, G0, 0, 0, 0);
+    G1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh, sh, G1, 0, 0, 0);
+    G0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, sl, G0, 0, 0, 0);
+    G1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh, sl, G1, 0, 0, 0);
+    G0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, sh, G0, 0, 0, 0);
+    G1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(bl, sh, G1, 0, 0, 0);
+  }
+  Gout0 = G0 * s_inv; Gout1 = G1 * s_inv;
+}
+
 // PREC 0: exact fp32 MFMA (v_mfma_f32_16x16x4_f32, 48 per tile).
 // PREC 1: split fp16 (v_mfma_f32_16x16x32_f16, 18 per tile): every operand is hi + lo in fp16 and the
 //         products hi*hi + hi*lo + lo*hi are accumulated in fp32 - 2^-21 relative per product instead of
@@ -907,41 +945,8 @@ __device__ __forceinline__ void tile_mlp(const FieldParams& P, int lane, const f
             gh[nt][r] = sg * reinterpret_cast<const f32x4*>(P.w2r0)[g * 4 + nt][r];
           }
         }
-      if constexpr (NRM) {
-        // G^T[32 channels x 16 points] = W1'^T[32 x 64] * GH[64 x 16] (rows 16 ct + 4 g + r: the channel ownership of
-        // `feat`), the operand of the normal map (field_wave).  Split fp16 like the layers themselves (round 6: 12 K = 32
-        // MFMAs instead of 32 exact-fp32 ones, which run at the fp32 VECTOR rate on gfx950), right behind this tile's
-        // softplus so that GH never outlives it: a gradient has no natural scale and the hi + lo split resolves 2^-24
-        // absolute, so GH is scaled per point by a power of two and the accumulator scaled back exactly.
-        const u32x4* w1t = reinterpret_cast<const u32x4*>(P.w1t);
-        float am = 0.0f;
-#pragma unroll
-        for (int nt = 0; nt < 4; ++nt)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) am = fmaxf(am, fabsf(gh[nt][r]));
-        am = max_xor32(max_xor16(am));                       // over the four hidden groups of point j
-        float ssc, s_inv;
-        pow2_normaliser(am, ssc, s_inv);
-        f32x4 G0 = {0.0f, 0.0f, 0.0f, 0.0f}, G1 = {0.0f, 0.0f, 0.0f, 0.0f};
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-          const f32x4 ga = gh[2 * kk], gb = gh[2 * kk + 1];
-          const float xs[8] = {ga.x * ssc, ga.y * ssc, ga.z * ssc, ga.w * ssc, gb.x * ssc, gb.y * ssc, gb.z * ssc, gb.w * ssc};
-          f16x8 sh, sl;
-          split_f16x8(xs, sh, sl);
-          const f16x8 ah = __builtin_bit_cast(f16x8, w1t[((0 * 2 + kk) * 2 + 0) * 64 + lane]);
-          const f16x8 al = __builtin_bit_cast(f16x8, w1t[((0 * 2 + kk) * 2 + 1) * 64 + lane]);
-          const f16x8 bh = __builtin_bit_cast(f16x8, w1t[((1 * 2 + kk) * 2 + 0) * 64 + lane]);
-          const f16x8 bl = __builtin_bit_cast(f16x8, w1t[((1 * 2 + kk) * 2 + 1) * 64 + lane]);
-          G0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, sh, G0, 0, 0, 0);
-          G1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh, sh, G1, 0, 0, 0);
-          G0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, sl, G0, 0, 0, 0);
-          G1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh, sl, G1, 0, 0, 0);
-          G0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, sh, G0, 0, 0, 0);
-          G1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(bl, sh, G1, 0, 0, 0);
-        }
-        Gout[n][0] = G0 * s_inv; Gout[n][1] = G1 * s_inv;
-      }
+      // (right behind this tile's softplus, so that GH never outlives it)
+      if constexpr (NRM) normal_contraction(P, lane, gh, Gout[n][0], Gout[n][1]);
     }
     const f32x4 b2 = ldsv[(kB2F >> 2) + g];
 #pragma unroll
@@ -1031,10 +1036,10 @@ __device__ __forceinline__ void tile_mlp(const FieldParams& P, int lane, const f
 // through), layer 3 over K = those 48 accumulator rows - the accumulator layout of one layer is the B
 // operand of the next, as between layers 1 and 2.  xr[n][t]: rows 16t+4g..+3 of the padded ray feature
 // of tile n's point j.  P.lds holds the nfi_decoder_pack_viewdir image.
-template <bool ATT, int N, int SEMP = 0>
+template <bool ATT, int N, int SEMP = 0, bool NRM = false>
 __device__ __forceinline__ void tile_mlp_vd(const FieldParams& P, int lane, const float (&feat)[N][8],
                                             const f32x4 (&xr)[N][3], const float (&outside)[N], float* const (&sem)[N],
-                                            TileOut (&res)[N]) {
+                                            TileOut (&res)[N], f32x4 (&Gout)[N][2]) {
   const int g = lane >> 4;
   const f32x4* ldsv = reinterpret_cast<const f32x4*>(P.lds);
   f32x4 acc1[N][4];
@@ -1056,7 +1061,8 @@ __device__ __forceinline__ void tile_mlp_vd(const FieldParams& P, int lane, cons
     }
   }
 #pragma unroll
-  for (int n = 0; n < N; ++n)
+  for (int n = 0; n < N; ++n) {
+    f32x4 gh[4];        // NRM: sigmoid(h) * W2'[0][unit] - the distance is row 0 of the second layer here too
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
@@ -1065,7 +1071,13 @@ __device__ __forceinline__ void tile_mlp_vd(const FieldParams& P, int lane, cons
         float e = __builtin_amdgcn_exp2f(h);
         float sp = __builtin_amdgcn_logf(1.0f + e);
         acc1[n][nt][r] = (h > kSoftplusThr2) ? h : sp;
+        if constexpr (NRM) {
+          const float sg = (h > kSoftplusThr2) ? 1.0f : e * __builtin_amdgcn_rcpf(1.0f + e);
+          gh[nt][r] = sg * reinterpret_cast<const f32x4*>(P.w2r0)[g * 4 + nt][r];
+        }
       }
+    if constexpr (NRM) normal_contraction(P, lane, gh, Gout[n][0], Gout[n][1]);
+  }
   f32x4 o2[N][3];
 #pragma unroll
   for (int t = 0; t < 3; ++t) {
@@ -1236,8 +1248,9 @@ __device__ __forceinline__ SampleOut field_wave(const FieldParams& P, float scen
     };
     float* const sems[2] = {(sem_base && (fa & 2)) ? sem_col(ta) : nullptr, (sem_base && pair && (fb & 2)) ? sem_col(tb) : nullptr};
     TileOut to[2];
+    f32x4 Gp[2][2];          // NRM: d(distance) / d(feature) of the pair's tiles (tile_mlp / tile_mlp_vd)
     if constexpr (VD) {
-      static_assert(PREC == 0 && !NRM, "the view-direction decoder exists in exact fp32 only, without the normal map");
+      static_assert(PREC == 0, "the view-direction decoder exists in exact fp32 only");
       const int ra = __shfl(ray_idx, 16 * ta + j, 64), rb = __shfl(ray_idx, 16 * tb + j, 64);
       f32x4 xr[2][3];
 #pragma unroll
@@ -1245,10 +1258,11 @@ __device__ __forceinline__ SampleOut field_wave(const FieldParams& P, float scen
         xr[0][t] = *reinterpret_cast<const f32x4*>(xray + (size_t)ra * kRayFeatPad + 16 * t + 4 * g);
         xr[1][t] = *reinterpret_cast<const f32x4*>(xray + (size_t)rb * kRayFeatPad + 16 * t + 4 * g);
       }
-      tile_mlp_vd<ATT, 2, SEMP>(P, lane, feat, xr, outs, sems, to);
-    } else if constexpr (NRM) {
-      f32x4 Gp[2][2];
-      tile_mlp<ATT, 2, PREC, SEMP, true>(P, lane, feat, outs, sems, to, Gp);
+      tile_mlp_vd<ATT, 2, SEMP, NRM>(P, lane, feat, xr, outs, sems, to, Gp);
+    } else {
+      tile_mlp<ATT, 2, PREC, SEMP, NRM>(P, lane, feat, outs, sems, to, Gp);
+    }
+    if constexpr (NRM) {
       // ---- normals of the pair's points, one tile at a time ----
 #pragma unroll 1
       for (int n = 0; n < 2; ++n) {
@@ -1320,8 +1334,6 @@ __device__ __forceinline__ SampleOut field_wave(const FieldParams& P, float scen
         const float sx = __shfl(gx, 4 * j, 64), sy = __shfl(gy, 4 * j, 64), sz = __shfl(gz, 4 * j, 64);
         if (g == t) { so.nx = sx; so.ny = sy; so.nz = sz; }
       }
-    } else {
-      tile_mlp<ATT, 2, PREC, SEMP>(P, lane, feat, outs, sems, to);
     }
     if (g == ta) { so.sdf = to[0].sdf; so.sigma = to[0].sigma; so.r = to[0].r; so.g = to[0].g; so.b = to[0].b; }
     if (pair && g == tb) { so.sdf = to[1].sdf; so.sigma = to[1].sigma; so.r = to[1].r; so.g = to[1].g; so.b = to[1].b; }

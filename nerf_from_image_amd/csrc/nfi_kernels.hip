@@ -1489,7 +1489,7 @@ __global__ __launch_bounds__(256, OCC) void render_fwd_kernel(RenderKernelParams
   __shared__ __attribute__((aligned(16))) float lds[kImg];
   __shared__ __attribute__((aligned(16))) float vfs[4][64];
   __shared__ WaveSlab slabs[4];
-  if constexpr (NRM) stage_normal_operands(nfi_dyn_lds, k.image);
+  if constexpr (NRM) stage_normal_operands(nfi_dyn_lds, k.image, VD ? kVdW1F : kW1F, VD ? kVdW2 : kW2F);
   ClockProbe clock;
   clock.start(k);
   if (PREC == 1) {
@@ -1773,7 +1773,7 @@ __global__ __launch_bounds__(256, OCC) void render_fwd_wide_kernel(RenderKernelP
   __shared__ __attribute__((aligned(16))) float lds[kImg];
   __shared__ __attribute__((aligned(16))) float vfs[4][64];
   __shared__ WaveSlabWide slabs[4];
-  if constexpr (NRM) stage_normal_operands(nfi_dyn_lds, k.image);
+  if constexpr (NRM) stage_normal_operands(nfi_dyn_lds, k.image, VD ? kVdW1F : kW1F, VD ? kVdW2 : kW2F);
   ClockProbe clock;
   clock.start(k);
   if (PREC == 1) {
@@ -2328,8 +2328,8 @@ extern "C" int nfi_render_fwd(const nfi_render_args* a, nfi_stream_t stream) {
           "render: termination_eps cannot be combined with stage taps, extra maps, the cycle profile, the view-direction decoder or the exact-fp32 MLP");
   REQUIRE(!extra || !(any_tap || a->profile_cycles || strict),
           "render: semantics / coords / normals maps cannot be combined with stage taps, the cycle profile or the exact-fp32 MLP");
-  REQUIRE(!(extra && a->ray_features) || (!a->normals && a->texel_dtype == NFI_TEXEL_F32),
-          "render: with the view-direction decoder the semantics / coords maps exist for fp32 texels (no normals map)");
+  REQUIRE(!(extra && a->ray_features) || a->texel_dtype == NFI_TEXEL_F32,
+          "render: with the view-direction decoder the semantics / coords / normals maps exist for fp32 texels");
   // the exact-fp32 MLP (a diagnostic of the split-fp16 arithmetic) and the cycle profile are built for fp32 texels only:
   // with 16-bit texel storage the texels, not the MLP operands, set the precision
   REQUIRE(!(strict || a->profile_cycles) || a->texel_dtype == NFI_TEXEL_F32,
@@ -2392,7 +2392,15 @@ extern "C" int nfi_render_fwd(const nfi_render_args* a, nfi_stream_t stream) {
   } while (0)
 #define NFI_LAUNCH_RENDER_VD(TEX, ATT)                                                                                        \
   do {                                                                                                                      \
-    if (extra && TEX == 0) {      /* semantics / coords maps with the view-direction decoder (fp32 texels: checked above) */ \
+    if (a->normals && TEX == 0) { /* + the normal map (round 6): the distance is row 0 of the second layer here too */       \
+      if (wide) {                                                                                                           \
+        NFI_ENSURE_DYNAMIC_LDS((render_fwd_wide_kernel<0, ATT, kRenderNormals, 0, true>), kSemLdsMaxWide, "render");         \
+        hipLaunchKernelGGL((render_fwd_wide_kernel<0, ATT, kRenderNormals, 0, true>), grid, dim3(256), sem_lds, s, k);       \
+      } else {                                                                                                              \
+        NFI_ENSURE_DYNAMIC_LDS((render_fwd_kernel<0, ATT, NFI_RENDER_OCC, kRenderNormals, 0, true>), kSemLdsMax, "render");  \
+        hipLaunchKernelGGL((render_fwd_kernel<0, ATT, NFI_RENDER_OCC, kRenderNormals, 0, true>), grid, dim3(256), sem_lds, s, k); \
+      }                                                                                                                     \
+    } else if (extra && TEX == 0) { /* semantics / coords maps with the view-direction decoder (fp32 texels: checked above) */ \
       if (wide) {                                                                                                           \
         NFI_ENSURE_DYNAMIC_LDS((render_fwd_wide_kernel<0, ATT, kRenderExtra, 0, true>), kSemLdsMaxWide, "render");           \
         hipLaunchKernelGGL((render_fwd_wide_kernel<0, ATT, kRenderExtra, 0, true>), grid, dim3(256), sem_lds, s, k);         \

@@ -407,7 +407,8 @@ def render_fwd(cam2world, focal, height, width, num_samples, texels, decoder_ima
     strict call / flush_strict().
     want_semantics / want_coords: also return 'semantics' [B,H,W,A] (composited softmax probabilities, run.py:312-335)
     / 'coords' [B,H,W,3] (composited query points, run.py:337-338) / 'normals' [B,H,W,3] (composited unit normals of the
-    SDF, + 1 - mask on a white background, lib/nerf_utils.py:149-151, 159; any texel storage) from the SAME launch.
+    SDF, + 1 - mask on a white background, lib/nerf_utils.py:149-151, 159; any texel storage; with ray_features: fp32
+    texels) from the SAME launch.
     Precision of 'semantics': with num_samples <= 64 the per-sample probabilities wait for the compositing in fp32; the
     64 < num_samples <= 128 kernel parks them as unorm16 (|error| <= 2^-17 = 7.7e-6 per sample, values below that become
     0), so its map is within 1e-5 of the reference's instead of 1e-6 (tests/test_hip_parity.py,

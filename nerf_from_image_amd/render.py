@@ -16,8 +16,8 @@ Three execution paths, all HIP through the C ABI:
                      backward launch over the 2S points of every ray (+ its binned plane-gradient scatter) -> ray /
                      camera backward.  Replaces the ~20 launches of the staged graph;
   * staged         - one launch per stage through ``nerf_utils`` and the ``sampler`` closure: extra maps with a gradient /
-                     the 'bbox' overlay / the view-direction decoder's normal map (its semantics and coords maps are
-                     fused), or over a single pass of more than 128 samples.
+                     the 'bbox' overlay / extra maps of the view-direction decoder on 16-bit texels, or over a single pass
+                     of more than 128 samples.
 A single pass of up to 512 samples (run.py's inversion without --fine_sampling: depth_samples_per_ray * 4, run.py:2271)
 takes the fused / fused + stash paths too (render_fwd_long_kernel).
 Randomness follows the reference, in its order: ``torch.rand`` of [B,H,W,S] for the stratified
@@ -211,11 +211,12 @@ def _render(cfg, dcfg, opts, target_model, height, width, tform_cam2world, focal
             return torch.rand([B * rows * width, S], dtype=torch.float32, device=dev)
         return None            # the kernels take linspace(0, 1, S) themselves (nerf_utils.py:196-200)
 
-    # semantics / coords / normals are composited by the fused kernel itself (any texel storage); the 'bbox' overlay (which
-    # edits sigma, generator.py:645-659) and normals / 16-bit texels with the view-direction decoder keep the staged path
-    # (with the view-direction decoder the kernel composites semantics / coords on fp32 texels; its normal map is staged)
+    # semantics / coords / normals are composited by the fused kernel itself (any texel storage; with the view-direction
+    # decoder: fp32 texels); the 'bbox' overlay (which edits sigma, generator.py:645-659) and 16-bit texels with the
+    # view-direction decoder keep the staged path
+    # (with the view-direction decoder the kernel composites semantics / coords / normals on fp32 texels)
     fused_maps = plain or (not getattr(fused, 'bbox_overlay', False) and
-                           (ray_features is None or (not compute_normals and fused.texels.dtype == torch.float32)))
+                           (ray_features is None or fused.texels.dtype == torch.float32))
     if compute_normals and fused is not None:
         # the sampler's own condition (generator.py:599-602; torch.is_grad_enabled() is autograd's business there)
         assert fused.use_sdf and not getattr(target_model, 'training', False)

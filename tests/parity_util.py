@@ -54,10 +54,14 @@ def err(a, b):
 def oracle_normal_map(meta, t, o):
     """The composited normal map of a golden case as the reference computes it (generator.py:599-623 + lib/nerf_utils.py:
     149-151, 159): autograd of the oracle's distance at every sample, normalised, composited with the oracle's weights."""
+    # (--use_viewdir cases: the distance is row 0 of the 33-row second layer; the colour rows do not matter here, so the
+    #  oracle is asked with the first four rows as a plain A = 0 decoder)
+    vd = 'viewdir_x' in t
+    w2, b2, att = (t['w2'][:4], t['b2'][:4], None) if vd else (t['w2'], t['b2'], t.get('attention_values'))
+
     def oracle_normals(pts):
         p = pts.clone().requires_grad_()
-        q = orc.field_query(t['planes'], t['w1'], t['b1'], t['w2'], t['b2'], p, meta['scene_range'], True, t['beta'],
-                            t['alpha'], t.get('attention_values'))
+        q = orc.field_query(t['planes'], t['w1'], t['b1'], w2, b2, p, meta['scene_range'], True, t['beta'], t['alpha'], att)
         gx, = torch.autograd.grad(q['sdf'].sum(), p)
         return torch.nn.functional.normalize(gx, dim=-1)
     B, H, W = meta['B'], meta['H'], meta['W']

@@ -343,8 +343,13 @@ def test_fused_render_extra_maps(case):
             close(r['coords'], o['semantics'], 1e-5, 'coords map (oracle render)')
             close(r['coords'], t['ref_coords_map'], 1e-5, 'coords map vs committed reference output')
     if vd:
-        with pytest.raises((RuntimeError, ValueError)):
-            hip_render(meta, t, dev, skip_missed_rays=True, want_normals=True)       # staged path only (render.py)
+        if meta['sdf']:
+            # the normal map with the view-direction decoder in the SAME launch since round 6 (the distance is row 0 of its
+            # second layer; run.py:1444-1454 on carla): against autograd of the oracle's distance, like the plain decoder
+            rn = hip_render(meta, t, dev, skip_missed_rays=True, want_normals=True, want_semantics=want_sem, want_coords=True)
+            for k in ('rgb', 'depth', 'mask'):
+                exact(rn[k], plain[k], 'normal-map launch (view-direction decoder), %s' % k)
+            close(rn['normals'], oracle_normal_map(meta, t, o), 3e-5, 'normal map, view-direction decoder')
         with pytest.raises(RuntimeError):
             hip_render(meta, t, dev, skip_missed_rays=True, texel_dtype=ops.TEXEL_F16, want_coords=True)
         return
