@@ -239,7 +239,7 @@ def test_inversion_steps_match_the_real_reference(gpu_device):
     (h0, q0, j0), (h1, q1, j1) = r['hip'][0], r['hip'][-1]
     assert l1 < l0 and h1 < h0 and p1 > p0 + 5.0, (r['reference'], r['hip'])                 # both descend (+ 11.8 dB)
     # free-running trajectories (each its own Adam; chaotic): measured 1.5e-5 ... 2.8e-3 dB apart after the 30 steps, IoU identical
-    assert abs(q1 - p1) <= 1e-2 and abs(j1 - i1) <= 1e-4, (r['reference'][-1], r['hip'][-1])
+    assert abs(q1 - p1) <= 8.5e-3 and abs(j1 - i1) <= 1e-4, (r['reference'][-1], r['hip'][-1])
 
 
 def test_regulariser_branch_on_the_real_generator(gpu_device):

@@ -102,6 +102,17 @@ def main():
     res['render_cfg5_semantics'] = stress('render 2 x 256^2 128+128 + semantics map (cfg5)',
                                           render_case(dev, 2, bench.RADIUS, ops.TEXEL_F32, R=256, S=128, want_semantics=True),
                                           max(n // 4, 50), ('rgb', 'depth', 'mask', 'semantics'))
+    # round 6: the normal map's split-fp16 contraction (new K = 32 MFMAs next to packed-fp32 code), fp32 / bf16 texels, 128 + 128
+    res['render_b8_chairs_normals'] = stress('render 8 x 128^2 64+64 chairs-like + normals map',
+                                             render_case(dev, 8, bench.RADIUS, ops.TEXEL_F32, want_normals=True), max(n // 2, 50),
+                                             ('rgb', 'depth', 'mask', 'normals'))
+    res['render_b8_all_hit_normals_bf16'] = stress('render 8 x 128^2 64+64 every ray hits + normals map, bf16 texels',
+                                                   render_case(dev, 8, 1.3, ops.TEXEL_BF16, want_normals=True), max(n // 4, 50),
+                                                   ('rgb', 'depth', 'mask', 'normals'))
+    res['render_cfg5_normals_semantics'] = stress('render 2 x 256^2 128+128 + normals + semantics maps (cfg5)',
+                                                  render_case(dev, 2, bench.RADIUS, ops.TEXEL_F32, R=256, S=128, want_normals=True,
+                                                              want_semantics=True), max(n // 4, 50),
+                                                  ('rgb', 'depth', 'mask', 'normals', 'semantics'))
     res['field_query_exact'] = stress('field_query_kernel 2 x 1 Mi points, exact fp32', field_case(dev, 0), max(n // 2, 50),
                                       ('sigma', 'rgb', 'sdf'))
     res['field_query_split'] = stress('field_query_kernel 2 x 1 Mi points, split fp16', field_case(dev, 1), max(n // 2, 50),
