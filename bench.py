@@ -556,6 +556,13 @@ def main():
                 cfg['end_to_end_reference_rays_per_s'] = e2e['reference_rays_per_s']
                 cfg['x_reference_end_to_end'] = e2e['x_reference_fp32_texels']
                 cfg['renderer_share_of_end_to_end_render'] = res['ms_per_step'] / e2e['hip_fp32_texels_ms']
+                b1 = (res['extras'].get('end_to_end_real_generator') or {}).get('render_incl_synthesis', {}).get('b1') or {}
+                if 'hip_fp32_texels_hip_graph_rays_per_s' in b1:
+                    # one image per call is launch bound (~380 producer launches): the whole call as ONE HIP graph
+                    # (nerf_from_image_amd/graphs.py) against the eager drop-in and the reference
+                    cfg['end_to_end_b1_rays_per_s'] = b1['hip_fp32_texels_rays_per_s']
+                    cfg['end_to_end_b1_hip_graph_rays_per_s'] = b1['hip_fp32_texels_hip_graph_rays_per_s']
+                    cfg['x_reference_end_to_end_b1_hip_graph'] = b1['x_reference_hip_graph']
             dev16 = res['extras'].get('texel_storage_vs_fp32_reference') or {}
             for tx in ('bf16', 'fp16'):
                 r16 = dev16.get('cfg2_b8_128px_64+64_%s_texels' % tx)
