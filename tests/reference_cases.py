@@ -51,7 +51,7 @@ def crop_boxes(n, gen):
     return torch.stack([start, size.expand(n, 2)], dim=1).contiguous()
 
 
-def build_scene(geometry, batch, dev, seed=1234, alpha=0.05, beta=0.1):
+def build_scene(geometry, batch, dev, seed=1234, alpha=0.05, beta=0.1, fine_sampling=True):
     """A default-initialised reference Generator with its SDF centred so that it renders surfaces (a random-init
     generator renders an almost empty scene: SURVEY.md 8(d)), its twin with the HIP sampler attached, and seeded
     cameras / latents.  Returns a namespace."""
@@ -98,7 +98,7 @@ def build_scene(geometry, batch, dev, seed=1234, alpha=0.05, beta=0.1):
     cam = cameras(batch, g['radius'], cpu, ortho).to(dev)
     focal = None if ortho else torch.full((batch,), g['focal']).to(dev)
     bbox = crop_boxes(batch, cpu).to(dev) if g['bbox'] else None
-    args = reference.render_args(fine_sampling=True, use_sdf=use_sdf, attention_values=n_att, use_viewdir=vd)
+    args = reference.render_args(fine_sampling=fine_sampling, use_sdf=use_sdf, attention_values=n_att, use_viewdir=vd)
     dcfg = {'scene_range': g['scene_range'], 'white_background': g['white']}
     return types.SimpleNamespace(geometry=geometry, g=g, gen=gen, hip=hip, z=z, ws=ws, cam=cam, focal=focal, bbox=bbox,
                                  args=args, dcfg=dcfg, batch=batch, dev=dev)
@@ -136,8 +136,10 @@ class ReplayNoise:
 
 def draw_noise(sc, res, samples, seed=99):
     gn = torch.Generator(device=sc.dev).manual_seed(seed)
-    return [torch.rand((sc.batch, res, res, samples), device=sc.dev, generator=gn),
-            torch.rand((sc.batch * res * res, samples), device=sc.dev, generator=gn)]
+    draws = [torch.rand((sc.batch, res, res, samples), device=sc.dev, generator=gn)]
+    if sc.args.fine_sampling:                    # (the inverse-CDF draw exists with fine sampling only, run.py:261-281)
+        draws.append(torch.rand((sc.batch * res * res, samples), device=sc.dev, generator=gn))
+    return draws
 
 
 def as_double(sc):
@@ -215,7 +217,7 @@ def reference_render(sc, res, samples, noise, device=None, images=None, grad=Fal
     pick = (lambda t: None if t is None else t[sl])
     gen, ws, cam, focal, bbox = sc.gen, sc.ws[sl], sc.cam[sl], pick(sc.focal), pick(sc.bbox)
     n = cam.shape[0]
-    nz = None if noise is None else [noise[0][sl], noise[1].view(sc.batch, -1, samples)[sl].reshape(-1, samples)]
+    nz = None if noise is None else [noise[0][sl]] + [n.view(sc.batch, -1, samples)[sl].reshape(-1, samples) for n in noise[1:]]
     ctx = contextlib.nullcontext()
     extra_in = dict(render_kw.pop('extra_model_inputs', {}))
     if device is not None and torch.device(device) != cam.device:

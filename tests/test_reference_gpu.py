@@ -74,6 +74,16 @@ def _check_storage(rep, measured):
     assert rep['mask_mean'] > 0.1, rep
 
 
+def test_cfg1_shape_coarse_only_matches_the_real_reference(gpu_device):
+    """BASELINE cfg1's shape - 4 scenes, 64 x 64 rays, 32 coarse samples, no fine pass (`--fine_sampling` off: ONE stratified
+    draw, no resampling, run.py:261 skipped) - on the real class: the single-pass fused kernel against the reference."""
+    _require_reference()
+    sc = rc.build_scene('chairs', 4, gpu_device, fine_sampling=False)
+    rep = rc.compare(sc, 64, 32, cpu_images=2)
+    _check(rep)
+    assert max(rep['pixels_over_1e-4_vs_reference_gpu'].values()) <= 2, rep
+
+
 @pytest.mark.parametrize('case', ['cfg5_b2_256px_128+128_fp32_texels', 'cfg2_b8_128px_64+64_fp32_texels_term1e-5',
                                   'cfg5_b2_256px_128+128_fp32_texels_term1e-5'])
 def test_cfg5_shape_and_termination_match_the_real_reference(gpu_device, case):
