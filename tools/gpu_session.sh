@@ -16,6 +16,8 @@ for w in $WHAT; do
   case $w in
     tests)
       timeout 1500 python -m pytest tests -m gpu -q --durations=15 > $O/pytest.log 2>&1; echo "pytest rc=$?" >> $O/env.txt; tail -5 $O/pytest.log;;
+    gsphere)
+      timeout 900 python tools/g_sphere.py 300 8 > $O/g_sphere.json 2> $O/g_sphere.err; echo "gsphere rc=$?" >> $O/env.txt; tail -3 $O/g_sphere.err; tail -c 2500 $O/g_sphere.json;;
     gradspread)
       timeout 900 python tools/gradient_spread.py 3 > $O/gradient_spread.json 2> $O/gradient_spread.err; echo "gradspread rc=$?" >> $O/env.txt; tail -3 $O/gradient_spread.err;;
     reftests)
