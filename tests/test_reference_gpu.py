@@ -74,6 +74,22 @@ def _check_storage(rep, measured):
     assert rep['mask_mean'] > 0.1, rep
 
 
+def test_sphere_pretrained_generator_matches_the_real_reference(gpu_device):
+    """SURVEY 8(d)'s "G-sphere": a default-initialised generator renders an almost empty scene, so the reference's own
+    `pretrain_sdf` (run.py:824-866) is run first - 80 Adam steps against the unit sphere here, 300 in tools/g_sphere.py - and
+    the drop-in is compared with the untouched reference on the result: every ray ends on an opaque surface."""
+    _require_reference()
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tools'))
+    import g_sphere
+    state = g_sphere.pretrained_state(gpu_device, 80, 4)
+    sc = g_sphere.scene_from_state(state, gpu_device, 4)
+    rep = rc.compare(sc, 128, 64, cpu_images=1)
+    _check(rep)
+    assert rep['mask_mean'] > 0.9 and max(rep['pixels_over_1e-4_vs_reference_gpu'].values()) <= 2, rep
+
+
 def test_cfg1_shape_coarse_only_matches_the_real_reference(gpu_device):
     """BASELINE cfg1's shape - 4 scenes, 64 x 64 rays, 32 coarse samples, no fine pass (`--fine_sampling` off: ONE stratified
     draw, no resampling, run.py:261 skipped) - on the real class: the single-pass fused kernel against the reference."""

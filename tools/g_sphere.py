@@ -32,25 +32,20 @@ import reference_cases as rc  # noqa: E402
 from oracle import reference  # noqa: E402
 
 
-def main():
-    iters = int(sys.argv[1]) if len(sys.argv) > 1 else 300
-    batch = int(sys.argv[2]) if len(sys.argv) > 2 else 8
-    dev = torch.device('cuda:0')
+GEOMETRY = 'p3d'
+
+
+def pretrained_state(dev, iters, batch, curve=None):
+    """run.py:824-866 on the attached model: `iters` Adam(lr_g) steps on all generator parameters, loss = sdf_distance_loss +
+    0.1 sdf_eikonal_loss against the unit sphere, fresh z every step.  Returns the state dict."""
     import nerf_from_image_amd.generator as nfi_gen
-    from nerf_from_image_amd import ops
-    g = rc.GEOMETRY['p3d']
+    g = rc.GEOMETRY[GEOMETRY]
     m = reference.modules()
     torch.manual_seed(1234)
     gen = m.generator.Generator(512, g['scene_range'], attention_values=10, use_sdf=True, disable_stylegan_noise=True).to(dev)
-    rep = {'iterations': iters, 'batch': batch, 'geometry': 'p3d_car-like: scene_range 1.4, camera distance 2, focal 1, black background'}
-
-    # ---- run.py:824-866 on the attached model ----
     model = nfi_gen.attach(gen, hip_regularisers=True, fused_handoff=True).train().requires_grad_(True)
     opt = torch.optim.Adam(model.parameters(), lr=0.0025)
     gz = torch.Generator(device=dev).manual_seed(7)
-    curve = []
-    torch.cuda.synchronize()
-    t0 = time.time()
     for i in range(iters):
         z = torch.randn((batch, 512), device=dev, generator=gz)
         losses = model(None, z, ['sdf_distance_loss', 'sdf_eikonal_loss'])
@@ -58,13 +53,17 @@ def main():
         (loss_dist + 0.1 * loss_eik).backward()
         opt.step()
         opt.zero_grad(set_to_none=True)
-        if i % 50 == 0 or i == iters - 1:
+        if curve is not None and (i % 50 == 0 or i == iters - 1):
             curve.append({'iteration': i, 'sdf_distance_loss': float(loss_dist), 'sdf_eikonal_loss': float(loss_eik)})
-    torch.cuda.synchronize()
-    rep['pretrain'] = {'seconds': time.time() - t0, 'curve': curve}
-    state = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    return {k: v.detach().clone() for k, v in model.state_dict().items()}
 
-    # ---- the pretrained weights in an UNTOUCHED reference Generator and in its attached twin ----
+
+def scene_from_state(state, dev, batch):
+    """The pretrained weights in an UNTOUCHED reference Generator and in its attached twin, p3d_car-like cameras: a
+    tests/reference_cases.py scene namespace."""
+    import nerf_from_image_amd.generator as nfi_gen
+    g = rc.GEOMETRY[GEOMETRY]
+    m = reference.modules()
     ref_gen = m.generator.Generator(512, g['scene_range'], attention_values=10, use_sdf=True, disable_stylegan_noise=True).to(dev)
     ref_gen.load_state_dict(state)
     with torch.no_grad():
@@ -77,9 +76,26 @@ def main():
         ws = ref_gen.mapping_network(z, None)
     cam = rc.cameras(batch, g['radius'], cpu).to(dev)
     focal = torch.full((batch,), g['focal']).to(dev)
-    sc = types.SimpleNamespace(geometry='p3d', g=g, gen=ref_gen, hip=nfi_gen.attach(copy.deepcopy(ref_gen)), z=z, ws=ws, cam=cam,
-                               focal=focal, bbox=None, args=reference.render_args(), batch=batch, dev=dev,
-                               dcfg={'scene_range': g['scene_range'], 'white_background': False})
+    return types.SimpleNamespace(geometry=GEOMETRY, g=g, gen=ref_gen, hip=nfi_gen.attach(copy.deepcopy(ref_gen)), z=z, ws=ws, cam=cam,
+                                 focal=focal, bbox=None, args=reference.render_args(), batch=batch, dev=dev,
+                                 dcfg={'scene_range': g['scene_range'], 'white_background': False})
+
+
+def main():
+    iters = int(sys.argv[1]) if len(sys.argv) > 1 else 300
+    batch = int(sys.argv[2]) if len(sys.argv) > 2 else 8
+    dev = torch.device('cuda:0')
+    from nerf_from_image_amd import ops
+    g = rc.GEOMETRY[GEOMETRY]
+    rep = {'iterations': iters, 'batch': batch, 'geometry': 'p3d_car-like: scene_range 1.4, camera distance 2, focal 1, black background'}
+    curve = []
+    torch.cuda.synchronize()
+    t0 = time.time()
+    state = pretrained_state(dev, iters, batch, curve)
+    torch.cuda.synchronize()
+    rep['pretrain'] = {'seconds': time.time() - t0, 'curve': curve}
+    sc = scene_from_state(state, dev, batch)
+    ref_gen, ws, cam, focal = sc.gen, sc.ws, sc.cam, sc.focal
     par = rc.compare(sc, 128, 64, cpu_images=1)
     rep['parity_vs_the_reference'] = {k: par[k] for k in ('mask_mean', 'vs_reference_gpu', 'vs_reference_cpu', 'reference_cpu_vs_gpu_gap',
                                                           'pixels_over_1e-4_vs_reference_gpu')}
