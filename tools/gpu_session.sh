@@ -17,7 +17,7 @@ for w in $WHAT; do
     tests)
       timeout 1500 python -m pytest tests -m gpu -q --durations=15 > $O/pytest.log 2>&1; echo "pytest rc=$?" >> $O/env.txt; tail -5 $O/pytest.log;;
     sweep)
-      timeout 1500 python tools/parity_sweep.py 10 > $O/parity_sweep.json 2> $O/parity_sweep.err; echo "sweep rc=$?" >> $O/env.txt; tail -3 $O/parity_sweep.err; tail -c 1500 $O/parity_sweep.json;;
+      timeout 1500 python tools/parity_sweep.py 10 $SWEEP_ONLY $SWEEP_CPU_ALL > $O/parity_sweep.json 2> $O/parity_sweep.err; echo "sweep rc=$?" >> $O/env.txt; tail -3 $O/parity_sweep.err; tail -c 1500 $O/parity_sweep.json;;
     gsphere)
       timeout 900 python tools/g_sphere.py 300 8 > $O/g_sphere.json 2> $O/g_sphere.err; echo "gsphere rc=$?" >> $O/env.txt; tail -3 $O/g_sphere.err; tail -c 2500 $O/g_sphere.json;;
     gradspread)
