@@ -24,6 +24,8 @@ GEOMETRY = {
     # the generator's OTHER branches on the chairs cameras: NeRF density softplus(d - 1) instead of the SDF
     # (models/generator.py:637-641) and the direct colour head wide_sigmoid_rescaled(features), A = 0 (665-666)
     'density': dict(scene_range=0.55, white=True, radius=2.0, focal=1.0254, bbox=False, use_sdf=False, attention_values=0),
+    # --use_class (class-conditional data sets): Generator(num_classes=...) with model_input = (z, labels) (generator.py:428-446)
+    'classes': dict(scene_range=0.55, white=True, radius=2.0, focal=1.0254, bbox=False, num_classes=5),
 }
 
 
@@ -61,8 +63,9 @@ def build_scene(geometry, batch, dev, seed=1234, alpha=0.05, beta=0.1, fine_samp
     vd = bool(g.get('viewdir'))
     use_sdf, n_att = bool(g.get('use_sdf', True)), int(g.get('attention_values', 10))
     torch.manual_seed(seed)
+    n_cls = g.get('num_classes')
     gen = m.generator.Generator(512, g['scene_range'], attention_values=n_att, use_viewdir=vd, use_sdf=use_sdf,
-                                disable_stylegan_noise=True)
+                                disable_stylegan_noise=True, num_classes=n_cls)
     cpu = torch.Generator().manual_seed(seed + 1)
     with torch.no_grad():
         if use_sdf:
@@ -75,8 +78,9 @@ def build_scene(geometry, batch, dev, seed=1234, alpha=0.05, beta=0.1, fine_samp
             gen.viewdir_mapper.output.bias.copy_(0.1 * torch.randn(gen.viewdir_mapper.output.bias.shape, generator=cpu))
     gen = gen.to(dev).eval().requires_grad_(False)
     z = torch.randn(batch, 512, generator=cpu).to(dev)
+    labels = torch.randint(n_cls, (batch,), generator=cpu).to(dev) if n_cls else None
     with torch.no_grad():
-        ws = gen.mapping_network(z, None)
+        ws = gen.mapping_network(z, gen.class_embedding(labels) if n_cls else None)
         # centre the distance output: shift its bias by the lower quartile of the SDF over the cube (all scenes of the
         # batch): a quarter of the volume is inside a surface
         pts = ((torch.rand(batch, 20000, 3, generator=cpu) * 2 - 1) * g['scene_range']).to(dev)
@@ -101,7 +105,7 @@ def build_scene(geometry, batch, dev, seed=1234, alpha=0.05, beta=0.1, fine_samp
     args = reference.render_args(fine_sampling=fine_sampling, use_sdf=use_sdf, attention_values=n_att, use_viewdir=vd)
     dcfg = {'scene_range': g['scene_range'], 'white_background': g['white']}
     return types.SimpleNamespace(geometry=geometry, g=g, gen=gen, hip=hip, z=z, ws=ws, cam=cam, focal=focal, bbox=bbox,
-                                 args=args, dcfg=dcfg, batch=batch, dev=dev)
+                                 args=args, dcfg=dcfg, batch=batch, dev=dev, labels=labels)
 
 
 class ReplayNoise:

@@ -90,6 +90,24 @@ def test_sphere_pretrained_generator_matches_the_real_reference(gpu_device):
     assert rep['mask_mean'] > 0.9 and max(rep['pixels_over_1e-4_vs_reference_gpu'].values()) <= 2, rep
 
 
+def test_class_conditional_generator_takes_z_and_labels(gpu_device):
+    """--use_class: `Generator(num_classes=...)` called with model_input = (z, labels) (models/generator.py:428-446: class
+    embedding, conditional mapping network) - the attached forward hands the tuple to the reference's own latent handling;
+    against the untouched Generator + reference render on this GPU, and with the latents ws given instead."""
+    _require_reference()
+    sc = rc.build_scene('classes', 4, gpu_device)
+    assert sc.gen.num_classes == 5 and sc.labels is not None
+    rep_ws = rc.compare(sc, 128, 64, cpu_images=1)
+    _check(rep_ws)
+    import copy
+    tup = copy.copy(sc)
+    tup.ws = (sc.z, sc.labels)                    # what run.py passes in the class-conditional training / eval loops
+    rep = rc.compare(tup, 128, 64, cpu_images=0)
+    for k in ('rgb', 'depth', 'mask'):
+        assert rep['vs_reference_gpu'][k] <= rep_ws['reference_cpu_vs_gpu_gap'][k] + BUDGET, (k, rep)
+        assert abs(rep['vs_reference_gpu'][k] - rep_ws['vs_reference_gpu'][k]) <= 1e-6, (k, rep, rep_ws)   # the same render
+
+
 def test_cfg1_shape_coarse_only_matches_the_real_reference(gpu_device):
     """BASELINE cfg1's shape - 4 scenes, 64 x 64 rays, 32 coarse samples, no fine pass (`--fine_sampling` off: ONE stratified
     draw, no resampling, run.py:261 skipped) - on the real class: the single-pass fused kernel against the reference."""
