@@ -224,11 +224,18 @@ def reference_render(sc, res, samples, noise, device=None, images=None, grad=Fal
     nz = None if noise is None else [noise[0][sl]] + [n.view(sc.batch, -1, samples)[sl].reshape(-1, samples) for n in noise[1:]]
     ctx = contextlib.nullcontext()
     extra_in = dict(render_kw.pop('extra_model_inputs', {}))
+    if images is not None and (device is None or torch.device(device) == cam.device):
+        extra_in = {k: v[sl] for k, v in extra_in.items()}
     if device is not None and torch.device(device) != cam.device:
         with torch.no_grad():
             planes = sc.gen.synthesis_network(ws[:, :14]).cpu()
             if sc.gen.attention_values > 0:
-                extra_in = dict(extra_in, attention_values=_attention(sc.gen, ws).cpu())
+                # the colour table the GPU model ends up with under the caller's model inputs (override / bias), as the
+                # CPU copy's override
+                given = {k: v[sl] for k, v in extra_in.items()}
+                extra_in = {'attention_values': sc.gen(None, ws, ['attention_values', 'sampler'], given)['attention_values'].cpu()}
+            else:
+                extra_in = {k: v[sl].to(device) for k, v in extra_in.items()}
         gen = copy.deepcopy(sc.gen).to(device)
         ws, cam, focal, bbox = ws.to(device), cam.to(device), pick_to(focal, device), pick_to(bbox, device)
         ctx = frozen_producer(gen, planes)

@@ -178,6 +178,13 @@ def test_extra_maps_match_the_real_reference(gpu_device):
     _check(rep, ('rgb', 'depth', 'mask', 'extra'))
     rep = rc.compare(sc, 128, 64, cpu_images=1, compute_coords=True)
     _check(rep, ('rgb', 'depth', 'mask', 'extra'))
+    # `extra_model_inputs` of Generator.forward (generator.py:419-421, 452-464): the caller's own colour table, and a bias
+    # on the texture mapper's - the attached forward leaves both to the reference's code and takes the table it returns
+    g = torch.Generator().manual_seed(3)
+    table = (torch.rand(4, 10, 3, generator=g) * 2 - 1).to(gpu_device)
+    for inputs in ({'attention_values': table}, {'attention_values_bias': 0.3 * table}):
+        rep = rc.compare(sc, 128, 64, cpu_images=1, compute_semantics=True, extra_model_inputs=inputs)
+        _check(rep, ('rgb', 'depth', 'mask', 'extra'))
 
 
 def test_normal_map_matches_the_real_reference(gpu_device):
@@ -263,6 +270,34 @@ def test_gradients_match_the_real_reference(gpu_device, geometry):
     # the whole graph in float64 (producer included): both fp32 implementations carry the producer's rounding
     for k in ('g_ws', 'g_planes'):
         assert rep['hip_vs_float64'][k] <= 2.5 * rep['reference_vs_float64'][k] + 1e-5, (k, rep)
+
+
+def test_force_no_cam_grad_matches_the_real_reference(gpu_device):
+    """`force_no_cam_grad=True` (run.py:211-214; the eval renders and --no_optimize_pose inversion, run.py:1262, 2045,
+    2274): query points, depths and ray directions are detached - the camera leaves get NO gradient in either
+    implementation, the latents' gradient is the same as the reference's."""
+    _require_reference()
+    import copy
+    with rc.deterministic_producer():
+        sc = rc.build_scene('p3d', 2, gpu_device)
+        noise = rc.draw_noise(sc, 128, 64)
+        gw = torch.Generator(device=gpu_device).manual_seed(5)
+        w_rgb = torch.randn((2, 128, 128, 3), device=gpu_device, generator=gw)
+        grads = {}
+        for which in ('hip', 'ref'):
+            ws = sc.ws.detach().clone().requires_grad_()
+            cam, focal = sc.cam.detach().clone().requires_grad_(), sc.focal.detach().clone().requires_grad_()
+            if which == 'hip':
+                out = rc.hip_render(sc, 128, 64, noise, grad=True, ws=ws, cam=cam, focal=focal, force_no_cam_grad=True)
+            else:
+                twin = copy.copy(sc)
+                twin.ws, twin.cam, twin.focal = ws, cam, focal
+                out = rc.reference_render(twin, 128, 64, noise, grad=True, force_no_cam_grad=True)
+            ((out[0] * w_rgb).sum() + out[2].sum()).backward()
+            assert cam.grad is None or float(cam.grad.abs().max()) == 0.0, which
+            assert focal.grad is None or float(focal.grad.abs().max()) == 0.0, which
+            grads[which] = ws.grad
+    assert rc.rel_err(grads['hip'], grads['ref']) <= 3 * LATENTS_MEASURED, rc.rel_err(grads['hip'], grads['ref'])
 
 
 def test_inversion_steps_match_the_real_reference(gpu_device):
