@@ -139,18 +139,25 @@ def _render_with_stash(fused, height, width, S, cam, focal, bbox, center, noise_
         g_rgb = zeros_like_or(grads[0], out_meta[0])
         g_mask = None if grads[2] is None else grads[2].contiguous()
         st_t, rd = keep['stash_t'], keep['ray_directions']
+        full = cam_grad is True
         cb = ops.composite_bwd_stash(rd, st_t, keep['stash_sigma'], keep['stash_rgb'], g_rgb, g_mask,
-                                     white_background=bool(white), want_rd=cam_grad, fine=fine)
+                                     white_background=bool(white), want_rd=full, fine=fine)
         pts = ops.points_on_rays(keep['ray_origins'], rd, st_t).view(B, -1, 3)
         viewdir = dict(ray_features=fused.ray_features, samples_per_ray=n_list, w3=inputs[11]) if vd else None
         g = field_query_bwd(pts, texels, image, a_w1, a_w2, scene_range, A, att, use_sdf, be, al,
-                            cb['g_sigma'].view(B, -1), cb['g_rgb'].view(B, -1, 3), want_points=cam_grad,
+                            cb['g_sigma'].view(B, -1), cb['g_rgb'].view(B, -1, 3), want_points=bool(cam_grad),
                             viewdir=viewdir, ray_order=(n_list, width))
         g_cam = g_focal = None
-        if cam_grad:
+        if full:
             g_ro, g_rd = ops.points_bwd(g['g_points'].view(*st_t.shape, 3), st_t)
             g_rd = g_rd + cb['g_ray_directions']
             g_cam, g_focal = ops.raygen_bwd(height, width, a_focal, a_cam, bbox, center, True, g_ro, g_rd)
+        elif cam_grad == 'fine_origins':
+            # force_no_cam_grad: only the origins of the FINE samples (stash columns S ...) are attached in the reference
+            g_pts = g['g_points'].view(*st_t.shape, 3).clone()
+            g_pts[..., :S, :] = 0.0
+            g_ro, _ = ops.points_bwd(g_pts, st_t, want_rd=False)
+            g_cam, _ = ops.raygen_bwd(height, width, a_focal, a_cam, bbox, center, True, g_ro, None)
         g_planes = ops.texel_grad_to_planes(g['g_texels']) if needs[2] else None
         base = (g_cam, g_focal, g_planes, g['g_w1'], g['g_b1'], g['g_w2'], g['g_b2'], g.get('g_attention_values'),
                 g.get('g_beta'), g.get('g_alpha'))
@@ -159,7 +166,7 @@ def _render_with_stash(fused, height, width, S, cam, focal, bbox, center, noise_
         return base + (g['g_ray_features'].reshape(inputs[10].shape), g['g_w3'], g['g_b3'])
 
     cam_in = cam if cam_grad else cam.detach()
-    focal_in = focal if (cam_grad or focal is None) else focal.detach()
+    focal_in = focal if (cam_grad is True or focal is None) else focal.detach()
     extra_in = tuple(fused.decoder_params[4:7]) if vd else ()          # (ray_feature [B,H,W,1,32], w3, b3)
     res = differentiable('render', fwd, cam_in, focal_in, fused.planes, w1, b1, w2, b2,
                          fused.attention_values if A > 0 else None, fused.beta if use_sdf else None,
@@ -185,6 +192,12 @@ def _render(cfg, dcfg, opts, target_model, height, width, tform_cam2world, focal
     dev = tform_cam2world.device
     plain = not (compute_normals or compute_semantics or compute_coords)
     cam_grad = (not force_no_cam_grad) and _needs_grad(tform_cam2world, focal_length, bbox, center)
+    if force_no_cam_grad and cfg.fine_sampling and _needs_grad(tform_cam2world, bbox, center):
+        # run.py:211-214 detaches the COARSE query points, the depths and the ray directions - and then builds the fine pass's
+        # points from the undetached ray origins (run.py:286-288): a camera that requires grad still receives
+        # d loss / d origin of the fine samples (its translation; with an orthographic camera also its rotation).
+        # Reproduced as is.
+        cam_grad = "fine_origins"
     rows = height if opts.row_window is None else int(opts.row_window[1])
 
     # Order of the random draws as in the reference: the stratified jitter (rand_like inside
@@ -306,9 +319,9 @@ def _render(cfg, dcfg, opts, target_model, height, width, tform_cam2world, focal
                 u = torch.linspace(0.0, 1.0, steps=S, dtype=torch.float32, device=dev).expand(B * height * width, S)
             z_samples, _ = ops.resample(sigma.detach(), ray_directions.detach(), depth_values.detach(), u)
             z_samples = z_samples.view(*depth_values.shape[:3], S)
+        # (force_no_cam_grad: the directions are detached above, the ORIGINS are not - run.py:286-288 builds the fine points from
+        #  them as they are, so their gradient reaches the camera)
         query_fine = nerf_utils.points_on_rays(ray_origins, ray_directions, z_samples)
-        if force_no_cam_grad:
-            query_fine = query_fine.detach()
         sigma_f, rgb_f, normals_f, semantics_f, coords_f = unpack(sampler(query_fine, req, **hip_kw))
         extra_f = coords_f if coords_f is not None else semantics_f
         rgb_map, depth_map, mask, normal_map, extra_map = nerf_utils.merge_and_composite(

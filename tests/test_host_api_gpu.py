@@ -247,7 +247,7 @@ def test_render_dropin_coords_and_force_no_cam_grad(setup):
                        attention_values=cpu(att), want_coords=True)
     close(rgb, o['rgb'], 1e-4, 'rgb'); close(mask, o['mask'], 1e-4, 'mask')
     close(coords_map, o['semantics'], 1e-5, 'composited coordinates')
-    # gradients: with force_no_cam_grad the camera and focal length get none, the latent does
+    # gradients: with force_no_cam_grad the focal length and the camera's rotation get none, the latent does
     cam_g, focal_g, z_g = cam.clone().requires_grad_(), focal.clone().requires_grad_(), z.clone().requires_grad_()
     draws = iter(tap.draws)
     real_rand = torch.rand
@@ -258,7 +258,10 @@ def test_render_dropin_coords_and_force_no_cam_grad(setup):
         torch.rand = real_rand
     close(rgb2, o['rgb'], 1e-4, 'rgb (force_no_cam_grad)')
     g_cam, g_focal, g_z = torch.autograd.grad(rgb2.sum() + mask2.sum(), [cam_g, focal_g, z_g], allow_unused=True)
-    assert g_cam is None and g_focal is None
+    # (the focal length gets none; the camera's TRANSLATION does - the reference builds the fine pass's points from the
+    #  undetached ray origins, run.py:286-288 - its rotation does not)
+    assert g_focal is None or float(g_focal.abs().max()) == 0.0
+    assert g_cam is not None and float(g_cam[:, :3, :3].abs().max()) == 0.0 and float(g_cam[:, :3, 3].abs().max()) > 0.0
     assert g_z is not None and torch.isfinite(g_z).all() and g_z.abs().sum() > 0
     # and without it the camera does get one
     draws = iter(tap.draws)

@@ -243,6 +243,9 @@ GRADIENT_MEASURED = {
 # every sample, summed over an image under a crop box with ~1000 : 1 cancellation; absolute: 2.8e-4 ... 6.6e-4 of the
 # gradient's norm, the fp32 reference 7e-5 ... 3e-4)
 FLOAT64_RATIO = dict(g_planes=2.5, g_cam=2.5, g_focal=6.0)
+# ... + a floor below which a ratio of two such distances says nothing (seen: camera 4.9e-5 against 1.4e-5 in one session,
+# 3.9e-5 against 6.0e-4 in another)
+FLOAT64_FLOOR = dict(g_planes=1e-5, g_cam=1e-4, g_focal=1e-4)
 
 
 @pytest.mark.parametrize('geometry', ['chairs', 'p3d', 'cub', 'carla', 'density'])
@@ -266,7 +269,7 @@ def test_gradients_match_the_real_reference(gpu_device, geometry):
         assert rep[k] <= 3.0 * measured + 1e-6, (k, rep[k], 'measured', measured, rep)
     ours, theirs = rep['renderer_only_hip_vs_float64'], rep['renderer_only_reference_vs_float64']
     for k in ours:
-        assert ours[k] <= FLOAT64_RATIO[k] * theirs[k] + 1e-5, (k, 'vs float64: HIP', ours[k], 'fp32 reference', theirs[k], rep)
+        assert ours[k] <= FLOAT64_RATIO[k] * theirs[k] + FLOAT64_FLOOR[k], (k, 'vs float64: HIP', ours[k], 'fp32 reference', theirs[k], rep)
     # the whole graph in float64 (producer included): both fp32 implementations carry the producer's rounding
     for k in ('g_ws', 'g_planes'):
         assert rep['hip_vs_float64'][k] <= 2.5 * rep['reference_vs_float64'][k] + 1e-5, (k, rep)
@@ -274,8 +277,10 @@ def test_gradients_match_the_real_reference(gpu_device, geometry):
 
 def test_force_no_cam_grad_matches_the_real_reference(gpu_device):
     """`force_no_cam_grad=True` (run.py:211-214; the eval renders and --no_optimize_pose inversion, run.py:1262, 2045,
-    2274): query points, depths and ray directions are detached - the camera leaves get NO gradient in either
-    implementation, the latents' gradient is the same as the reference's."""
+    2274): the coarse query points, the depths and the ray directions are detached - but run.py:286-288 builds the FINE
+    pass's points from the undetached ray origins, so a camera that requires grad still receives the gradient of the fine
+    samples' origins (its translation column), and the focal length none.  The drop-in reproduces exactly that; the
+    latents' gradient is the reference's."""
     _require_reference()
     import copy
     with rc.deterministic_producer():
@@ -294,10 +299,13 @@ def test_force_no_cam_grad_matches_the_real_reference(gpu_device):
                 twin.ws, twin.cam, twin.focal = ws, cam, focal
                 out = rc.reference_render(twin, 128, 64, noise, grad=True, force_no_cam_grad=True)
             ((out[0] * w_rgb).sum() + out[2].sum()).backward()
-            assert cam.grad is None or float(cam.grad.abs().max()) == 0.0, which
             assert focal.grad is None or float(focal.grad.abs().max()) == 0.0, which
-            grads[which] = ws.grad
-    assert rc.rel_err(grads['hip'], grads['ref']) <= 3 * LATENTS_MEASURED, rc.rel_err(grads['hip'], grads['ref'])
+            assert cam.grad is not None and float(cam.grad[:, :3, :3].abs().max()) == 0.0, which     # rotation: nothing
+            assert float(cam.grad[:, :3, 3].abs().max()) > 0.0, which                                   # translation: the fine origins
+            grads[which] = (ws.grad, cam.grad[:, :3, 3])
+    assert rc.rel_err(grads['hip'][0], grads['ref'][0]) <= 3 * LATENTS_MEASURED, rc.rel_err(grads['hip'][0], grads['ref'][0])
+    # (the camera figure is a sum over the image like GRADIENT_MEASURED['p3d']['g_cam'], 5.3e-4)
+    assert rc.rel_err(grads['hip'][1], grads['ref'][1]) <= 3 * 5.3e-4, rc.rel_err(grads['hip'][1], grads['ref'][1])
 
 
 def test_inversion_steps_match_the_real_reference(gpu_device):
