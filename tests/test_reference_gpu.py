@@ -105,7 +105,7 @@ def test_class_conditional_generator_takes_z_and_labels(gpu_device):
     rep = rc.compare(tup, 128, 64, cpu_images=0)
     for k in ('rgb', 'depth', 'mask'):
         assert rep['vs_reference_gpu'][k] <= rep_ws['reference_cpu_vs_gpu_gap'][k] + BUDGET, (k, rep)
-        assert abs(rep['vs_reference_gpu'][k] - rep_ws['vs_reference_gpu'][k]) <= 1e-6, (k, rep, rep_ws)   # the same render
+        assert abs(rep['vs_reference_gpu'][k] - rep_ws['vs_reference_gpu'][k]) <= 1e-5, (k, rep, rep_ws)   # the same render
 
 
 def test_cfg1_shape_coarse_only_matches_the_real_reference(gpu_device):
