@@ -26,6 +26,8 @@ GEOMETRY = {
     'density': dict(scene_range=0.55, white=True, radius=2.0, focal=1.0254, bbox=False, use_sdf=False, attention_values=0),
     # --use_class (class-conditional data sets): Generator(num_classes=...) with model_input = (z, labels) (generator.py:428-446)
     'classes': dict(scene_range=0.55, white=True, radius=2.0, focal=1.0254, bbox=False, num_classes=5),
+    # cub with the crop box its loader passes (orthographic branch of get_ray_bundle WITH bbox, lib/nerf_utils.py:72-77)
+    'cub_bbox': dict(scene_range=2.0, white=False, radius=3.0, focal=None, bbox=True),
 }
 
 
@@ -53,7 +55,7 @@ def crop_boxes(n, gen):
     return torch.stack([start, size.expand(n, 2)], dim=1).contiguous()
 
 
-def build_scene(geometry, batch, dev, seed=1234, alpha=0.05, beta=0.1, fine_sampling=True):
+def build_scene(geometry, batch, dev, seed=1234, alpha=0.05, beta=0.1, fine_sampling=True, stylegan_noise=False):
     """A default-initialised reference Generator with its SDF centred so that it renders surfaces (a random-init
     generator renders an almost empty scene: SURVEY.md 8(d)), its twin with the HIP sampler attached, and seeded
     cameras / latents.  Returns a namespace."""
@@ -65,7 +67,7 @@ def build_scene(geometry, batch, dev, seed=1234, alpha=0.05, beta=0.1, fine_samp
     torch.manual_seed(seed)
     n_cls = g.get('num_classes')
     gen = m.generator.Generator(512, g['scene_range'], attention_values=n_att, use_viewdir=vd, use_sdf=use_sdf,
-                                disable_stylegan_noise=True, num_classes=n_cls)
+                                disable_stylegan_noise=not stylegan_noise, num_classes=n_cls)
     cpu = torch.Generator().manual_seed(seed + 1)
     with torch.no_grad():
         if use_sdf:

@@ -108,6 +108,50 @@ def test_class_conditional_generator_takes_z_and_labels(gpu_device):
         assert abs(rep['vs_reference_gpu'][k] - rep_ws['vs_reference_gpu'][k]) <= 1e-5, (k, rep, rep_ws)   # the same render
 
 
+def test_more_call_patterns_of_render_match_the_real_reference(gpu_device):
+    """Call patterns of run.py::render / Generator.forward beyond the BASELINE configurations, each against the untouched
+    reference on this GPU (and its CPU path): the orthographic camera WITH a crop box (cub's loader passes one), deterministic
+    sampling (`randomize=False`: no stratified jitter, linspace in sample_pdf), `extra_model_outputs=['attention_values']`
+    (slot 5 of the tuple), the 'bbox' visualisation overlay (generator.py:645-659, needs compute_coords), the normal and
+    semantic maps of the first eval batch together (run.py:2036-2051)."""
+    _require_reference()
+    sc = rc.build_scene('cub_bbox', 4, gpu_device)
+    _check(rc.compare(sc, 128, 64, cpu_images=1))
+    _check(rc.compare(sc, 128, 64, cpu_images=1, randomize=False))
+    sc = rc.build_scene('p3d', 2, gpu_device)
+    noise = rc.draw_noise(sc, 64, 32)
+    ours = rc.hip_render(sc, 64, 32, noise, extra_model_outputs=['attention_values'])
+    ref = rc.reference_render(sc, 64, 32, noise, extra_model_outputs=['attention_values'])
+    assert set(ours[5]) == set(ref[5]) == {'attention_values'} and torch.equal(ours[5]['attention_values'], ref[5]['attention_values'])
+    rep = rc.compare(sc, 64, 32, cpu_images=1, compute_coords=True, extra_model_outputs=['bbox'])
+    _check(rep, ('rgb', 'depth', 'mask', 'extra'))
+    sc = rc.build_scene('chairs', 2, gpu_device)
+    rep = rc.compare(sc, 64, 32, cpu_images=1, grad=True, compute_normals=True, compute_semantics=True)
+    _check(rep, ('rgb', 'depth', 'mask', 'extra'))
+    assert rep['vs_reference_cpu']['normals'] <= 3e-3, rep
+
+
+def test_stylegan_noise_draws_interleave_like_the_reference(gpu_device):
+    """A generator WITH per-layer StyleGAN2 noise (`disable_stylegan_noise=False`, the training default): after the same
+    torch.manual_seed the drop-in must consume PyTorch's Philox stream in the reference's order - stratified jitter
+    (nerf_utils.py:115) BEFORE the model is called, the synthesis network's randn draws inside it, the inverse-CDF draw
+    (nerf_utils.py:202) after it - or every layer's noise, and with it every plane, differs."""
+    _require_reference()
+    sc = rc.build_scene('chairs', 2, gpu_device, stylegan_noise=True)
+    for mod in (sc.gen, sc.hip):
+        mod.train()                                  # (noise_mode 'random' draws; eval would draw too: use_noise is the switch)
+    torch.manual_seed(777)
+    ours = rc.hip_render(sc, 128, 64, None)
+    torch.manual_seed(777)
+    ref = rc.reference_render(sc, 128, 64, None)
+    torch.manual_seed(778)
+    other = rc.reference_render(sc, 128, 64, None)
+    assert rc.max_err(ref[0], other[0]) > 1e-2           # the noise matters: another seed, another image
+    for k, a, b in zip(('rgb', 'depth', 'mask'), ours[:3], ref[:3]):
+        over = int(((a - b).abs() > BUDGET).sum())
+        assert over <= 2 and rc.max_err(a, b) < 5e-3, (k, rc.max_err(a, b), over)
+
+
 def test_cfg1_shape_coarse_only_matches_the_real_reference(gpu_device):
     """BASELINE cfg1's shape - 4 scenes, 64 x 64 rays, 32 coarse samples, no fine pass (`--fine_sampling` off: ONE stratified
     draw, no resampling, run.py:261 skipped) - on the real class: the single-pass fused kernel against the reference."""
