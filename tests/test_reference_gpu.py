@@ -319,6 +319,24 @@ def test_gradients_match_the_real_reference(gpu_device, geometry):
         assert rep['hip_vs_float64'][k] <= 2.5 * rep['reference_vs_float64'][k] + 1e-5, (k, rep)
 
 
+@pytest.mark.parametrize('samples', [128, 256])
+def test_single_pass_render_and_gradients_match_the_real_reference(gpu_device, samples):
+    """`--fine_sampling` off: ONE pass of 128 samples (training) or 4 x 64 = 256 (`ray_multiplier=4` of the inversion loop,
+    run.py:2271) - the single-list fused kernels (render_fwd_wide / render_fwd_long) and their one-node backward against the
+    real reference: forward inside the budget, gradients (measured, one session: latents 1.3e-5, planes 2.0e-5 / 1.6e-5,
+    camera 8e-6 / 1.2e-5, focal 3e-6 / 1.1e-5; asserted at 3 x resp. the 1e-4 below which the image-wide sums say nothing)."""
+    _require_reference()
+    with rc.deterministic_producer():
+        sc = rc.build_scene('p3d', 2, gpu_device, fine_sampling=False)
+        _check(rc.compare(sc, 64, samples, cpu_images=1))
+        rep = rc.gradients(sc, 64, samples)
+    assert abs(rep['loss_hip'] - rep['loss_reference']) <= 1e-5 * abs(rep['loss_reference']), rep
+    assert rep['g_ws'] <= 3 * LATENTS_MEASURED and rep['g_planes'] <= 6.5e-5 and rep['g_cam'] <= 1e-4 and rep['g_focal'] <= 1e-4, rep
+    ours, theirs = rep['renderer_only_hip_vs_float64'], rep['renderer_only_reference_vs_float64']
+    for k in ours:
+        assert ours[k] <= FLOAT64_RATIO[k] * theirs[k] + FLOAT64_FLOOR[k], (k, ours[k], theirs[k], rep)
+
+
 def test_force_no_cam_grad_matches_the_real_reference(gpu_device):
     """`force_no_cam_grad=True` (run.py:211-214; the eval renders and --no_optimize_pose inversion, run.py:1262, 2045,
     2274): the coarse query points, the depths and the ray directions are detached - but run.py:286-288 builds the FINE
