@@ -358,15 +358,24 @@ def parallel_model(render_fn, model, resolution, samples):
     return env['ParallelModel'](resolution, model=model, model_ema=model)
 
 
-def gradients(sc, res, samples, seed=5, float64=True):
+def gradients(sc, res, samples, seed=5, float64=True, **render_kw):
     """Forward + backward of  sum(rgb * w_rgb) + sum(mask * w_mask)  w.r.t. the latents ws, the camera matrix and the
     focal length, in both implementations (same noise).  Returns relative L2 errors of the gradients: HIP against the
     fp32 reference, and (float64=True) HIP and the fp32 reference each against the reference run in FLOAT64 on the same
-    device (`as_double`) - the comparator that does not move from run to run."""
+    device (`as_double`) - the comparator that does not move from run to run.
+    render_kw (compute_semantics=True ...): passed to both renders; the extra map in slot 4 then joins the loss with random
+    weights of its own (the staged path WITH a gradient)."""
     noise = draw_noise(sc, res, samples)
     gw = torch.Generator(device=sc.dev).manual_seed(seed)
     w_rgb = torch.randn((sc.batch, res, res, 3), device=sc.dev, generator=gw)
     w_mask = torch.randn((sc.batch, res, res), device=sc.dev, generator=gw)
+    w_extra = torch.randn((sc.batch, res, res, 16), device=sc.dev, generator=gw)
+
+    def loss_of(out, cast=lambda t: t):
+        loss = (out[0] * cast(w_rgb)).sum() + (out[2] * cast(w_mask)).sum()
+        if out[4] is not None:
+            loss = loss + (out[4] * cast(w_extra[..., :out[4].shape[-1]])).sum()
+        return loss
 
     def leaves():
         ws = sc.ws.detach().clone().requires_grad_()
@@ -384,17 +393,17 @@ def gradients(sc, res, samples, seed=5, float64=True):
                 kept['planes'] = out
         if which == 'hip':
             h = sc.hip.synthesis_network.register_forward_hook(keep_planes)
-            out = hip_render(sc, res, samples, noise, grad=True, ws=ws, cam=cam, focal=focal)
-            loss = (out[0] * w_rgb).sum() + (out[2] * w_mask).sum()
+            out = hip_render(sc, res, samples, noise, grad=True, ws=ws, cam=cam, focal=focal, **render_kw)
+            loss = loss_of(out)
         elif which == 'ref':
             keep = sc.ws, sc.cam, sc.focal
             sc.ws, sc.cam, sc.focal = ws, cam, focal
             h = sc.gen.synthesis_network.register_forward_hook(keep_planes)
             try:
-                out = reference_render(sc, res, samples, noise, grad=True)
+                out = reference_render(sc, res, samples, noise, grad=True, **render_kw)
             finally:
                 sc.ws, sc.cam, sc.focal = keep
-            loss = (out[0] * w_rgb).sum() + (out[2] * w_mask).sum()
+            loss = loss_of(out)
         else:                              # the reference in float64: the deterministic ground truth
             sc64 = as_double(sc)
             sc64.gen.requires_grad_(False)
@@ -402,8 +411,8 @@ def gradients(sc, res, samples, seed=5, float64=True):
             focal = None if focal is None else focal.detach().double().requires_grad_()
             sc64.ws, sc64.cam, sc64.focal = ws, cam, focal
             h = sc64.gen.synthesis_network.register_forward_hook(keep_planes)
-            out = reference_render(sc64, res, samples, [n.double() for n in noise], grad=True)
-            loss = (out[0] * w_rgb.double()).sum() + (out[2] * w_mask.double()).sum()
+            out = reference_render(sc64, res, samples, [n.double() for n in noise], grad=True, **render_kw)
+            loss = loss_of(out, lambda t: t.double())
         h.remove()
         loss.backward()
         g_planes.append(kept['planes'].grad.detach().clone())
@@ -426,8 +435,8 @@ def gradients(sc, res, samples, seed=5, float64=True):
             with torch.no_grad():
                 extra = {'attention_values': _attention(sc.gen, sc.ws).double()}
         with frozen_producer(sc64.gen, planes):
-            out = reference_render(sc64, res, samples, [n.double() for n in noise], grad=True, extra_model_inputs=extra)
-        loss = (out[0] * w_rgb.double()).sum() + (out[2] * w_mask.double()).sum()
+            out = reference_render(sc64, res, samples, [n.double() for n in noise], grad=True, extra_model_inputs=extra, **render_kw)
+        loss = loss_of(out, lambda t: t.double())
         loss.backward()
         return planes.grad, cam.grad, None if focal is None else focal.grad
     g_planes, planes32 = [], []

@@ -337,6 +337,21 @@ def test_single_pass_render_and_gradients_match_the_real_reference(gpu_device, s
         assert ours[k] <= FLOAT64_RATIO[k] * theirs[k] + FLOAT64_FLOOR[k], (k, ours[k], theirs[k], rep)
 
 
+def test_semantic_map_gradient_matches_the_real_reference(gpu_device):
+    """`compute_semantics=True` WITH a gradient (the staged path: one launch per stage, every per-sample tensor an autograd
+    tensor): a loss on rgb, mask and the composited semantic map, gradients w.r.t. latents / planes / camera / focal against
+    the real reference (measured, one session: 5.9e-6 / 5.6e-5 / 8.2e-5 / 3.7e-5 - asserted against the p3d row of
+    GRADIENT_MEASURED, whose spread over the sessions is known)."""
+    _require_reference()
+    with rc.deterministic_producer():
+        sc = rc.build_scene('p3d', 2, gpu_device)
+        rep = rc.gradients(sc, 128, 64, compute_semantics=True)
+    assert abs(rep['loss_hip'] - rep['loss_reference']) <= 1e-5 * abs(rep['loss_reference']), rep
+    for k, measured in GRADIENT_MEASURED['p3d'].items():
+        measured = max(measured, LATENTS_MEASURED) if k == 'g_ws' else measured
+        assert rep[k] <= 3.0 * measured + 1e-6, (k, rep[k], rep)
+
+
 def test_force_no_cam_grad_matches_the_real_reference(gpu_device):
     """`force_no_cam_grad=True` (run.py:211-214; the eval renders and --no_optimize_pose inversion, run.py:1262, 2045,
     2274): the coarse query points, the depths and the ray directions are detached - but run.py:286-288 builds the FINE
