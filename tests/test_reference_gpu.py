@@ -129,6 +129,17 @@ def test_more_call_patterns_of_render_match_the_real_reference(gpu_device):
     rep = rc.compare(sc, 64, 32, cpu_images=1, grad=True, compute_normals=True, compute_semantics=True)
     _check(rep, ('rgb', 'depth', 'mask', 'extra'))
     assert rep['vs_reference_cpu']['normals'] <= 3e-3, rep
+    # error behaviour: a batch in which NO ray meets the scene cube - the reference fails on min() of an empty selection
+    # (lib/nerf_utils.py:258), the drop-in raises the same exception type
+    import copy
+    lost = copy.copy(sc)
+    lost.cam = sc.cam.clone()
+    lost.cam[:, :3, 3] += 10.0 * sc.cam[:, :3, 0]          # ten units sideways, same viewing direction
+    noise = rc.draw_noise(sc, 64, 32)
+    with pytest.raises(RuntimeError):
+        rc.reference_render(lost, 64, 32, noise)
+    with pytest.raises(RuntimeError, match='no ray intersects the scene cube'):
+        rc.hip_render(lost, 64, 32, noise)
 
 
 def test_stylegan_noise_draws_interleave_like_the_reference(gpu_device):
