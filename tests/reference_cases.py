@@ -616,11 +616,14 @@ def _summary(g_a, g_b):
     return {'all_parameters': (num / den) ** 0.5, 'worst_tensor': worst, 'worst_tensor_rel_l2': big[worst], 'significant_tensors': len(big)}
 
 
-def training_step(sc, res, samples, seed=77, reg_weight=0.1, float64=True, fused_handoff=False):
+def training_step(sc, res, samples, seed=77, reg_weight=0.1, float64=True, fused_handoff=False, one_forward=False):
     """One generator-side training step in cfg4's shape on the REAL Generator (training mode, latents through the mapping
     network): render + image / alpha loss (run.py:980-1010), regulariser forward (974-979, 1011-1028), one backward - the
     reference's own render + forward against the drop-in render + `attach(..., hip_regularisers=True)`, same noise and
-    seed.  Compares the loss and the gradient of EVERY generator parameter.  Returns a dict."""
+    seed.  Compares the loss and the gradient of EVERY generator parameter.  Returns a dict.
+    one_forward: the way run.py's G loop calls it (run.py:966-986): ONE Generator.forward inside render() serves the sampler AND
+    the regularisers (`extra_model_outputs=['sdf_eikonal_loss', 'total_variation_loss', 'entropy_loss']`); the forward's own
+    stratified volume draw (lib/ops.py sample_volume_stratified: rand_like) sits between render's two draws."""
     import nerf_from_image_amd.generator as nfi_gen
     import nerf_from_image_amd.render as nfi_render
     noise = draw_noise(sc, res, samples, seed=seed)
@@ -629,12 +632,26 @@ def training_step(sc, res, samples, seed=77, reg_weight=0.1, float64=True, fused
     t_mask = (torch.rand(sc.batch, res, res, generator=g) > 0.5).float().to(sc.dev)
     ref_render, _ = reference.load_render(sc.args, sc.dcfg, unscripted_stages=True)
     hip_render_fn = nfi_render.make_render(sc.args, sc.dcfg)
+    bins_noise = torch.rand((sc.batch, 31, 31, 31, 3), generator=g).to(sc.dev)      # sample_volume_stratified's draw (nstrata 32)
 
     def run(model, render_fn, double=False):
         model = model.train().requires_grad_(True)
         for p_ in model.parameters():
             p_.grad = None
         cast = (lambda t: None if t is None else t.double()) if double else (lambda t: t)
+        if one_forward:
+            names = ['sdf_eikonal_loss', 'total_variation_loss', 'entropy_loss']
+            draws = [cast(noise[0]), cast(bins_noise), cast(noise[1])]
+            torch.manual_seed(seed)                                     # (the total-variation perturbation: randn_like)
+            with ReplayNoise(draws), (default_dtype(torch.float64) if double else contextlib.nullcontext()), \
+                    (float32_draws_in_float64() if double else contextlib.nullcontext()):
+                out = render_fn(model, res, res, cast(sc.cam), cast(sc.focal), None, cast(sc.bbox), cast(sc.z), samples,
+                                extra_model_outputs=names)
+                loss = ((out[0] - cast(t_rgb)) ** 2).mean() + ((out[2] - cast(t_mask)) ** 2).mean()
+                loss = loss + reg_weight * (out[5]['sdf_eikonal_loss'].mean() + 5.0 * out[5]['total_variation_loss'].mean() +
+                                            0.1 * out[5]['entropy_loss'].mean())
+                loss.backward()
+            return float(loss.detach()), {n: p_.grad.detach().clone() for n, p_ in model.named_parameters() if p_.grad is not None}
         with ReplayNoise([cast(n) for n in noise]), (default_dtype(torch.float64) if double else contextlib.nullcontext()):
             out = render_fn(model, res, res, cast(sc.cam), cast(sc.focal), None, cast(sc.bbox), cast(sc.z), samples)
         loss = ((out[0] - cast(t_rgb)) ** 2).mean() + ((out[2] - cast(t_mask)) ** 2).mean()
