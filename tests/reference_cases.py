@@ -616,7 +616,8 @@ def _summary(g_a, g_b):
     return {'all_parameters': (num / den) ** 0.5, 'worst_tensor': worst, 'worst_tensor_rel_l2': big[worst], 'significant_tensors': len(big)}
 
 
-def training_step(sc, res, samples, seed=77, reg_weight=0.1, float64=True, fused_handoff=False, one_forward=False):
+def training_step(sc, res, samples, seed=77, reg_weight=0.1, float64=True, fused_handoff=False, one_forward=False,
+                  path_length=False):
     """One generator-side training step in cfg4's shape on the REAL Generator (training mode, latents through the mapping
     network): render + image / alpha loss (run.py:980-1010), regulariser forward (974-979, 1011-1028), one backward - the
     reference's own render + forward against the drop-in render + `attach(..., hip_regularisers=True)`, same noise and
@@ -640,7 +641,9 @@ def training_step(sc, res, samples, seed=77, reg_weight=0.1, float64=True, fused
             p_.grad = None
         cast = (lambda t: None if t is None else t.double()) if double else (lambda t: t)
         if one_forward:
-            names = ['sdf_eikonal_loss', 'total_variation_loss', 'entropy_loss']
+            # (+ the path-length regulariser of run.py:968-969, 1029-1043: a double backward through the synthesis network - the
+            #  attached forward runs the last block unfused for it)
+            names = ['sdf_eikonal_loss', 'total_variation_loss', 'entropy_loss'] + (['path_length'] if path_length else [])
             draws = [cast(noise[0]), cast(bins_noise), cast(noise[1])]
             torch.manual_seed(seed)                                     # (the total-variation perturbation: randn_like)
             with ReplayNoise(draws), (default_dtype(torch.float64) if double else contextlib.nullcontext()), \
@@ -650,6 +653,9 @@ def training_step(sc, res, samples, seed=77, reg_weight=0.1, float64=True, fused
                 loss = ((out[0] - cast(t_rgb)) ** 2).mean() + ((out[2] - cast(t_mask)) ** 2).mean()
                 loss = loss + reg_weight * (out[5]['sdf_eikonal_loss'].mean() + 5.0 * out[5]['total_variation_loss'].mean() +
                                             0.1 * out[5]['entropy_loss'].mean())
+                if path_length:
+                    ppl = out[5]['path_length']
+                    loss = loss + 2.0 * (ppl - ppl.mean().detach()).square().mean()
                 loss.backward()
             return float(loss.detach()), {n: p_.grad.detach().clone() for n, p_ in model.named_parameters() if p_.grad is not None}
         with ReplayNoise([cast(n) for n in noise]), (default_dtype(torch.float64) if double else contextlib.nullcontext()):

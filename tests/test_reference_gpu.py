@@ -436,8 +436,9 @@ def test_regulariser_branch_on_the_real_generator(gpu_device):
     assert rep['hip_vs_float64']['ws'] <= 1.5 * rep['reference_vs_float64']['ws'] + 1e-6, rep
 
 
-@pytest.mark.parametrize('fused_handoff,one_forward', [(False, False), (True, False), (True, True)])
-def test_generator_training_step_on_the_real_generator(gpu_device, fused_handoff, one_forward):
+@pytest.mark.parametrize('fused_handoff,one_forward,path_length', [(False, False, False), (True, False, False), (True, True, False),
+                                                                   (True, True, True)])
+def test_generator_training_step_on_the_real_generator(gpu_device, fused_handoff, one_forward, path_length):
     """BASELINE cfg4's generator step on the real class (cub-like: orthographic, scene_range 2.0, black background, 4 images
     x 128 x 128 x (64 + 64), model.train(), latents through the mapping network, image + alpha loss + eikonal / distance
     regularisers, ONE backward): the gradient of EVERY generator parameter - mapping network, StyleGAN2 synthesis, texture
@@ -450,7 +451,7 @@ def test_generator_training_step_on_the_real_generator(gpu_device, fused_handoff
         sc = rc.build_scene('cub', 4, gpu_device)
         # (one_forward: as run.py's G loop has it, 966-986 - ONE Generator.forward inside render() serves the sampler and the
         #  eikonal / total-variation / entropy regularisers, its volume draw between render's two noise draws)
-        rep = rc.training_step(sc, 128, 64, fused_handoff=fused_handoff, one_forward=one_forward)
+        rep = rc.training_step(sc, 128, 64, fused_handoff=fused_handoff, one_forward=one_forward, path_length=path_length)
     assert abs(rep['loss_hip'] - rep['loss_reference']) <= 1e-6 * abs(rep['loss_reference']), rep
     # (all parameters: 8.0e-6 in every session so far; most of them sit behind the producer's backward like the latents)
     assert rep['n_parameter_tensors'] > 100 and rep['grad_rel_l2_all_parameters'] <= 3 * LATENTS_MEASURED, rep
