@@ -133,10 +133,9 @@ def _composite(name, ray_directions, depth_a, sigma_a, rgb_a, depth_b, sigma_b, 
                extra_a, extra_b, white_background):
     """Shared body of render_volume_density (one list) and merge_and_composite (two lists)."""
     two = depth_b is not None
-    if torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in (normals_a, normals_b)):
-        # the reference composites normals with weights.detach() (lib/nerf_utils.py:146-147); the extras path of
-        # the backward kernel differentiates through the weights, which is right for semantics / coords only
-        raise NotImplementedError('normals that require grad are not supported (the sampler returns them detached)')
+    if two and torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in (normals_a, normals_b)):
+        raise NotImplementedError('merge_and_composite: normals that require grad are not supported (the sampler returns '
+                                  'them detached, models/generator.py:612-621)')
     ex_a = [t for t in (normals_a, extra_a) if t is not None]
     ex_b = [t for t in (normals_b, extra_b) if t is not None] if two else []
     n_norm = normals_a.shape[-1] if normals_a is not None else 0
@@ -165,9 +164,16 @@ def _composite(name, ray_directions, depth_a, sigma_a, rgb_a, depth_b, sigma_b, 
         rd, sa, ca, sb, cb, ea, eb = split(inputs)
         g_rgb = zeros_like_or(grads[0], outputs[0])
         g_mask = None if grads[2] is None else grads[2].contiguous()
-        g_ex = None
+        g_ex = g_normal_map = None
         if n_ex and len(grads) > 3 and grads[3] is not None:
             g_ex = grads[3].contiguous()
+            if n_norm:
+                # the reference composites normals with weights.detach() (lib/nerf_utils.py:146-147): what arrives on the
+                # normal channels must not reach sigma / the directions through the weights (the backward kernel's extras
+                # path differentiates through them, which is right for semantics / coords only)
+                g_normal_map = g_ex[..., :n_norm]
+                g_ex = g_ex.clone()
+                g_ex[..., :n_norm] = 0
         g = ops.composite_bwd(rd, da, sa, ca, g_rgb, g_mask, db, sb, cb, ea, eb, g_ex, white_background, want_rd=True)
         out = [g['g_ray_directions'], g['g_sigma_a'], g['g_rgb_a']]
         if two:
@@ -184,6 +190,9 @@ def _composite(name, ray_directions, depth_a, sigma_a, rgb_a, depth_b, sigma_b, 
             out += unsplit(g.get('g_extra_a'), ex_a)
             if two:
                 out += unsplit(g.get('g_extra_b'), ex_b)
+            elif n_norm and needs[3] and g_normal_map is not None:
+                # d normal_map / d normals = the (detached) weights; one list only (render_volume_density)
+                out[3] = ops.ray_weights(sa, rd, da)[..., None] * g_normal_map[..., None, :]
         return tuple(out)
 
     tensors = [ray_directions, sigma_a, rgb_a] + ([sigma_b, rgb_b] if two else []) + ex_a + ex_b

@@ -84,8 +84,12 @@ def make_render(new_args, new_dataset_config, **new_options):
     """A render function bound to its own args / dataset_config / options (multi-config processes, one per thread)."""
     opts = _options(new_options)
 
-    def bound(*a, **k):
-        return _render(new_args, new_dataset_config, opts, *a, **k)
+    def bound(target_model, height, width, tform_cam2world, focal_length, center, bbox, model_input,
+              depth_samples_per_ray, randomize=True, compute_normals=False, compute_semantics=False,
+              compute_coords=False, extra_model_outputs=[], extra_model_inputs={}, force_no_cam_grad=False):
+        return _render(new_args, new_dataset_config, opts, target_model, height, width, tform_cam2world, focal_length,
+                       center, bbox, model_input, depth_samples_per_ray, randomize, compute_normals, compute_semantics,
+                       compute_coords, extra_model_outputs, extra_model_inputs, force_no_cam_grad)
     bound.options = opts                 # (read by graphs.GraphedRender: a strict render cannot be captured)
     return bound
 
