@@ -151,3 +151,83 @@ def test_psnr_and_iou_against_reference_vectors(gpu_device):
         nfi_metrics.psnr(pred * 2, target)
     with pytest.raises(AssertionError):
         nfi_metrics.psnr(pred[:, :2], target[:, :2])          # not an RGB image
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('white', [False, True])
+def test_augment_against_the_live_reference_on_the_gpu(gpu_device, white):
+    """run.py::augment / augment_impl (run.py:720-817, AST-sliced) on PyTorch-ROCm against the drop-in on the same device under
+    the same seed: the inversion loop's call (15 augmentations of cat(prediction, target), run.py:2216-2225, with the
+    gradient back to the prediction) and the training loop's (image + pose + focal, run.py:937)."""
+    if REF is None:
+        pytest.skip('reference sources not staged (oracle/make_ref.py)')
+    import torch.nn.functional as F
+    import nerf_from_image_amd.augment as aug
+    cfg = types.SimpleNamespace(supervise_alpha=False), {'white_background': white}
+    env = reference.slice_functions('run.py', ['augment_impl', 'augment'],
+                                    {'torch': torch, 'np': np, 'F': F, 'pose_utils': reference.modules().pose_utils,
+                                     'args': cfg[0], 'dataset_config': cfg[1]})
+    aug.configure(*cfg)
+    g = torch.Generator(device=gpu_device).manual_seed(17)
+    cat = torch.rand((2, 6, 128, 128), device=gpu_device, generator=g) * 2 - 1
+    cot = torch.randn((30, 6, 128, 128), device=gpu_device, generator=g)
+    res = []
+    for fn in (env['augment'], aug.augment):
+        x = cat.clone().requires_grad_(True)
+        stack = x.unsqueeze(1).expand(-1, 15, -1, -1, -1).contiguous().flatten(0, 1)
+        torch.manual_seed(23)
+        out, pose, focal = fn(stack, None, None, 1.0)
+        assert pose is None and focal is None
+        (out * cot).sum().backward()
+        res.append((out.detach(), x.grad))
+    (o_r, g_r), (o, gx) = res
+    # white-noise images: neighbouring texels differ by up to 2, the sampling coordinates by an ulp of [-1, 1] (8e-6 px at
+    # 128 px; ATen builds them with a batched matmul of the base grid, the kernel per pixel) on each axis: 3.1e-5 measured
+    assert (o - o_r).abs().max().item() <= 6e-5
+    assert (gx - g_r).abs().max().item() <= 6e-5 * g_r.abs().max().item()
+    # image + pose + focal, perspective and orthographic, p < 1 (some images stay as they are), with the transform returned
+    for ortho in (False, True):
+        pose = torch.eye(4, device=gpu_device).repeat(6, 1, 1)
+        pose[:, :3, :3] = torch.linalg.qr(torch.randn((6, 3, 3), device=gpu_device, generator=g))[0]
+        pose[:, :3, 3] = torch.randn((6, 3), device=gpu_device, generator=g)
+        if ortho:
+            pose[:, 3, 3] = 1 + 0.3 * torch.rand(6, device=gpu_device, generator=g)
+        focal = None if ortho else 1 + 0.2 * torch.rand(6, device=gpu_device, generator=g)
+        img = torch.rand((6, 4 if not white else 3, 64, 64), device=gpu_device, generator=g) * 2 - 1
+        outs = []
+        for fn in (env['augment'], aug.augment):
+            torch.manual_seed(29)
+            outs.append(fn(img.clone(), pose.clone(), None if focal is None else focal.clone(), 0.6, False, None, True))
+        (i_r, p_r, f_r, t_r), (i_m, p_m, f_m, t_m) = outs
+        assert all(torch.equal(a, b) for a, b in zip(t_r, t_m)), 'random draws differ'
+        assert (i_m - i_r).abs().max().item() <= 6e-5
+        assert (p_m - p_r).abs().max().item() <= 1e-5
+        assert (f_r is None and f_m is None) or (f_m - f_r).abs().max().item() <= 1e-6
+
+
+@pytest.mark.gpu
+def test_psnr_and_iou_against_the_live_reference_on_the_gpu(gpu_device):
+    """lib/metrics.py::psnr / iou (30-45, 79-94, AST-sliced: the module itself needs lpips and skimage) on PyTorch-ROCm against
+    the HIP monitors on render-sized inputs, both layouts and both reductions."""
+    if REF is None:
+        pytest.skip('reference sources not staged (oracle/make_ref.py)')
+    import nerf_from_image_amd.metrics as nfi_metrics
+    env = reference.slice_functions('lib/metrics.py', ['range_check', 'psnr', 'iou'], {'torch': torch})
+    g = torch.Generator(device=gpu_device).manual_seed(31)
+    target = torch.rand((16, 128, 128, 3), device=gpu_device, generator=g)
+    noise = torch.randn((16, 128, 128, 3), device=gpu_device, generator=g)
+    level = torch.logspace(-4, -1, 16, device=gpu_device).view(16, 1, 1, 1)
+    pred = (target + noise * level).clamp(-0.05, 1.05)               # (inside the range check's margin, outside [0, 1])
+    pred[3] = target[3]                                              # a perfect image: the 60 dB clamp
+    for a, b in ((pred, target), (pred.permute(0, 3, 1, 2).contiguous(), target.permute(0, 3, 1, 2).contiguous())):
+        ref_each, got_each = env['psnr'](a, b, reduction='none'), nfi_metrics.psnr(a, b, reduction='none')
+        assert (got_each - ref_each).abs().max().item() <= 2e-4, (got_each, ref_each)          # dB, out of 20 ... 60
+        assert float(got_each[3]) == 60.0 == float(ref_each[3])
+        assert abs(float(nfi_metrics.psnr(a, b)) - float(env['psnr'](a, b))) <= 2e-4
+    ma = torch.rand((16, 128, 128), device=gpu_device, generator=g)
+    mb = (ma + 0.3 * torch.randn((16, 128, 128), device=gpu_device, generator=g)).clamp(0, 1)
+    mb[5], ma[5] = 0.0, 0.0                                          # empty masks: (0 + eps) / (0 + eps) = 1
+    for a, b in ((ma, mb), (ma.unsqueeze(1), mb.unsqueeze(1))):
+        assert torch.equal(nfi_metrics.iou(a, b, reduction='none'), env['iou'](a, b, reduction='none'))
+        assert abs(float(nfi_metrics.iou(a, b)) - float(env['iou'](a, b))) <= 1e-6
+    assert float(nfi_metrics.iou(ma, mb, reduction='none')[5]) == 1.0
