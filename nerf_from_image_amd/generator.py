@@ -151,8 +151,12 @@ def make_sampler(planes, decoder, scene_range, n_attention, attention_values, us
         bwd = None
         if texel_dtype == ops.TEXEL_F32 or ray_pad is None:      # (the view-direction decoder's backward is fp32-texel only)
             bwd = make_field_bwd(texels, image, scene_range, n_attention, use_sdf, want_sdf, want_sem, ray_pad, spr)
-        args = (pts, planes, w1, b1, w2, b2, attention_values if n_attention > 0 else None,
-                beta if use_sdf else None, alpha if use_sdf else None)
+        # what an output does not depend on gets no gradient (None, not zeros - as in the reference's graph): the colour
+        # table only enters rgb, beta / alpha only sigma
+        det = (lambda t, used: t if (t is None or used) else t.detach())
+        want_sigma = 'sigma' in request_sampler_outputs
+        args = (pts, planes, w1, b1, w2, b2, det(attention_values, 'rgb' in request_sampler_outputs) if n_attention > 0 else None,
+                det(beta, want_sigma) if use_sdf else None, det(alpha, want_sigma) if use_sdf else None)
         if ray_pad is not None:
             args = args + (ray_feature, w3, b3)
         if want_normals:
@@ -164,7 +168,8 @@ def make_sampler(planes, decoder, scene_range, n_attention, attention_values, us
                                              n_attention, None if attention_values is None else attention_values.detach(),
                                              use_sdf, beta.detach(), alpha.detach(),
                                              viewdir=None if ray_pad is None else dict(
-                                                 ray_features=ray_pad, samples_per_ray=spr, w3=w3.detach()))
+                                                 ray_features=ray_pad, samples_per_ray=spr, w3=w3.detach())
+                                             ).view(x_in.shape)        # (the gradient w.r.t. x_in: its shape, generator.py:614-621)
         i = 2
         if want_sdf:
             out['sdf_distance'] = res[i].unsqueeze(-1)
