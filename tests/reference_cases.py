@@ -28,6 +28,9 @@ GEOMETRY = {
     'classes': dict(scene_range=0.55, white=True, radius=2.0, focal=1.0254, bbox=False, num_classes=5),
     # cub with the crop box its loader passes (orthographic branch of get_ray_bundle WITH bbox, lib/nerf_utils.py:72-77)
     'cub_bbox': dict(scene_range=2.0, white=False, radius=3.0, focal=None, bbox=True),
+    # --use_encoder: Generator(use_encoder=True) with model_input = (z, image) (generator.py:357-358, 423-426: ResidualEncoder
+    # -> conditional mapping network)
+    'encoder': dict(scene_range=0.55, white=True, radius=2.0, focal=1.0254, bbox=False, use_encoder=True),
 }
 
 
@@ -66,13 +69,20 @@ def build_scene(geometry, batch, dev, seed=1234, alpha=0.05, beta=0.1, fine_samp
     use_sdf, n_att = bool(g.get('use_sdf', True)), int(g.get('attention_values', 10))
     torch.manual_seed(seed)
     n_cls = g.get('num_classes')
+    enc = bool(g.get('use_encoder'))
     gen = m.generator.Generator(512, g['scene_range'], attention_values=n_att, use_viewdir=vd, use_sdf=use_sdf,
-                                disable_stylegan_noise=not stylegan_noise, num_classes=n_cls)
+                                disable_stylegan_noise=not stylegan_noise, num_classes=n_cls, use_encoder=enc)
     cpu = torch.Generator().manual_seed(seed + 1)
     with torch.no_grad():
         if use_sdf:
             gen.alpha.fill_(alpha)
             gen.beta.fill_(beta)
+        if stylegan_noise:
+            # noise_strength is zero-initialised (stylegan.py:322): a trained model's is not, and only then do the per-layer
+            # draws reach the planes
+            for mod in gen.modules():
+                if hasattr(mod, 'noise_strength'):
+                    mod.noise_strength.fill_(0.1)
         if vd:
             # the mapper's output layer is zero-initialised (generator.py:217-219): give it weights, or every colour
             # would be the same constant in both implementations
@@ -81,8 +91,9 @@ def build_scene(geometry, batch, dev, seed=1234, alpha=0.05, beta=0.1, fine_samp
     gen = gen.to(dev).eval().requires_grad_(False)
     z = torch.randn(batch, 512, generator=cpu).to(dev)
     labels = torch.randint(n_cls, (batch,), generator=cpu).to(dev) if n_cls else None
+    image = (torch.rand(batch, 3, 128, 128, generator=cpu) * 2 - 1).to(dev) if enc else None
     with torch.no_grad():
-        ws = gen.mapping_network(z, gen.class_embedding(labels) if n_cls else None)
+        ws = gen.mapping_network(z, gen.emb(image) if enc else (gen.class_embedding(labels) if n_cls else None))
         # centre the distance output: shift its bias by the lower quartile of the SDF over the cube (all scenes of the
         # batch): a quarter of the volume is inside a surface
         pts = ((torch.rand(batch, 20000, 3, generator=cpu) * 2 - 1) * g['scene_range']).to(dev)
@@ -90,7 +101,7 @@ def build_scene(geometry, batch, dev, seed=1234, alpha=0.05, beta=0.1, fine_samp
             out = gen(torch.zeros(batch, 1, 1, 1, 3, device=dev), ws, ['sampler'])
             sdf = out['sampler'](pts.view(batch, 1, 1, -1, 3), ['sdf_distance'])['sdf_distance']
         else:
-            sdf = gen(None, ws, ['sampler'])['sampler'](pts, ['sdf_distance'])['sdf_distance']
+            sdf = gen(None, (z, image) if enc else ws, ['sampler'])['sampler'](pts, ['sdf_distance'])['sdf_distance']
         if use_sdf:
             gen.decoder.net[2].bias[0] -= sdf.flatten().quantile(0.25)
         else:
@@ -107,7 +118,7 @@ def build_scene(geometry, batch, dev, seed=1234, alpha=0.05, beta=0.1, fine_samp
     args = reference.render_args(fine_sampling=fine_sampling, use_sdf=use_sdf, attention_values=n_att, use_viewdir=vd)
     dcfg = {'scene_range': g['scene_range'], 'white_background': g['white']}
     return types.SimpleNamespace(geometry=geometry, g=g, gen=gen, hip=hip, z=z, ws=ws, cam=cam, focal=focal, bbox=bbox,
-                                 args=args, dcfg=dcfg, batch=batch, dev=dev, labels=labels)
+                                 args=args, dcfg=dcfg, batch=batch, dev=dev, labels=labels, image=image)
 
 
 class ReplayNoise:
@@ -226,18 +237,20 @@ def reference_render(sc, res, samples, noise, device=None, images=None, grad=Fal
     nz = None if noise is None else [noise[0][sl]] + [n.view(sc.batch, -1, samples)[sl].reshape(-1, samples) for n in noise[1:]]
     ctx = contextlib.nullcontext()
     extra_in = dict(render_kw.pop('extra_model_inputs', {}))
+    cut = (lambda v: v[sl] if torch.is_tensor(v) else v)               # ('freeze_noise' is a bool)
     if images is not None and (device is None or torch.device(device) == cam.device):
-        extra_in = {k: v[sl] for k, v in extra_in.items()}
+        extra_in = {k: cut(v) for k, v in extra_in.items()}
     if device is not None and torch.device(device) != cam.device:
         with torch.no_grad():
-            planes = sc.gen.synthesis_network(ws[:, :14]).cpu()
+            planes = sc.gen.synthesis_network(ws[:, :14], **({'noise_mode': 'const'} if extra_in.get('freeze_noise') else {})).cpu()
+            extra_in.pop('freeze_noise', None)                           # (the CPU copy's producer is frozen altogether)
             if sc.gen.attention_values > 0:
                 # the colour table the GPU model ends up with under the caller's model inputs (override / bias), as the
                 # CPU copy's override
-                given = {k: v[sl] for k, v in extra_in.items()}
+                given = {k: cut(v) for k, v in extra_in.items()}
                 extra_in = {'attention_values': sc.gen(None, ws, ['attention_values', 'sampler'], given)['attention_values'].cpu()}
             else:
-                extra_in = {k: v[sl].to(device) for k, v in extra_in.items()}
+                extra_in = {k: cut(v).to(device) for k, v in extra_in.items()}
         gen = copy.deepcopy(sc.gen).to(device)
         ws, cam, focal, bbox = ws.to(device), cam.to(device), pick_to(focal, device), pick_to(bbox, device)
         ctx = frozen_producer(gen, planes)
