@@ -687,6 +687,10 @@ def training_step(sc, res, samples, seed=77, reg_weight=0.1, float64=True, fused
     rep = {'loss_hip': l_h, 'loss_reference': l_r, 'n_parameter_tensors': len(g_r), 'grad_rel_l2_all_parameters': s_['all_parameters'],
            'worst_tensor_among_the_significant': s_['worst_tensor'], 'worst_tensor_rel_l2': s_['worst_tensor_rel_l2'],
            'significant_tensors': s_['significant_tensors']}
+    strengths = [n for n in g_r if n.endswith('noise_strength')]
+    if strengths:
+        rep['noise_strength_tensors'] = len(strengths)
+        rep['noise_strength_grad_rel_l2'] = rel_err(torch.stack([g_h[n] for n in strengths]), torch.stack([g_r[n] for n in strengths]))
     if float64:
         l_d, g_d = run(copy.deepcopy(sc.gen).double(), ref_render, double=True)
         assert set(g_d) == set(g_h)

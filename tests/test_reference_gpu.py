@@ -222,6 +222,17 @@ def test_stylegan_noise_draws_interleave_like_the_reference(gpu_device):
         over = int(((a - b).abs() > BUDGET).sum())
         # 3 values of 98 304 over the budget (2.0e-4 at most) measured: the pixels the GPU reference moves against its own CPU path
         assert over <= 8 and rc.max_err(a, b) < 5e-3, (k, rc.max_err(a, b), over)
+    # the same with the tail of the last synthesis block fused into the texel hand-off (attach(fused_handoff=True)): the block's
+    # two noise draws come before the fused part
+    import copy
+    import nerf_from_image_amd.generator as nfi_gen
+    fused = copy.copy(sc)
+    fused.hip = nfi_gen.attach(copy.deepcopy(sc.gen), fused_handoff=True).train()
+    torch.manual_seed(777)
+    theirs = rc.hip_render(fused, 128, 64, None)
+    for k, a, b in zip(('rgb', 'depth', 'mask'), theirs[:3], ref[:3]):
+        over = int(((a - b).abs() > BUDGET).sum())
+        assert over <= 8 and rc.max_err(a, b) < 5e-3, (k, 'fused hand-off', rc.max_err(a, b), over)
 
 
 def test_cfg1_shape_coarse_only_matches_the_real_reference(gpu_device):
@@ -497,9 +508,10 @@ def test_regulariser_branch_on_the_real_generator(gpu_device):
     assert rep['hip_vs_float64']['ws'] <= 1.5 * rep['reference_vs_float64']['ws'] + 1e-6, rep
 
 
-@pytest.mark.parametrize('fused_handoff,one_forward,path_length', [(False, False, False), (True, False, False), (True, True, False),
-                                                                   (True, True, True)])
-def test_generator_training_step_on_the_real_generator(gpu_device, fused_handoff, one_forward, path_length):
+@pytest.mark.parametrize('fused_handoff,one_forward,path_length,noisy', [(False, False, False, False), (True, False, False, False),
+                                                                         (True, True, False, False), (True, True, True, False),
+                                                                         (True, True, True, True)])
+def test_generator_training_step_on_the_real_generator(gpu_device, fused_handoff, one_forward, path_length, noisy):
     """BASELINE cfg4's generator step on the real class (cub-like: orthographic, scene_range 2.0, black background, 4 images
     x 128 x 128 x (64 + 64), model.train(), latents through the mapping network, image + alpha loss + eikonal / distance
     regularisers, ONE backward): the gradient of EVERY generator parameter - mapping network, StyleGAN2 synthesis, texture
@@ -509,14 +521,20 @@ def test_generator_training_step_on_the_real_generator(gpu_device, fused_handoff
     6.6e-5 (decoder.net.0.weight); both fp32 implementations 9.5e-5 from the float64 reference."""
     _require_reference()
     with rc.deterministic_producer():
-        sc = rc.build_scene('cub', 4, gpu_device)
+        # (noisy: per-layer StyleGAN2 noise on - run.py's training default - with non-zero strengths, drawn by torch.randn from
+        #  the same seed in both; the strengths are parameters too.  No float64 leg: a float64 producer draws other numbers.)
+        sc = rc.build_scene('cub', 4, gpu_device, stylegan_noise=noisy)
         # (one_forward: as run.py's G loop has it, 966-986 - ONE Generator.forward inside render() serves the sampler and the
         #  eikonal / total-variation / entropy regularisers, its volume draw between render's two noise draws)
-        rep = rc.training_step(sc, 128, 64, fused_handoff=fused_handoff, one_forward=one_forward, path_length=path_length)
+        rep = rc.training_step(sc, 128, 64, fused_handoff=fused_handoff, one_forward=one_forward, path_length=path_length,
+                               float64=not noisy)
     assert abs(rep['loss_hip'] - rep['loss_reference']) <= 1e-6 * abs(rep['loss_reference']), rep
     # (all parameters: 8.0e-6 in every session so far; most of them sit behind the producer's backward like the latents)
     assert rep['n_parameter_tensors'] > 100 and rep['grad_rel_l2_all_parameters'] <= 3 * LATENTS_MEASURED, rep
     assert rep['worst_tensor_rel_l2'] <= 2e-4, rep
+    if noisy:
+        assert rep['noise_strength_tensors'] == 13 and rep['noise_strength_grad_rel_l2'] <= 2e-4, rep
+        return
     h, r = rep['hip_vs_float64'], rep['reference_vs_float64']
     assert h['all_parameters'] <= 1.5 * r['all_parameters'] and h['worst_tensor_rel_l2'] <= 1.5 * r['worst_tensor_rel_l2'] + 1e-5, rep
 
