@@ -178,3 +178,26 @@ def test_wrapped_forward_can_hand_the_regularisers_to_hip(monkeypatch):
     assert inner['req'] == ['sampler', 'path_length', 'attention_values']
     assert set(out) == {'sampler', 'sdf_distance_loss', 'sdf_eikonal_loss', 'path_length'}
     assert seen['planes'].shape == (2, 3, 32, 256, 256) and seen['planes'].requires_grad
+
+
+def test_a_deep_copy_of_an_attached_model_is_attached_to_itself(monkeypatch):
+    """run.py keeps EMA / test copies of its generator (copy.deepcopy, load_state_dict into a second instance): the copy's
+    forward, its kept original forward and the fused last block have to be bound to the COPY's modules and parameters."""
+    import copy
+    ref_gen = reference.modules().generator
+    import nerf_from_image_amd.generator as nfi_gen
+    torch.manual_seed(0)
+    model = nfi_gen.attach(ref_gen.Generator(512, 0.55, attention_values=10, use_sdf=True, disable_stylegan_noise=True),
+                           hip_regularisers=True, fused_handoff=True)
+    twin = copy.deepcopy(model)
+    assert twin.forward.__self__ is twin and twin._nfi_original_forward.__self__ is twin
+    assert model.forward.__self__ is model
+    last = [b for b in twin.synthesis_network.children() if hasattr(b, '_nfi_original_forward')]
+    assert len(last) == 1 and last[0].forward.__self__ is last[0] and last[0]._nfi_original_forward.__self__ is last[0]
+    assert twin.nfi_hip_regularisers and list(twin.state_dict()) == list(model.state_dict())
+    seen = []
+    monkeypatch.setattr(nfi_gen, 'make_sampler', lambda planes, decoder, *a, **k: seen.append(decoder) or (lambda x, req=None: {}))
+    from nerf_from_image_amd import handoff
+    with torch.no_grad(), handoff.unfused(twin.synthesis_network):           # (the fused tail is a HIP kernel; the CPU runs the original)
+        twin.eval()(None, torch.randn(1, 512), ['sampler'])
+    assert seen == [twin.decoder] and seen[0] is not model.decoder
