@@ -240,3 +240,81 @@ def test_work_queues_cover_every_ray_exactly_once(gpu_device, H, W, S, B):
         for k in ('rgb', 'depth', 'mask'):
             assert torch.equal(r[k], outs[0][k]), k
     assert outs[0]['mask'].max() > 0.1
+
+
+def test_two_host_threads_on_their_own_streams(gpu_device):
+    """under nn.DataParallel the reference calls render() from one Python thread per replica, concurrently - the
+    library has to be re-entrant (no global mutable state, the caller's stream, thread-local error text).  One GPU here, so
+    the two threads share the device and differ in stream and scene: every launch of each thread (fused render, and the field
+    query forward + backward of a training step) has to reproduce, bit for bit, what the same thread's work gives when run alone."""
+    import threading
+    import nerf_from_image_amd.generator as nfi_gen
+    dev = gpu_device
+    H = W = 48
+    S, A = 32, 10
+    jobs = []
+    for seed in (5, 6):
+        d, g = scene(2, A, 64, seed)
+        cam = look_at_cameras(2, 2.0, g)
+        focal = torch.full((2,), 1.0254)
+        mv = lambda t: t.to(dev)
+        jobs.append(dict(texels=ops.planes_to_texels(mv(d['planes'])), planes=mv(d['planes']),
+                         image=ops.decoder_pack(mv(d['w1']), mv(d['b1']), mv(d['w2']), mv(d['b2']), A),
+                         w=[mv(d[k]) for k in ('w1', 'b1', 'w2', 'b2')], att=mv(d['att']), beta=mv(d['beta']), alpha=mv(d['alpha']),
+                         cam=mv(cam), focal=mv(focal), nc=mv(torch.rand(2, H, W, S, generator=g)), nf=mv(torch.rand(2 * H * W, S, generator=g)),
+                         pts=mv((torch.rand(2, 20000, 3, generator=g) * 2 - 1) * 0.6), cot=mv(torch.randn(2, 20000, 4, generator=g))))
+
+    class Dec(torch.nn.Module):                      # (what make_sampler reads: .net[0] / .net[2] with weight and bias)
+        def __init__(self, w):
+            super().__init__()
+            self.net = torch.nn.ModuleList([torch.nn.Linear(32, 64), torch.nn.Identity(), torch.nn.Linear(64, 1 + A)])
+            with torch.no_grad():
+                self.net[0].weight.copy_(w[0]); self.net[0].bias.copy_(w[1]); self.net[2].weight.copy_(w[2]); self.net[2].bias.copy_(w[3])
+
+    def work(j, rounds, out):
+        stream = torch.cuda.Stream(device=dev)
+        with torch.cuda.stream(stream):
+            dec = Dec(j['w']).to(dev)
+            res = []
+            for _ in range(rounds):
+                r = ops.render_fwd(j['cam'], j['focal'], H, W, S, j['texels'], j['image'], 0.55, A, j['att'], True, j['beta'], j['alpha'],
+                                   noise_coarse=j['nc'], noise_fine=j['nf'], fine_sampling=True, white_background=True,
+                                   skip_missed_rays=True, strict=False)
+                planes = j['planes'].clone().requires_grad_(True)
+                pts = j['pts'].clone().requires_grad_(True)
+                smp = nfi_gen.make_sampler(planes, dec, 0.55, A, j['att'], True, j['beta'], j['alpha'])
+                q = smp(pts, ['sigma', 'rgb'])
+                ((q['sigma'] * j['cot'][..., 0]).sum() + (q['rgb'] * j['cot'][..., 1:]).sum()).backward()
+                res.append((r['rgb'].clone(), r['depth'].clone(), r['mask'].clone(), planes.grad.clone(), pts.grad.clone(),
+                            dec.net[0].weight.grad.clone()))
+                dec.zero_grad(set_to_none=True)
+            stream.synchronize()
+        out.append(res)
+    alone = []
+    for j in jobs:
+        work(j, 2, alone)
+    together = [[], []]
+    failures = []
+
+    def guarded(i):
+        try:
+            work(jobs[i], 12, together[i])
+        except BaseException as e:                    # noqa: BLE001 - re-raised below, on the main thread
+            failures.append(e)
+    threads = [threading.Thread(target=guarded, args=(i,)) for i in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    if failures:
+        raise failures[0]
+    def same(a, b, k):
+        # outputs 3 and 5, the plane and weight gradients: sums that end in float atomics (order-dependent in the last bits)
+        return torch.equal(a, b) if k not in (3, 5) else float((a - b).abs().max()) <= 3e-6 * float(b.abs().max())
+    for i in range(2):
+        for k, (a, b) in enumerate(zip(alone[i][0], alone[i][1])):                           # (reproducible to begin with)
+            assert same(a, b, k), ('alone, job %d output %d' % (i, k), float((a - b).abs().max()), float(a.abs().max()))
+        for r, res in enumerate(together[i][0]):
+            for k, (a, b) in enumerate(zip(res, alone[i][0])):
+                assert same(a, b, k), ('thread %d round %d output %d' % (i, r, k), float((a - b).abs().max()))
+    assert not torch.equal(together[0][0][0][0], together[1][0][0][0])                         # (two different scenes)
