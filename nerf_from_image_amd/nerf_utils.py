@@ -12,8 +12,11 @@ on the rays' device (same shapes and order, hence the same Philox stream as the 
 PyTorch-ROCm run); the noise is then handed to the kernels.
 
 Gradients: as in the reference's autograd graph, depth samples and depth_map carry none;
-rgb/mask/extra maps differentiate w.r.t. sigma, rgb, extras and the ray directions; query points
-differentiate w.r.t. ray origins/directions; rays w.r.t. tform_cam2world and focal_length.
+rgb/mask/extra maps differentiate w.r.t. sigma, rgb, extras and the ray directions; the normal map is
+composited with DETACHED weights (lib/nerf_utils.py:146-147): its cotangent reaches the normals (and, on a
+white background, the mask) but not sigma; query points differentiate w.r.t. ray origins/directions; rays
+w.r.t. tform_cam2world and focal_length.  Every function is held against the live reference module in
+tests/test_reference_nerf_utils.py (signatures, values, gradients).
 """
 from typing import Optional
 
