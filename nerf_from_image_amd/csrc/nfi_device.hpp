@@ -381,7 +381,7 @@ struct FieldParams {
   const float* w1t;
   const float* w2r0;
 };
-constexpr int kW1TFloats = 2 * 2 * 2 * 64 * 4, kNrmLdsFloats = kW1TFloats + 64;
+constexpr int kW1TFloats = 2 * 2 * 2 * 64 * 4, kNrmLdsFloats = kW1TFloats + 64 + 4;     // (+ the scale-back factor)
 
 __device__ __forceinline__ void split_f16x8(const float (&x)[8], f16x8& hi, f16x8& lo);
 
@@ -393,6 +393,7 @@ __device__ __forceinline__ void split_f16x8(const float (&x)[8], f16x8& hi, f16x
 //   W2F[nt][(g, m)][r] = W2'[row m][unit 16 nt + 4 g + r]  ->  w2r0[g][nt][r] = W2F[nt][(g, 0)][r]
 // (w1f / w2f: float offsets of the W1 fragments and of the second layer's fragments in `image` - kW1F / kW2F of the plain
 //  decoder image, kVdW1F / kVdW2 of the view-direction one, whose tile 0 holds the distance row)
+__device__ __forceinline__ void pow2_normaliser(float amax, float& s, float& inv);
 __device__ __forceinline__ void stage_normal_operands(float* dst, const float* image, int w1f = kW1F, int w2f = kW2F) {
   for (int idx = threadIdx.x; idx < 256; idx += blockDim.x) {
     const int l = idx & 63, kk = (idx >> 6) & 1, ct = idx >> 7;
@@ -409,10 +410,19 @@ __device__ __forceinline__ void stage_normal_operands(float* dst, const float* i
     reinterpret_cast<u32x4*>(dst)[((ct * 2 + kk) * 2 + 0) * 64 + l] = __builtin_bit_cast(u32x4, hi);
     reinterpret_cast<u32x4*>(dst)[((ct * 2 + kk) * 2 + 1) * 64 + l] = __builtin_bit_cast(u32x4, lo);
   }
+  // the distance row of the second layer under ONE power-of-two scale for the whole launch: GH = sigmoid(h) * W2'[0] is
+  // bounded by |W2'[0]|, so the largest entry is brought to [2^12, 2^13) - the hi + lo fp16 split then resolves 2^-24 of a
+  // point's GH as long as its largest component is within 2^-12 of the row's (fp16 subnormals start 2^-24 below 1), which
+  // is what the per-point normaliser of round 6's first form bought with 16 max + 2 cross-lane steps + 24 multiplies a tile
+  float amax = 0.0f;
+  for (int i = 0; i < 64; ++i) amax = fmaxf(amax, fabsf(image[w2f + ((((i >> 2) & 3) * 64 + 16 * (i >> 4)) << 2) + (i & 3)]));
+  float ssc, s_inv;
+  pow2_normaliser(amax, ssc, s_inv);
   for (int i = threadIdx.x; i < 64; i += blockDim.x) {
     const int r = i & 3, nt = (i >> 2) & 3, g = i >> 4;
-    dst[kW1TFloats + i] = image[w2f + ((nt * 64 + 16 * g) << 2) + r];
+    dst[kW1TFloats + i] = image[w2f + ((nt * 64 + 16 * g) << 2) + r] * ssc * 4096.0f;
   }
+  if (threadIdx.x == 0) dst[kW1TFloats + 64] = s_inv * (1.0f / 4096.0f);
 }
 
 // per-point gather set-up in sample layout: unnormalised, border-clamped plane coordinates.
@@ -693,6 +703,46 @@ __device__ __forceinline__ void tile_gather_two_rounds(const FieldParams& P, int
   plane_blend(2, fx, fy, fz, tv[0], feat);
 }
 
+// The normal map's gather (fp32 texels): features AND derivative features (tile_bilinear_deriv's arithmetic) with two planes
+// in flight at any time - planes 0 and 1 go out together, plane 2 takes plane 0's registers as soon as they are consumed: 64
+// texel registers + 24 derivative sums instead of 96 + 24 (which spills), one round trip exposed instead of three.
+__device__ __forceinline__ void plane_blend_deriv(int pl, float fx, float fy, float fz, const float (&src)[4][8], float (&feat)[8],
+                                                  float (&dfeat)[3][8]) {
+  // written on channel PAIRS: the compiler's SLP pass leaves this blend scalar (288 instructions per tile; as v_pk_fma_f32 /
+  // v_pk_add_f32 it is 144), the plain blend it packs by itself
+  typedef float v2f __attribute__((ext_vector_type(2)));
+  const float fa = (pl == 2) ? fy : fx, fb = (pl == 0) ? fy : fz;
+  const float ga = 1.0f - fa, gb = 1.0f - fb;
+  const float w00 = ga * gb, w10 = fa * gb, w01 = ga * fb, w11 = fa * fb;
+  const v2f W00 = {w00, w00}, W10 = {w10, w10}, W01 = {w01, w01}, W11 = {w11, w11};
+  const v2f FA = {fa, fa}, FB = {fb, fb}, GA = {ga, ga}, GB = {gb, gb};
+  const int ia = (pl == 2) ? 1 : 0, ib = (pl == 0) ? 1 : 2;
+#pragma unroll
+  for (int s = 0; s < 8; s += 2) {
+    const v2f t0 = {src[0][s], src[0][s + 1]}, t1 = {src[1][s], src[1][s + 1]}, t2 = {src[2][s], src[2][s + 1]},
+              t3 = {src[3][s], src[3][s + 1]};
+    v2f acc = {feat[s], feat[s + 1]};
+    acc = __builtin_elementwise_fma(W00, t0, acc);
+    acc = __builtin_elementwise_fma(W10, t1, acc);
+    acc = __builtin_elementwise_fma(W01, t2, acc);
+    acc = __builtin_elementwise_fma(W11, t3, acc);
+    feat[s] = acc.x; feat[s + 1] = acc.y;
+    v2f da = {dfeat[ia][s], dfeat[ia][s + 1]}, db = {dfeat[ib][s], dfeat[ib][s + 1]};
+    da = __builtin_elementwise_fma(FB, t3 - t2, __builtin_elementwise_fma(GB, t1 - t0, da));
+    db = __builtin_elementwise_fma(FA, t3 - t1, __builtin_elementwise_fma(GA, t2 - t0, db));
+    dfeat[ia][s] = da.x; dfeat[ia][s + 1] = da.y;
+    dfeat[ib][s] = db.x; dfeat[ib][s + 1] = db.y;
+  }
+}
+// plane 0's sums exist HERE and later loads stay behind them (see tile_gather_planewise)
+__device__ __forceinline__ void pin_deriv_sums(float (&feat)[8], float (&dfeat)[3][8]) {
+  asm volatile("" : "+v"(feat[0]), "+v"(feat[1]), "+v"(feat[2]), "+v"(feat[3]), "+v"(feat[4]), "+v"(feat[5]), "+v"(feat[6]), "+v"(feat[7]),
+               "+v"(dfeat[0][0]), "+v"(dfeat[0][1]), "+v"(dfeat[0][2]), "+v"(dfeat[0][3]), "+v"(dfeat[0][4]), "+v"(dfeat[0][5]),
+               "+v"(dfeat[0][6]), "+v"(dfeat[0][7]), "+v"(dfeat[1][0]), "+v"(dfeat[1][1]), "+v"(dfeat[1][2]), "+v"(dfeat[1][3]),
+               "+v"(dfeat[1][4]), "+v"(dfeat[1][5]), "+v"(dfeat[1][6]), "+v"(dfeat[1][7]) : : "memory");
+  __builtin_amdgcn_sched_barrier(0);
+}
+
 // density / colour epilogue on the decoder outputs o (lane (g,j): rows 4g..4g+3 of point j; row 0 =
 // distance/density, rows 1.. = colour logits pre-scaled by log2e)
 // SEMP: where the softmax probabilities of a point go.  0: sem[n] is a global row [A] (the sampler closure's
@@ -865,33 +915,30 @@ __device__ __forceinline__ uint32_t ratio_f16x2(int es, float inv_pt) {
 // so GH is scaled per point by a power of two and the accumulator scaled back exactly.
 __device__ __forceinline__ void normal_contraction(const FieldParams& P, int lane, const f32x4 (&gh)[4], f32x4& Gout0, f32x4& Gout1) {
   const u32x4* w1t = reinterpret_cast<const u32x4*>(P.w1t);
-  float am = 0.0f;
-#pragma unroll
-  for (int nt = 0; nt < 4; ++nt)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) am = fmaxf(am, fabsf(gh[nt][r]));
-  am = max_xor32(max_xor16(am));                       // over the four hidden groups of point j
-  float ssc, s_inv;
-  pow2_normaliser(am, ssc, s_inv);
-  f32x4 G0 = {0.0f, 0.0f, 0.0f, 0.0f}, G1 = {0.0f, 0.0f, 0.0f, 0.0f};
+  // four accumulators (one per channel tile and K half, summed at the end): chains of 3 dependent MFMAs instead of 6
+  f32x4 G[2][2];
 #pragma unroll
   for (int kk = 0; kk < 2; ++kk) {
     const f32x4 ga = gh[2 * kk], gb = gh[2 * kk + 1];
-    const float xs[8] = {ga.x * ssc, ga.y * ssc, ga.z * ssc, ga.w * ssc, gb.x * ssc, gb.y * ssc, gb.z * ssc, gb.w * ssc};
+    const float xs[8] = {ga.x, ga.y, ga.z, ga.w, gb.x, gb.y, gb.z, gb.w};
     f16x8 sh, sl;
     split_f16x8(xs, sh, sl);
     const f16x8 ah = __builtin_bit_cast(f16x8, w1t[((0 * 2 + kk) * 2 + 0) * 64 + lane]);
     const f16x8 al = __builtin_bit_cast(f16x8, w1t[((0 * 2 + kk) * 2 + 1) * 64 + lane]);
     const f16x8 bh = __builtin_bit_cast(f16x8, w1t[((1 * 2 + kk) * 2 + 0) * 64 + lane]);
     const f16x8 bl = __builtin_bit_cast(f16x8, w1t[((1 * 2 + kk) * 2 + 1) * 64 + lane]);
-    G0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, sh, G0, 0, 0, 0);
-    G1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh, sh, G1, 0, 0, 0);
-    G0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, sl, G0, 0, 0, 0);
-    G1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh, sl, G1, 0, 0, 0);
-    G0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, sh, G0, 0, 0, 0);
-    G1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(bl, sh, G1, 0, 0, 0);
+    const f32x4 zero = {0.0f, 0.0f, 0.0f, 0.0f};
+    G[kk][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, sh, zero, 0, 0, 0);
+    G[kk][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bl, sh, zero, 0, 0, 0);
+    G[kk][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, sl, G[kk][0], 0, 0, 0);
+    G[kk][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh, sl, G[kk][1], 0, 0, 0);
+    G[kk][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, sh, G[kk][0], 0, 0, 0);
+    G[kk][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh, sh, G[kk][1], 0, 0, 0);
   }
-  Gout0 = G0 * s_inv; Gout1 = G1 * s_inv;
+  const f32x4 G0 = G[0][0] + G[1][0], G1 = G[0][1] + G[1][1];
+  // (the launch-wide scale of the staged W2' row is NOT taken back: every axis of a point's gradient carries it, and a
+  //  power of two passes through the normalisation exactly - P.w2r0[64] holds it for whoever needs the magnitude)
+  Gout0 = G0; Gout1 = G1;
 }
 
 // PREC 0: exact fp32 MFMA (v_mfma_f32_16x16x4_f32, 48 per tile).
@@ -941,8 +988,10 @@ __device__ __forceinline__ void tile_mlp(const FieldParams& P, int lane, const f
           float sp = __builtin_amdgcn_logf(1.0f + e);
           acc1[n][nt][r] = __builtin_amdgcn_fmed3f(sp, h, 128.0f);
           if constexpr (NRM) {
-            const float sg = (h > kSoftplusThr2) ? 1.0f : e * __builtin_amdgcn_rcpf(1.0f + e);     // d softplus2 / d h2
-            gh[nt][r] = sg * reinterpret_cast<const f32x4*>(P.w2r0)[g * 4 + nt][r];
+            // d softplus2 / d h2 = e / (1 + e) = 1 - 1 / (1 + e): 1 where e overflows, absolute error 2^-24 (GH is a sum's operand)
+            // (times the staged W2' entry in the same instruction: w - w / (1 + e))
+            const float w2u = reinterpret_cast<const f32x4*>(P.w2r0)[g * 4 + nt][r];
+            gh[nt][r] = fmaf(-w2u, __builtin_amdgcn_rcpf(1.0f + e), w2u);
           }
         }
       // (right behind this tile's softplus, so that GH never outlives it)
@@ -1072,8 +1121,8 @@ __device__ __forceinline__ void tile_mlp_vd(const FieldParams& P, int lane, cons
         float sp = __builtin_amdgcn_logf(1.0f + e);
         acc1[n][nt][r] = (h > kSoftplusThr2) ? h : sp;
         if constexpr (NRM) {
-          const float sg = (h > kSoftplusThr2) ? 1.0f : e * __builtin_amdgcn_rcpf(1.0f + e);
-          gh[nt][r] = sg * reinterpret_cast<const f32x4*>(P.w2r0)[g * 4 + nt][r];
+          const float w2u = reinterpret_cast<const f32x4*>(P.w2r0)[g * 4 + nt][r];                // (as in tile_mlp)
+          gh[nt][r] = fmaf(-w2u, __builtin_amdgcn_rcpf(1.0f + e), w2u);
         }
       }
     if constexpr (NRM) normal_contraction(P, lane, gh, Gout[n][0], Gout[n][1]);
@@ -1125,6 +1174,14 @@ __device__ __forceinline__ void tile_mlp_vd(const FieldParams& P, int lane, cons
   tile_epilogue<ATT, N, SEMP>(P, lane, o, outside, sem, res);
 }
 
+// normal map, fp32 texels: forward-mode derivative features from the one gather (1; 0.72 x the plain rate at cfg2) or the corner
+// products of a second, cache-hot gather behind the decoder (0: 0.56 -> 0.60 x; what the other texel storages still do) -
+// profiles/r6/extra_maps_render_times.log
+#ifndef NFI_NORMALS_FORWARD_MODE
+#define NFI_NORMALS_FORWARD_MODE 1
+#endif
+constexpr bool kNormalsForwardMode = NFI_NORMALS_FORWARD_MODE != 0;
+
 struct SampleOut {
   float sdf, sigma, r, g, b;
   float nx, ny, nz;     // field_wave<..., NRM>: normalize(d sdf / d x) of the sample (models/generator.py:609-618)
@@ -1142,10 +1199,12 @@ struct SampleOut {
 // transpose + MLP + epilogue, tiles} filled with s_memtime deltas (profiling builds only)
 // VD: view-direction decoder; xray = padded per-ray features [rays][kRayFeatPad], ray_idx = this lane's ray.
 // NRM (fused renderer, compute_normals): the sample's unit normal normalize(d sdf / d x) - the decoder's distance
-// differentiated analytically: G = W1'^T (sigmoid(h) * W2'[0]) on 32 fp32 MFMAs per tile, then its inner product with the
-// bilinear footprint's corner differences from a second (cache-hot) gather, one plane at a time; the positive factors
-// common to the three axes ((R - 1) / 2 / scene_range, the plane mean's 1/3, the base-2 scalings) drop out of the
-// normalisation.  Border-clamped coordinates carry no gradient, like grid_sample's.
+// differentiated analytically: G = W1'^T (sigmoid(h) * W2'[0]) on 12 split-fp16 MFMAs per tile, times d feature / d axis of the
+// bilinear footprint.  fp32 texels (kNormalsForwardMode): the derivative features come out of the tile's ONE gather
+// (plane_blend_deriv), one tile per turn; 16-bit texels and the view-direction decoder: G's inner products with the corner
+// differences from a second (cache-hot) gather, one plane at a time.  The positive factors common to the three axes (the
+// plane mean's 1/3, the base-2 scalings) drop out of the normalisation.  Border-clamped coordinates carry no gradient,
+// like grid_sample's.
 template <int TEX, bool ATT, bool SKIP, int PREC = 0, bool VD = false, int SEMP = 0, bool NRM = false>
 __device__ __forceinline__ SampleOut field_wave(const FieldParams& P, float scene_range, int lane, float px, float py,
                                                 float pz, bool valid, float* sem_base, bool* outside_flag,
@@ -1214,8 +1273,120 @@ __device__ __forceinline__ SampleOut field_wave(const FieldParams& P, float scen
     __builtin_amdgcn_sched_barrier(0);
     return fcur;
   };
+  // a point's semantics: row [A] of the global output, or its column of the wave's LDS table (SEMP > 0)
+  // (SEMP < 0: a table of 16-bit entries - the pointer only carries the column's address to tile_epilogue)
+  const size_t sem_pt = SEMP != 0 ? (size_t)1 : (size_t)P.n_attention;
+  auto sem_col = [&](int t) -> float* {
+    if constexpr (SEMP < 0) return reinterpret_cast<float*>(reinterpret_cast<unsigned short*>(sem_base) + (16 * t + j));
+    else return sem_base + (size_t)(16 * t + j) * sem_pt;
+  };
+  // the tail of a tile's normals, given this lane's partial (8-channel) coordinate gradients in the L layout
+  auto finish_normals = [&](int t, float (&gcoord)[3]) {
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {                             // sum over the 4 lanes (channel chunks) of the point
+      gcoord[a] += dpp_f32<kDppQuadXor1>(0.0f, gcoord[a]);
+      gcoord[a] += dpp_f32<kDppQuadXor2>(0.0f, gcoord[a]);
+    }
+    const int flL = __shfl(flags, 16 * t + lp, 64);
+    float gx = ((flL >> 2) & 1) ? gcoord[0] : 0.0f, gy = ((flL >> 3) & 1) ? gcoord[1] : 0.0f,
+          gz = ((flL >> 4) & 1) ? gcoord[2] : 0.0f;
+    // F.normalize(x_grad, dim=-1): the common factor (R - 1) / 2 / scene_range is applied first so that the eps clamp
+    // sees the reference's magnitude
+    // (and the launch-wide power of two the staged W2' row carries is taken back: exact)
+    const float sc = ((P.res_m1 * 0.5f) / scene_range) * P.w2r0[64];
+    gx *= sc; gy *= sc; gz *= sc;
+    // (x * (1 / n) for F.normalize's x / n: one reciprocal instead of three IEEE divisions, an ulp inside the map's 3e-5)
+    // (1 / max(n, eps) as rsq(max(n^2, eps^2)): one transcendental instead of sqrt + reciprocal)
+    const float rn = __builtin_amdgcn_rsqf(fmaxf(fmaf(gx, gx, fmaf(gy, gy, gz * gz)), 1e-24f));
+    gx *= rn; gy *= rn; gz *= rn;
+    // the point's lanes 4 p .. 4 p + 3 all hold the result; sample lane 16 t + p takes it from lane 4 p
+    const float sx = __shfl(gx, 4 * j, 64), sy = __shfl(gy, 4 * j, 64), sz = __shfl(gz, 4 * j, 64);
+    if (g == t) { so.nx = sx; so.ny = sy; so.nz = sz; }
+  };
 #pragma unroll 1
   while (tm != 0) {
+    if constexpr (NRM && kNormalsForwardMode && TEX == 0 && !VD) {
+      // ---- the normal map's own schedule: ONE tile per turn; the derivative features d feature / d (x, y, z) come out of
+      // the tile's (only) gather, wait in registers while the decoder runs, and meet G = d sdf / d feature behind it - one turn
+      // later, between the NEXT tile's load issue and its blend, where the gather's latency would otherwise be idle ----
+      int tprev = -1;                       // wave-uniform: the tile whose normals are still owed
+      float dL[3][8];                       // its derivative features (L layout)
+      f32x4 Gp1[2];                         // its G = d sdf / d feature (M layout)
+      auto normals_of_previous = [&]() {
+        f32x4* wr = reinterpret_cast<f32x4*>(stage + j * 36 + g * 4);      // G: M -> L layout through the stage tile
+        wr[0] = Gp1[0]; wr[4] = Gp1[1];
+        wave_lds_fence();
+        float gfL[8];
+        {
+          const f32x4* rd = reinterpret_cast<const f32x4*>(stage + lp * 36 + lq * 4);
+          const f32x4 lo = rd[0], hi = rd[4];
+          gfL[0] = lo.x; gfL[1] = lo.y; gfL[2] = lo.z; gfL[3] = lo.w;
+          gfL[4] = hi.x; gfL[5] = hi.y; gfL[6] = hi.z; gfL[7] = hi.w;
+        }
+        wave_lds_fence();
+        // the lane's 8-channel part of G . d feature / d axis, on channel pairs (v_pk_fma_f32: 12 instead of 24 instructions)
+        typedef float v2f __attribute__((ext_vector_type(2)));
+        float gcoord[3];
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+          v2f acc = {0.0f, 0.0f};
+#pragma unroll
+          for (int s8 = 0; s8 < 8; s8 += 2)
+            acc = __builtin_elementwise_fma((v2f){gfL[s8], gfL[s8 + 1]}, (v2f){dL[a][s8], dL[a][s8 + 1]}, acc);
+          gcoord[a] = acc.x + acc.y;
+        }
+        finish_normals(tprev, gcoord);
+      };
+#pragma unroll 1
+      while (tm != 0) {
+        const int t = __builtin_ctz(tm);
+        tm &= tm - 1;
+        float feat1[1][8];
+        __builtin_amdgcn_s_setprio(3);
+        const int srcL = 16 * t + lp, srcM = 16 * t + j;
+        const float cfx = __shfl(fx, srcL, 64), cfy = __shfl(fy, srcL, 64), cfz = __shfl(fz, srcL, 64);
+        const uint32_t cxi = (uint32_t)__shfl(xi, srcL, 64);
+        const int f1 = __shfl(flags, srcM, 64);
+        float tv[2][4][8];
+        plane_issue<TEX>(P, lq, cxi, 0, tv[0]);
+        plane_issue<TEX>(P, lq, cxi, 1, tv[1]);
+        __builtin_amdgcn_sched_barrier(0);
+        if (tprev >= 0) normals_of_previous();
+        __builtin_amdgcn_sched_barrier(0);
+        float featL[8];
+#pragma unroll
+        for (int s8 = 0; s8 < 8; ++s8) { featL[s8] = 0.0f; dL[0][s8] = 0.0f; dL[1][s8] = 0.0f; dL[2][s8] = 0.0f; }
+        plane_blend_deriv(0, cfx, cfy, cfz, tv[0], featL, dL);
+        pin_deriv_sums(featL, dL);                                         // plane 2's loads stay behind plane 0's sums
+        plane_issue<TEX>(P, lq, cxi, 2, tv[0]);
+        plane_blend_deriv(1, cfx, cfy, cfz, tv[1], featL, dL);
+        plane_blend_deriv(2, cfx, cfy, cfz, tv[0], featL, dL);
+        __builtin_amdgcn_sched_barrier(0);
+        {
+          f32x4* wr = reinterpret_cast<f32x4*>(stage + lp * 36 + lq * 4);
+          wr[0] = f32x4{featL[0], featL[1], featL[2], featL[3]};
+          wr[4] = f32x4{featL[4], featL[5], featL[6], featL[7]};
+          wave_lds_fence();
+          const f32x4* rd = reinterpret_cast<const f32x4*>(stage + j * 36 + g * 4);
+          const f32x4 lo = rd[0], hi = rd[4];
+          feat1[0][0] = lo.x; feat1[0][1] = lo.y; feat1[0][2] = lo.z; feat1[0][3] = lo.w;
+          feat1[0][4] = hi.x; feat1[0][5] = hi.y; feat1[0][6] = hi.z; feat1[0][7] = hi.w;
+          wave_lds_fence();
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(0);
+        const float outs1[1] = {(f1 & 1) ? 1.0f : 0.0f};
+        float* const sems1[1] = {(sem_base && (f1 & 2)) ? sem_col(t) : nullptr};
+        TileOut to1[1];
+        f32x4 G1[1][2];
+        tile_mlp<ATT, 1, PREC, SEMP, true>(P, lane, feat1, outs1, sems1, to1, G1);
+        Gp1[0] = G1[0][0]; Gp1[1] = G1[0][1];
+        tprev = t;
+        if (g == t) { so.sdf = to1[0].sdf; so.sigma = to1[0].sigma; so.r = to1[0].r; so.g = to1[0].g; so.b = to1[0].b; }
+      }
+      if (tprev >= 0) normals_of_previous();
+      return so;
+    }
     unsigned long long c0 = prof ? __builtin_readcyclecounter() : 0;
     const int ta = __builtin_ctz(tm);
     tm &= tm - 1;
@@ -1239,13 +1410,6 @@ __device__ __forceinline__ SampleOut field_wave(const FieldParams& P, float scen
     unsigned long long c2 = prof ? __builtin_readcyclecounter() : 0;
     __builtin_amdgcn_s_setprio(0);
     const float outs[2] = {(fa & 1) ? 1.0f : 0.0f, (fb & 1) ? 1.0f : 0.0f};
-    // a point's semantics: row [A] of the global output, or its column of the wave's LDS table (SEMP > 0)
-    // (SEMP < 0: a table of 16-bit entries - the pointer only carries the column's address to tile_epilogue)
-    const size_t sem_pt = SEMP != 0 ? (size_t)1 : (size_t)P.n_attention;
-    auto sem_col = [&](int t) -> float* {
-      if constexpr (SEMP < 0) return reinterpret_cast<float*>(reinterpret_cast<unsigned short*>(sem_base) + (16 * t + j));
-      else return sem_base + (size_t)(16 * t + j) * sem_pt;
-    };
     float* const sems[2] = {(sem_base && (fa & 2)) ? sem_col(ta) : nullptr, (sem_base && pair && (fb & 2)) ? sem_col(tb) : nullptr};
     TileOut to[2];
     f32x4 Gp[2][2];          // NRM: d(distance) / d(feature) of the pair's tiles (tile_mlp / tile_mlp_vd)
@@ -1284,7 +1448,6 @@ __device__ __forceinline__ SampleOut field_wave(const FieldParams& P, float scen
         const int srcL = 16 * t + lp;
         const float cfx = __shfl(fx, srcL, 64), cfy = __shfl(fy, srcL, 64), cfz = __shfl(fz, srcL, 64);
         const uint32_t cxi = (uint32_t)__shfl(xi, srcL, 64);
-        const int flL = __shfl(flags, srcL, 64);
         float gcoord[3] = {0.0f, 0.0f, 0.0f};
         const uint32_t x0 = cxi & 1023u, y0 = (cxi >> 10) & 1023u, z0 = (cxi >> 20) & 1023u;
         // (round 6, measured: issuing a plane's loads one plane ahead - plane 0 in front of the contraction - costs more in
@@ -1316,23 +1479,7 @@ __device__ __forceinline__ SampleOut field_wave(const FieldParams& P, float scen
           gcoord[(pl == 0) ? 1 : 2] += g_fb;
           __builtin_amdgcn_sched_barrier(0);                    // one plane's 32 texel registers at a time
         }
-#pragma unroll
-        for (int a = 0; a < 3; ++a) {                           // sum over the 4 lanes (channel chunks) of the point
-          gcoord[a] += dpp_f32<kDppQuadXor1>(0.0f, gcoord[a]);
-          gcoord[a] += dpp_f32<kDppQuadXor2>(0.0f, gcoord[a]);
-        }
-        float gx = ((flL >> 2) & 1) ? gcoord[0] : 0.0f, gy = ((flL >> 3) & 1) ? gcoord[1] : 0.0f,
-              gz = ((flL >> 4) & 1) ? gcoord[2] : 0.0f;
-        // F.normalize(x_grad, dim=-1): the common factor (R - 1) / 2 / scene_range is applied first so that the eps clamp
-        // sees the reference's magnitude
-        const float sc = (P.res_m1 * 0.5f) / scene_range;
-        gx *= sc; gy *= sc; gz *= sc;
-        // (x * (1 / n) for F.normalize's x / n: one reciprocal instead of three IEEE divisions, an ulp inside the map's 3e-5)
-        const float rn = 1.0f / fmaxf(norm3(gx, gy, gz), 1e-12f);
-        gx *= rn; gy *= rn; gz *= rn;
-        // the point's lanes 4 p .. 4 p + 3 all hold the result; sample lane 16 t + p takes it from lane 4 p
-        const float sx = __shfl(gx, 4 * j, 64), sy = __shfl(gy, 4 * j, 64), sz = __shfl(gz, 4 * j, 64);
-        if (g == t) { so.nx = sx; so.ny = sy; so.nz = sz; }
+        finish_normals(t, gcoord);
       }
     }
     if (g == ta) { so.sdf = to[0].sdf; so.sigma = to[0].sigma; so.r = to[0].r; so.g = to[0].g; so.b = to[0].b; }
