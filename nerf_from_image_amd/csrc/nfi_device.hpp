@@ -1174,9 +1174,9 @@ __device__ __forceinline__ void tile_mlp_vd(const FieldParams& P, int lane, cons
   tile_epilogue<ATT, N, SEMP>(P, lane, o, outside, sem, res);
 }
 
-// normal map, fp32 texels: forward-mode derivative features from the one gather (1; 0.72 x the plain rate at cfg2) or the corner
-// products of a second, cache-hot gather behind the decoder (0: 0.56 -> 0.60 x; what the other texel storages still do) -
-// profiles/r6/extra_maps_render_times.log
+// normal map: forward-mode derivative features from the one gather (1; 0.72 x the plain rate at cfg2 on fp32 texels, 0.62 x
+// at cfg5 on fp16 texels) or the corner products of a second, cache-hot gather behind the decoder (0: 0.60 / 0.61 x; what the
+// view-direction decoder still does) - profiles/r6/extra_maps_render_times.log
 #ifndef NFI_NORMALS_FORWARD_MODE
 #define NFI_NORMALS_FORWARD_MODE 1
 #endif
@@ -1200,9 +1200,9 @@ struct SampleOut {
 // VD: view-direction decoder; xray = padded per-ray features [rays][kRayFeatPad], ray_idx = this lane's ray.
 // NRM (fused renderer, compute_normals): the sample's unit normal normalize(d sdf / d x) - the decoder's distance
 // differentiated analytically: G = W1'^T (sigmoid(h) * W2'[0]) on 12 split-fp16 MFMAs per tile, times d feature / d axis of the
-// bilinear footprint.  fp32 texels (kNormalsForwardMode): the derivative features come out of the tile's ONE gather
-// (plane_blend_deriv), one tile per turn; 16-bit texels and the view-direction decoder: G's inner products with the corner
-// differences from a second (cache-hot) gather, one plane at a time.  The positive factors common to the three axes (the
+// bilinear footprint.  kNormalsForwardMode: the derivative features come out of the tile's ONE gather (plane_blend_deriv;
+// 16-bit texels are widened at the load there), one tile per turn; the view-direction decoder: G's inner products with the
+// corner differences from a second (cache-hot) gather, one plane at a time.  The positive factors common to the three axes (the
 // plane mean's 1/3, the base-2 scalings) drop out of the normalisation.  Border-clamped coordinates carry no gradient,
 // like grid_sample's.
 template <int TEX, bool ATT, bool SKIP, int PREC = 0, bool VD = false, int SEMP = 0, bool NRM = false>
@@ -1305,7 +1305,7 @@ __device__ __forceinline__ SampleOut field_wave(const FieldParams& P, float scen
   };
 #pragma unroll 1
   while (tm != 0) {
-    if constexpr (NRM && kNormalsForwardMode && TEX == 0 && !VD) {
+    if constexpr (NRM && kNormalsForwardMode && !VD) {
       // ---- the normal map's own schedule: ONE tile per turn; the derivative features d feature / d (x, y, z) come out of
       // the tile's (only) gather, wait in registers while the decoder runs, and meet G = d sdf / d feature behind it - one turn
       // later, between the NEXT tile's load issue and its blend, where the gather's latency would otherwise be idle ----
