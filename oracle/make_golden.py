@@ -379,6 +379,63 @@ def check_cfg1():
             '+32' if fine else '', mask.mean().item()))
 
 
+def check_normals():
+    """The NORMAL MAP of the oracle pinned to the live reference on the CPU: the real Generator renders 2 scenes at 32x32 with
+    16 + 16 samples through run.py::render(compute_normals=True) - normals = normalize(autograd of the SDF w.r.t. the query
+    points), models/generator.py:599-623, composited with detached weights + white background, lib/nerf_utils.py:146-159 -;
+    the oracle's map is what tests/parity_util.oracle_normal_map builds (autograd of the oracle's own field at the oracle's
+    samples, its weights, its permutation).  Same samples bit for bit (same noise), so the maps agree to rounding: the
+    HIP-vs-oracle bound of tests/test_hip_parity.py is then a bound against the reference.  Nothing is written."""
+    B, R, S = 2, 32, 16
+    cfg_args = types.SimpleNamespace(use_viewdir=False, use_sdf=True, attention_values=10, fine_sampling=True)
+    dataset_config = {'scene_range': 0.55, 'white_background': True}
+    render, _ = load_reference_render(cfg_args, dataset_config)
+    torch.manual_seed(1234)
+    gen = ref_gen.Generator(512, 0.55, attention_values=10, use_sdf=True, disable_stylegan_noise=True).eval()
+    g = torch.Generator().manual_seed(6)
+    cam = look_at_cameras(B, 2.0, g)
+    focal = torch.full((B,), 1.0254)
+    z = torch.randn(B, 512, generator=g)
+    with torch.no_grad():
+        probe = (torch.rand(B, 2048, 3, generator=g) * 2 - 1) * 0.55
+        d = gen(None, z, ['sampler'])['sampler'](probe, ['sdf_distance'])['sdf_distance']
+        gen.decoder.net[2].bias[0] -= d.median()
+        gen.alpha.fill_(0.05)
+    gen.requires_grad_(False)
+    seen = {}
+    hook = gen.synthesis_network.register_forward_hook(lambda m, i, o_: seen.__setitem__('planes', o_.detach()))
+    noise_gen = torch.Generator().manual_seed(4321)
+    with NoiseTap(noise_gen) as tap:                                     # (grad mode ON: the reference asserts it)
+        rgb, depth, mask, normals, _, extra = render(gen, R, R, cam, focal, None, None, z, S, compute_normals=True,
+                                                     extra_model_outputs=['attention_values'])
+    hook.remove()
+    assert normals is not None and normals.shape == (B, R, R, 3)
+    planes = seen['planes'].view(B, 3, 32, 256, 256)
+    dec = gen.decoder.net
+    w = [t.detach() for t in (dec[0].weight, dec[0].bias, dec[2].weight, dec[2].bias)]
+    att = extra['attention_values'].detach()
+    with torch.no_grad():
+        o = orc.render(planes, *w, cam, focal, R, R, S, 0.55, white_background=True, fine_sampling=True,
+                       noise_coarse=tap.draws[0], noise_fine=tap.draws[1], use_sdf=True, beta=gen.beta.detach(),
+                       alpha=gen.alpha.detach(), attention_values=att)
+    for k, ref in (('rgb', rgb), ('depth', depth), ('mask', mask)):
+        assert torch.equal(o[k], ref.detach()), ('normals case', k, (o[k] - ref).abs().max().item())
+
+    def oracle_normals(pts):
+        p = pts.clone().requires_grad_()
+        q = orc.field_query(planes, *w, p, 0.55, True, gen.beta.detach(), gen.alpha.detach(), att)
+        gx, = torch.autograd.grad(q['sdf'].sum(), p)
+        return torch.nn.functional.normalize(gx, dim=-1)
+    n_c = oracle_normals(orc.points_on_rays(o['ro'], o['rd'], o['t_coarse']).reshape(B, -1, 3)).view(B, R, R, -1, 3)
+    n_f = oracle_normals(orc.points_on_rays(o['ro'], o['rd'], o['t_fine']).reshape(B, -1, 3)).view(B, R, R, -1, 3)
+    n_all = torch.cat((n_c, n_f), dim=-2).gather(-2, o['perm'].unsqueeze(-1).expand(-1, -1, -1, -1, 3))
+    ours = (o['weights'][..., None] * n_all).sum(dim=-2) + (1. - o['mask'][..., None])
+    err = (ours - normals.detach()).abs().max().item()
+    assert err <= 2e-6, ('normal map', err)
+    print('normal map (B=2, 32x32, 16+16 samples, real Generator): oracle == reference to %.1e (rgb / depth / mask bit for bit); '
+          'mask mean %.3f' % (err, mask.mean().item()))
+
+
 def slice_functions(path, names, g):
     """exec the named top-level functions of a reference file that cannot be imported as a module."""
     tree = ast.parse(open(path).read())
@@ -453,6 +510,8 @@ def neighbours(gold):
 def main():
     if '--cfg1' in sys.argv:
         return check_cfg1()
+    if '--normals' in sys.argv:
+        return check_normals()
     import json
     gold = os.path.join(ROOT, 'tests', 'golden')
     os.makedirs(gold, exist_ok=True)
