@@ -1174,14 +1174,6 @@ __device__ __forceinline__ void tile_mlp_vd(const FieldParams& P, int lane, cons
   tile_epilogue<ATT, N, SEMP>(P, lane, o, outside, sem, res);
 }
 
-// normal map: forward-mode derivative features from the one gather (1; 0.72 x the plain rate at cfg2 on fp32 texels, 0.62 x
-// at cfg5 on fp16 texels) or the corner products of a second, cache-hot gather behind the decoder (0: 0.60 / 0.61 x; what the
-// view-direction decoder still does) - profiles/r6/extra_maps_render_times.log
-#ifndef NFI_NORMALS_FORWARD_MODE
-#define NFI_NORMALS_FORWARD_MODE 1
-#endif
-constexpr bool kNormalsForwardMode = NFI_NORMALS_FORWARD_MODE != 0;
-
 struct SampleOut {
   float sdf, sigma, r, g, b;
   float nx, ny, nz;     // field_wave<..., NRM>: normalize(d sdf / d x) of the sample (models/generator.py:609-618)
@@ -1200,11 +1192,11 @@ struct SampleOut {
 // VD: view-direction decoder; xray = padded per-ray features [rays][kRayFeatPad], ray_idx = this lane's ray.
 // NRM (fused renderer, compute_normals): the sample's unit normal normalize(d sdf / d x) - the decoder's distance
 // differentiated analytically: G = W1'^T (sigmoid(h) * W2'[0]) on 12 split-fp16 MFMAs per tile, times d feature / d axis of the
-// bilinear footprint.  kNormalsForwardMode: the derivative features come out of the tile's ONE gather (plane_blend_deriv;
-// 16-bit texels are widened at the load there), one tile per turn; the view-direction decoder: G's inner products with the
-// corner differences from a second (cache-hot) gather, one plane at a time.  The positive factors common to the three axes (the
-// plane mean's 1/3, the base-2 scalings) drop out of the normalisation.  Border-clamped coordinates carry no gradient,
-// like grid_sample's.
+// bilinear footprint, which comes out of the tile's ONE gather in forward mode (plane_blend_deriv; 16-bit texels are widened
+// at the load there), one tile per turn.  (Round 6's first form took G's inner products with the corner differences from a
+// second, cache-hot gather behind the decoder: 0.56 x the plain rate where this is 0.72 x - profiles/r6/
+// extra_maps_render_times.log.)  The positive factors common to the three axes (the plane mean's 1/3, the base-2 scalings)
+// drop out of the normalisation.  Border-clamped coordinates carry no gradient, like grid_sample's.
 template <int TEX, bool ATT, bool SKIP, int PREC = 0, bool VD = false, int SEMP = 0, bool NRM = false>
 __device__ __forceinline__ SampleOut field_wave(const FieldParams& P, float scene_range, int lane, float px, float py,
                                                 float pz, bool valid, float* sem_base, bool* outside_flag,
@@ -1305,7 +1297,7 @@ __device__ __forceinline__ SampleOut field_wave(const FieldParams& P, float scen
   };
 #pragma unroll 1
   while (tm != 0) {
-    if constexpr (NRM && kNormalsForwardMode && !VD) {
+    if constexpr (NRM) {
       // ---- the normal map's own schedule: ONE tile per turn; the derivative features d feature / d (x, y, z) come out of
       // the tile's (only) gather, wait in registers while the decoder runs, and meet G = d sdf / d feature behind it - one turn
       // later, between the NEXT tile's load issue and its blend, where the gather's latency would otherwise be idle ----
@@ -1379,7 +1371,16 @@ __device__ __forceinline__ SampleOut field_wave(const FieldParams& P, float scen
         float* const sems1[1] = {(sem_base && (f1 & 2)) ? sem_col(t) : nullptr};
         TileOut to1[1];
         f32x4 G1[1][2];
-        tile_mlp<ATT, 1, PREC, SEMP, true>(P, lane, feat1, outs1, sems1, to1, G1);
+        if constexpr (VD) {
+          static_assert(PREC == 0, "the view-direction decoder exists in exact fp32 only");
+          const int r1 = __shfl(ray_idx, 16 * t + j, 64);
+          f32x4 xr1[1][3];
+#pragma unroll
+          for (int c3 = 0; c3 < 3; ++c3) xr1[0][c3] = *reinterpret_cast<const f32x4*>(xray + (size_t)r1 * kRayFeatPad + 16 * c3 + 4 * g);
+          tile_mlp_vd<ATT, 1, SEMP, true>(P, lane, feat1, xr1, outs1, sems1, to1, G1);
+        } else {
+          tile_mlp<ATT, 1, PREC, SEMP, true>(P, lane, feat1, outs1, sems1, to1, G1);
+        }
         Gp1[0] = G1[0][0]; Gp1[1] = G1[0][1];
         tprev = t;
         if (g == t) { so.sdf = to1[0].sdf; so.sigma = to1[0].sigma; so.r = to1[0].r; so.g = to1[0].g; so.b = to1[0].b; }
@@ -1412,7 +1413,7 @@ __device__ __forceinline__ SampleOut field_wave(const FieldParams& P, float scen
     const float outs[2] = {(fa & 1) ? 1.0f : 0.0f, (fb & 1) ? 1.0f : 0.0f};
     float* const sems[2] = {(sem_base && (fa & 2)) ? sem_col(ta) : nullptr, (sem_base && pair && (fb & 2)) ? sem_col(tb) : nullptr};
     TileOut to[2];
-    f32x4 Gp[2][2];          // NRM: d(distance) / d(feature) of the pair's tiles (tile_mlp / tile_mlp_vd)
+    f32x4 Gp[2][2];          // (only the normal map's schedule above asks the decoder for d distance / d feature)
     if constexpr (VD) {
       static_assert(PREC == 0, "the view-direction decoder exists in exact fp32 only");
       const int ra = __shfl(ray_idx, 16 * ta + j, 64), rb = __shfl(ray_idx, 16 * tb + j, 64);
@@ -1422,65 +1423,9 @@ __device__ __forceinline__ SampleOut field_wave(const FieldParams& P, float scen
         xr[0][t] = *reinterpret_cast<const f32x4*>(xray + (size_t)ra * kRayFeatPad + 16 * t + 4 * g);
         xr[1][t] = *reinterpret_cast<const f32x4*>(xray + (size_t)rb * kRayFeatPad + 16 * t + 4 * g);
       }
-      tile_mlp_vd<ATT, 2, SEMP, NRM>(P, lane, feat, xr, outs, sems, to, Gp);
+      tile_mlp_vd<ATT, 2, SEMP, false>(P, lane, feat, xr, outs, sems, to, Gp);
     } else {
-      tile_mlp<ATT, 2, PREC, SEMP, NRM>(P, lane, feat, outs, sems, to, Gp);
-    }
-    if constexpr (NRM) {
-      // ---- normals of the pair's points, one tile at a time ----
-#pragma unroll 1
-      for (int n = 0; n < 2; ++n) {
-        if (n == 1 && !pair) break;
-        const int t = n ? tb : ta;
-        const f32x4 G[2] = {n ? Gp[1][0] : Gp[0][0], n ? Gp[1][1] : Gp[0][1]};
-        // M -> L layout through the stage tile (the mirror image of gather_tile's transpose)
-        f32x4* wr = reinterpret_cast<f32x4*>(stage + j * 36 + g * 4);
-        wr[0] = G[0]; wr[4] = G[1];
-        wave_lds_fence();
-        float gfL[8];
-        {
-          const f32x4* rd = reinterpret_cast<const f32x4*>(stage + lp * 36 + lq * 4);
-          const f32x4 lo = rd[0], hi = rd[4];
-          gfL[0] = lo.x; gfL[1] = lo.y; gfL[2] = lo.z; gfL[3] = lo.w;
-          gfL[4] = hi.x; gfL[5] = hi.y; gfL[6] = hi.z; gfL[7] = hi.w;
-        }
-        wave_lds_fence();
-        const int srcL = 16 * t + lp;
-        const float cfx = __shfl(fx, srcL, 64), cfy = __shfl(fy, srcL, 64), cfz = __shfl(fz, srcL, 64);
-        const uint32_t cxi = (uint32_t)__shfl(xi, srcL, 64);
-        float gcoord[3] = {0.0f, 0.0f, 0.0f};
-        const uint32_t x0 = cxi & 1023u, y0 = (cxi >> 10) & 1023u, z0 = (cxi >> 20) & 1023u;
-        // (round 6, measured: issuing a plane's loads one plane ahead - plane 0 in front of the contraction - costs more in
-        //  spilled registers than the hidden latency returns: 0.54 -> 0.49 x the plain rate)
-#pragma unroll
-        for (int pl = 0; pl < 3; ++pl) {
-          const uint32_t a0 = (pl == 2) ? y0 : x0, b0 = (pl == 0) ? y0 : z0;
-          const uint32_t voff = (uint32_t)pl * P.plane_bytes + __umul24(b0 * (uint32_t)P.res + a0, P.pix_bytes) + (uint32_t)lq * 16u;
-          float tv[4][8];
-          load_texel8<TEX>(P, voff, 0, 0, tv[0]);
-          load_texel8<TEX>(P, voff, P.pix_bytes, 0, tv[1]);
-          load_texel8<TEX>(P, voff, P.row_bytes, 0, tv[2]);
-          load_texel8<TEX>(P, voff, P.row_pix_bytes, 0, tv[3]);
-          const float fa = (pl == 2) ? cfy : cfx, fb = (pl == 0) ? cfy : cfz;
-          const float ga = 1.0f - fa, gb = 1.0f - fb;
-          float dcorner[4];                                     // this lane's 8 channels of the four corner products
-#pragma unroll
-          for (int c = 0; c < 4; ++c) {
-            float acc = 0.0f;
-#pragma unroll
-            for (int s8 = 0; s8 < 8; ++s8) acc = fmaf(gfL[s8], tv[c][s8], acc);
-            dcorner[c] = acc;
-          }
-          // (the bilinear derivative is linear in the corner products and fa, fb are the point's - the same in its four
-          //  lanes -, so the sum over the lanes is taken ONCE per axis behind the planes: 6 cross-lane adds per tile, not 24)
-          const float g_fa = gb * (dcorner[1] - dcorner[0]) + fb * (dcorner[3] - dcorner[2]);
-          const float g_fb = ga * (dcorner[2] - dcorner[0]) + fa * (dcorner[3] - dcorner[1]);
-          gcoord[(pl == 2) ? 1 : 0] += g_fa;                    // plane 0: (x,y)  plane 1: (x,z)  plane 2: (y,z)
-          gcoord[(pl == 0) ? 1 : 2] += g_fb;
-          __builtin_amdgcn_sched_barrier(0);                    // one plane's 32 texel registers at a time
-        }
-        finish_normals(t, gcoord);
-      }
+      tile_mlp<ATT, 2, PREC, SEMP, false>(P, lane, feat, outs, sems, to, Gp);
     }
     if (g == ta) { so.sdf = to[0].sdf; so.sigma = to[0].sigma; so.r = to[0].r; so.g = to[0].g; so.b = to[0].b; }
     if (pair && g == tb) { so.sdf = to[1].sdf; so.sigma = to[1].sigma; so.r = to[1].r; so.g = to[1].g; so.b = to[1].b; }
